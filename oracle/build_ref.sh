@@ -1,0 +1,34 @@
+#!/bin/bash
+# oracle/build_ref.sh -- TEST INFRASTRUCTURE.
+#
+# Builds oracle/_ref/ from the reference sources WHERE THEY LIE under
+# /root/reference (nothing is copied into the repo; oracle/_ref is git-ignored).
+# Only the self-contained inner modules of each file are compiled -- the line
+# ranges that end just before the WRF-facing wrapper modules
+# (MODULE module_ra_rrtmg_lw at LW:11408, MODULE module_ra_rrtmg_sw at SW:9878),
+# because those wrappers USE WRF modules that do not exist here and the round
+# rules forbid stand-ins for them.  The inner modules need no external module;
+# their only external symbol is the error hook wrf_error_fatal, which the
+# harness provides as an abort.
+#
+# -fdefault-real-8 makes kind_rb = kind(1.0) (LW:42) fp64, i.e. a WRF "-r8" build.
+set -euo pipefail
+REF=${REF_ROOT:-/root/reference}/WRF-Chem_code/v3.9.1/phys
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+FC=${FC:-/opt/rocm/lib/llvm/bin/flang}
+if [ ! -d "$REF" ]; then echo "build_ref: $REF not present (GPU box) -- using prebuilt $OUT" >&2; exit 0; fi
+mkdir -p "$OUT"
+FFLAGS="-cpp -ffree-form -fdefault-real-8 -DWRF_CHEM=1 -DEM_CORE=1 -DRWORDSIZE=8 -DIWORDSIZE=4 -O2 -fPIC"
+LW_END=11407   # last line before "MODULE module_ra_rrtmg_lw"
+SW_END=9876    # last line before "MODULE module_ra_rrtmg_sw"
+grep -n -m1 -i '^MODULE module_ra_rrtmg_lw' "$REF/module_ra_rrtmg_lw.F" | grep -q "^$((LW_END+1)):" || { echo "LW line range moved" >&2; exit 1; }
+grep -n -m1 -i '^MODULE module_ra_rrtmg_sw' "$REF/module_ra_rrtmg_sw.F" | grep -q "^$((SW_END+2)):" || { echo "SW line range moved" >&2; exit 1; }
+cd "$OUT"
+sed -n "1,${LW_END}p" "$REF/module_ra_rrtmg_lw.F" | $FC $FFLAGS -c -x f95-cpp-input - -o lw_inner.o -module-dir "$OUT"
+sed -n "1,${SW_END}p" "$REF/module_ra_rrtmg_sw.F" | $FC $FFLAGS -c -x f95-cpp-input - -o sw_inner.o -module-dir "$OUT"
+$FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_sw.F90" sw_inner.o lw_inner.o -o ref_sw -module-dir "$OUT"
+if [ -f "$HERE/ref_harness_lw.F90" ]; then
+  $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_lw.F90" lw_inner.o -o ref_lw -module-dir "$OUT"
+fi
+echo "build_ref: built $(ls $OUT/ref_* | tr '\n' ' ')"

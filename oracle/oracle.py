@@ -1,0 +1,102 @@
+"""ctypes access to the CPU restatement (oracle/liboracle.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+dp = C.POINTER(C.c_double)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.sw_oracle_load.restype = C.c_void_p
+        _LIB.sw_oracle_load.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.c_int]
+        _LIB.sw_oracle_free.argtypes = [C.c_void_p]
+        _LIB.sw_oracle_table.restype = dp
+        _LIB.sw_oracle_table.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_int)]
+        _LIB.sw_oracle_rrtmg_sw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.sw_oracle_swrad_tile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+    return _LIB
+
+
+class SwColumnIn(C.Structure):
+    _fields_ = [("nlay", C.c_int),
+                ("play", dp), ("plev", dp), ("tlay", dp), ("tlev", dp), ("tsfc", C.c_double),
+                ("h2ovmr", dp), ("o3vmr", dp), ("co2vmr", dp), ("ch4vmr", dp), ("n2ovmr", dp), ("o2vmr", dp),
+                ("asdir", C.c_double), ("asdif", C.c_double), ("aldir", C.c_double), ("aldif", C.c_double),
+                ("coszen", C.c_double), ("adjes", C.c_double), ("scon", C.c_double), ("dyofyr", C.c_int),
+                ("tauaer", dp), ("ssaaer", dp), ("asmaer", dp), ("clean_atm_diag", C.c_int)]
+
+
+SW_COL_OUT = ["swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc", "swuflxcln", "swdflxcln",
+              "sibvisdir", "sibvisdif", "sibnirdir", "sibnirdif", "swdkdir", "swdkdif"]
+
+
+class SwColumnOut(C.Structure):
+    _fields_ = [(n, dp) for n in SW_COL_OUT]
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+class SwOracle:
+    CP = 7.0 * 287.0 / 2.0
+
+    def __init__(self, table_path, real_bytes=8, cpdair=None):
+        err = C.create_string_buffer(256)
+        self.h = lib().sw_oracle_load(table_path.encode(), real_bytes, cpdair or self.CP, err, 256)
+        if not self.h:
+            raise RuntimeError(err.value.decode())
+
+    def table(self, band, name):
+        n = C.c_int(0)
+        p = lib().sw_oracle_table(self.h, band, name.encode(), C.byref(n))
+        if not p or n.value == 0:
+            return None
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def rrtmg_sw(self, cols: dict, clean=1) -> dict:
+        """cols: dict of arrays with leading dim ncol (see tools/make_golden.py)."""
+        ncol, nlay = cols["play"].shape
+        out = {n: np.zeros((ncol, nlay if n in ("swhr", "swhrc") else nlay + 1)) for n in SW_COL_OUT}
+        for ic in range(ncol):
+            keep = {k: np.ascontiguousarray(cols[k][ic], dtype=np.float64)
+                    for k in ("play", "plev", "tlay", "tlev", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr",
+                              "o2vmr", "tauaer", "ssaaer", "asmaer")}
+            s = cols["scal"][ic]
+            ci = SwColumnIn(nlay, _p(keep["play"]), _p(keep["plev"]), _p(keep["tlay"]), _p(keep["tlev"]),
+                            float(cols["tsfc"][ic]), _p(keep["h2ovmr"]), _p(keep["o3vmr"]), _p(keep["co2vmr"]),
+                            _p(keep["ch4vmr"]), _p(keep["n2ovmr"]), _p(keep["o2vmr"]),
+                            s[0], s[1], s[2], s[3], s[4], s[5], s[6], 0,
+                            _p(keep["tauaer"]), _p(keep["ssaaer"]), _p(keep["asmaer"]), clean)
+            rows = [np.zeros(out[n].shape[1]) for n in SW_COL_OUT]
+            co = SwColumnOut(*[_p(r) for r in rows])
+            rc = lib().sw_oracle_rrtmg_sw(self.h, C.byref(ci), C.byref(co))
+            if rc:
+                raise RuntimeError(f"sw_oracle_rrtmg_sw rc={rc}")
+            for n, r in zip(SW_COL_OUT, rows):
+                out[n][ic] = r
+        return out
+
+    def close(self):
+        if self.h:
+            lib().sw_oracle_free(self.h)
+            self.h = None

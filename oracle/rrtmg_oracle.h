@@ -1,0 +1,114 @@
+/*
+ * oracle/rrtmg_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, one column at a time, fp64) of the reference's
+ * aerosol + clean-sky RRTMG double call, WRF-Chem v3.9.1 patch set:
+ *   SW:  phys/module_ra_rrtmg_sw.F   (setcoef_sw, taumol_sw, reftra_sw,
+ *        vrtqdr_sw, spcvmc_sw, rrtmg_sw, inatm_sw, rrtmg_sw_ini/cmbgbNN,
+ *        RRTMG_SWRAD pre/post-processing)
+ *   LW:  phys/module_ra_rrtmg_lw.F   (see rrtmg_lw_oracle.c)
+ * Every function cites the reference lines it follows.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.  The shipped HIP path never does.
+ *
+ * Pinning: the column solvers (rrtmg_sw / rrtmg_lw and everything below them,
+ * including the g-point reduction at init) are pinned against the reference
+ * Fortran itself, compiled from /root/reference by oracle/build_ref.sh into
+ * oracle/_ref and run on synthetic tables + columns (tests/golden npz fixtures,
+ * generator tools/make_golden.py).  The WRF-facing wrapper arithmetic
+ * (RRTMG_SWRAD / RRTMG_LWRAD pre- and post-processing) cannot be compiled
+ * here without stand-ins for absent WRF modules, so for those rows the
+ * oracle is "parity unpinned" (restated from the source text only).
+ */
+#ifndef RRTMG_ORACLE_H
+#define RRTMG_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_NBND 14
+#define SW_NGPT 112
+#define SW_JPB1 16
+
+typedef struct SwTables SwTables;
+
+/* rrtmg_swlookuptable + rrtmg_sw_ini (SW:11236-11293, SW:4571-4698):
+ * read a RRTMG_SW_DATA-layout file, reduce 224->112 g-points, build exp_tbl. */
+SwTables *sw_oracle_load(const char *path, int real_bytes, double cpdair, char *err, int errlen);
+void sw_oracle_free(SwTables *t);
+
+/* Reduced table access for parity tests of the init (band = 16..29).
+ * name: "absa","absb","selfref","forref","sfluxref","rayl","rayla","raylb",
+ *       "abso3a","abso3b","absch4","absh2o","absco2","exp_tbl","rwgt".
+ * Returns pointer to doubles in the reference's (Fortran) memory order and
+ * the element count in *n; NULL if the band has no such table. */
+const double *sw_oracle_table(const SwTables *t, int band, const char *name, int *n);
+
+/* One column of rrtmg_sw (SW:8740-9490), cloud-free (icld handling: all
+ * McICA cloud fractions zero), iaer=10, aerosol + clean double call.
+ * Arrays are bottom->top; nlay = number of RRTMG layers (WRF K+1).
+ *   play,tlay,h2ovmr,o3vmr,co2vmr,ch4vmr,n2ovmr,o2vmr : [nlay]
+ *   plev,tlev : [nlay+1]
+ *   tauaer,ssaaer,asmaer : [SW_NBND][nlay]  (band-major)
+ * Outputs: flux arrays [nlay+1], heating [nlay] (K/day). */
+typedef struct {
+    int nlay;
+    const double *play, *plev, *tlay, *tlev;
+    double tsfc;
+    const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
+    double asdir, asdif, aldir, aldif;
+    double coszen, adjes, scon;
+    int dyofyr;
+    const double *tauaer, *ssaaer, *asmaer;
+    int clean_atm_diag;
+} SwColumnIn;
+
+typedef struct {
+    double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
+    double *swuflxcln, *swdflxcln;
+    double *sibvisdir, *sibvisdif, *sibnirdir, *sibnirdif;
+    double *swdkdir, *swdkdif;
+} SwColumnOut;
+
+int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out);
+
+/* RRTMG_SWRAD over a tile (SW:9901-11207), cloud-free path (icloud = 0),
+ * aer_ra_feedback = 1 with the WRF-Chem compact aerosol form, o3input != 2.
+ * WRF memory order, fp64 (a -r8 build): 3-D (ims:ime,kms:kme,jms:jme),
+ * flux profiles (ims:ime,kms:kme+2,jms:jme), 2-D (ims:ime,jms:jme).
+ * Any output pointer may be NULL (== argument not PRESENT). */
+typedef struct {
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    const double *xcoszen, *albedo, *tsk;                    /* 2-D */
+    const double *t3d, *t8w, *p3d, *p8w, *pi3d, *qv3d;       /* 3-D */
+    const double *tauaer300, *tauaer400, *tauaer600, *tauaer999;
+    const double *gaer300, *gaer400, *gaer600, *gaer999;
+    const double *waer300, *waer400, *waer600, *waer999;
+    double solcon;
+    int aer_ra_feedback, clean_atm_diag;
+} SwTileIn;
+
+typedef struct {
+    double *rthratensw;                                      /* 3-D, INOUT */
+    double *gsw, *swcf, *coszr;                              /* 2-D */
+    double *swupt, *swuptc, *swuptcln, *swdnt, *swdntc, *swdntcln;
+    double *swupb, *swupbc, *swupbcln, *swdnb, *swdnbc, *swdnbcln;
+    double *swvisdir, *swvisdif, *swnirdir, *swnirdif;
+    double *swddir, *swddni, *swddif;
+    double *swupflx, *swupflxc, *swupflxcln, *swdnflx, *swdnflxc, *swdnflxcln; /* (i,kms:kme+2,j) */
+} SwTileOut;
+
+/* returns 0, or >0 with a message (the text wrf_error_fatal would get) */
+int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, char *err, int errlen);
+
+/* O3 climatology: INIRAD/O3DATA (LW:12704-12840). plev[nlev=kte-kts+3] in mb
+ * bottom->top, o3prof[kte-kts+2] out (mass mixing ratio). */
+void oracle_inirad(double *o3prof, const double *plev, int nlay_model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

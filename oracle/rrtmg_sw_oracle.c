@@ -1,0 +1,1288 @@
+/*
+ * oracle/rrtmg_sw_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C, one-column-at-a-time, fp64 restatement of the reference shortwave
+ * path (WRF-Chem v3.9.1 patch, phys/module_ra_rrtmg_sw.F, cited as SW:line).
+ * Operation order follows the Fortran expression order so that results can be
+ * compared at the few-ulp level with the reference compiled by
+ * oracle/build_ref.sh.  See rrtmg_oracle.h for the pinning statement.
+ */
+#include "rrtmg_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MG 16
+#define MAXLAY 256
+
+/* ---- g-point reduction maps, SW:4800-4870 (swcmbdat) -------------------- */
+static const int ngc[SW_NBND] = {6, 12, 8, 8, 10, 10, 2, 10, 8, 6, 6, 8, 6, 12};
+static const int ngs[SW_NBND] = {6, 18, 26, 34, 44, 54, 56, 66, 74, 80, 86, 94, 100, 112};
+static const int ngm[SW_NBND * MG] = {
+    1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6,        /* 16 */
+    1, 2, 3, 4, 5, 6, 6, 7, 8, 8, 9, 10, 10, 11, 12, 12,   /* 17 */
+    1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8,        /* 18 */
+    1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8,        /* 19 */
+    1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 10, 10, 10, 10, 10, 10,  /* 20 */
+    1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 10, 10, 10, 10, 10, 10,  /* 21 */
+    1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2,        /* 22 */
+    1, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 9, 10, 10, 10, 10,    /* 23 */
+    1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8,        /* 24 */
+    1, 2, 3, 3, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6,        /* 25 */
+    1, 2, 3, 3, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6,        /* 26 */
+    1, 2, 3, 4, 5, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8,        /* 27 */
+    1, 2, 3, 3, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6,        /* 28 */
+    1, 2, 3, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 10, 11, 12};    /* 29 */
+static const int ngn[SW_NGPT] = {
+    2, 2, 2, 2, 4, 4,                        /* 16 */
+    1, 1, 1, 1, 1, 2, 1, 2, 1, 2, 1, 2,      /* 17 */
+    1, 1, 1, 1, 2, 2, 4, 4,                  /* 18 */
+    1, 1, 1, 1, 2, 2, 4, 4,                  /* 19 */
+    1, 1, 1, 1, 1, 1, 1, 1, 2, 6,            /* 20 */
+    1, 1, 1, 1, 1, 1, 1, 1, 2, 6,            /* 21 */
+    8, 8,                                    /* 22 */
+    2, 2, 1, 1, 1, 1, 1, 1, 2, 4,            /* 23 */
+    2, 2, 2, 2, 2, 2, 2, 2,                  /* 24 */
+    1, 1, 2, 2, 4, 6,                        /* 25 */
+    1, 1, 2, 2, 4, 6,                        /* 26 */
+    1, 1, 1, 1, 1, 1, 4, 6,                  /* 27 */
+    1, 1, 2, 2, 4, 6,                        /* 28 */
+    1, 1, 1, 1, 2, 2, 2, 2, 1, 1, 1, 1};     /* 29 */
+static const double wt[MG] = {
+    0.1527534276, 0.1491729617, 0.1420961469, 0.1316886544, 0.1181945205, 0.1019300893,
+    0.0832767040, 0.0626720116, 0.0424925000, 0.0046269894, 0.0038279891, 0.0030260086,
+    0.0022199750, 0.0014140010, 0.0005330000, 0.0000750000};
+/* SW:4724-4725 */
+static const int nspa[SW_NBND] = {9, 9, 9, 9, 1, 9, 9, 1, 9, 1, 0, 1, 9, 1};
+static const int nspb[SW_NBND] = {1, 5, 1, 1, 1, 5, 1, 0, 1, 0, 0, 1, 5, 1};
+
+/* reference atmosphere, SW:3002-3045 (swatmref): ln(p) and T on 59 levels */
+static const double preflog[59] = {
+    6.9600e+00, 6.7600e+00, 6.5600e+00, 6.3600e+00, 6.1600e+00, 5.9600e+00, 5.7600e+00, 5.5600e+00,
+    5.3600e+00, 5.1600e+00, 4.9600e+00, 4.7600e+00, 4.5600e+00, 4.3600e+00, 4.1600e+00, 3.9600e+00,
+    3.7600e+00, 3.5600e+00, 3.3600e+00, 3.1600e+00, 2.9600e+00, 2.7600e+00, 2.5600e+00, 2.3600e+00,
+    2.1600e+00, 1.9600e+00, 1.7600e+00, 1.5600e+00, 1.3600e+00, 1.1600e+00, 9.6000e-01, 7.6000e-01,
+    5.6000e-01, 3.6000e-01, 1.6000e-01, -4.0000e-02, -2.4000e-01, -4.4000e-01, -6.4000e-01, -8.4000e-01,
+    -1.0400e+00, -1.2400e+00, -1.4400e+00, -1.6400e+00, -1.8400e+00, -2.0400e+00, -2.2400e+00, -2.4400e+00,
+    -2.6400e+00, -2.8400e+00, -3.0400e+00, -3.2400e+00, -3.4400e+00, -3.6400e+00, -3.8400e+00, -4.0400e+00,
+    -4.2400e+00, -4.4400e+00, -4.6400e+00};
+static const double tref[59] = {
+    2.9420e+02, 2.8799e+02, 2.7894e+02, 2.6925e+02, 2.5983e+02, 2.5017e+02, 2.4077e+02, 2.3179e+02,
+    2.2306e+02, 2.1578e+02, 2.1570e+02, 2.1570e+02, 2.1570e+02, 2.1706e+02, 2.1858e+02, 2.2018e+02,
+    2.2174e+02, 2.2328e+02, 2.2479e+02, 2.2655e+02, 2.2834e+02, 2.3113e+02, 2.3401e+02, 2.3703e+02,
+    2.4022e+02, 2.4371e+02, 2.4726e+02, 2.5085e+02, 2.5457e+02, 2.5832e+02, 2.6216e+02, 2.6606e+02,
+    2.6999e+02, 2.7340e+02, 2.7536e+02, 2.7568e+02, 2.7372e+02, 2.7163e+02, 2.6955e+02, 2.6593e+02,
+    2.6211e+02, 2.5828e+02, 2.5360e+02, 2.4854e+02, 2.4348e+02, 2.3809e+02, 2.3206e+02, 2.2603e+02,
+    2.2000e+02, 2.1435e+02, 2.0887e+02, 2.0340e+02, 1.9792e+02, 1.9290e+02, 1.8809e+02, 1.8329e+02,
+    1.7849e+02, 1.7394e+02, 1.7212e+02};
+
+#define NTBL 10000
+
+typedef struct {
+    int ng, nrowa, nrowb, nfor, nsf, layreffr;
+    double rayl, strrat, givfac, scalekur;
+    double *absa, *absb, *selfref, *forref, *sfluxref;
+    double *rayl_g, *rayla, *raylb, *abso3a, *abso3b, *absch4, *absh2o, *absco2;
+} SwBand;
+
+struct SwTables {
+    SwBand b[SW_NBND];
+    double rwgt[SW_NBND * MG];
+    double exp_tbl[NTBL + 1];
+    double bpade, heatfac, oneminus;
+};
+
+/* ------------------------------------------------------------------------ */
+/* file reader                                                              */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const unsigned char *p, *end;
+    int rb;
+    int bad;
+} Cur;
+
+static double rd_real(Cur *c)
+{
+    if (c->p + c->rb > c->end) { c->bad = 1; return 0.0; }
+    double v;
+    if (c->rb == 8) { memcpy(&v, c->p, 8); } else { float f; memcpy(&f, c->p, 4); v = f; }
+    c->p += c->rb;
+    return v;
+}
+static int rd_int(Cur *c)
+{
+    if (c->p + 4 > c->end) { c->bad = 1; return 0; }
+    int32_t v; memcpy(&v, c->p, 4); c->p += 4;
+    return v;
+}
+static double *rd_arr(Cur *c, size_t n)
+{
+    double *a = (double *)malloc(n * sizeof(double));
+    for (size_t i = 0; i < n; ++i) a[i] = rd_real(c);
+    return a;
+}
+
+/* weighted g-point reduction of a [16][nrow] table into [ng][nrow]:
+ * the inner loops of cmbgbNN, e.g. SW:5049-5062 */
+static double *reduce_w(const double *src, int nrow, int ibnd, const double *rwgt)
+{
+    int ng = ngc[ibnd];
+    int g0 = ibnd == 0 ? 0 : ngs[ibnd - 1];
+    double *dst = (double *)malloc((size_t)ng * nrow * sizeof(double));
+    for (int r = 0; r < nrow; ++r) {
+        int iprsm = 0;
+        for (int igc = 0; igc < ng; ++igc) {
+            double sumk = 0.;
+            for (int ipr = 0; ipr < ngn[g0 + igc]; ++ipr) {
+                sumk = sumk + src[(size_t)iprsm * nrow + r] * rwgt[iprsm + ibnd * MG];
+                ++iprsm;
+            }
+            dst[(size_t)igc * nrow + r] = sumk;
+        }
+    }
+    return dst;
+}
+/* reduction of per-g vectors stored g-fastest: src[j][16] -> dst[j][ng];
+ * weighted (rayl, abs*) or plain sum (sfluxref), e.g. SW:5103-5111 */
+static double *reduce_g(const double *src, int nj, int ibnd, const double *rwgt, int weighted)
+{
+    int ng = ngc[ibnd];
+    int g0 = ibnd == 0 ? 0 : ngs[ibnd - 1];
+    double *dst = (double *)malloc((size_t)ng * nj * sizeof(double));
+    for (int j = 0; j < nj; ++j) {
+        int iprsm = 0;
+        for (int igc = 0; igc < ng; ++igc) {
+            double sumf = 0.;
+            for (int ipr = 0; ipr < ngn[g0 + igc]; ++ipr) {
+                if (weighted) sumf = sumf + src[j * MG + iprsm] * rwgt[iprsm + ibnd * MG];
+                else sumf = sumf + src[j * MG + iprsm];
+                ++iprsm;
+            }
+            dst[j * ng + igc] = sumf;
+        }
+    }
+    return dst;
+}
+
+static const int nfor_b[SW_NBND] = {3, 4, 3, 3, 4, 4, 3, 3, 3, 0, 0, 0, 0, 4};
+static const int nsf_b[SW_NBND] = {1, 5, 9, 9, 1, 9, 9, 1, 9, 1, 1, 1, 5, 1};
+
+SwTables *sw_oracle_load(const char *path, int real_bytes, double cpdair, char *err, int errlen)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { if (err) snprintf(err, errlen, "cannot open %s", path); return NULL; }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char *buf = (unsigned char *)malloc(sz);
+    if (fread(buf, 1, sz, f) != (size_t)sz) { fclose(f); free(buf); return NULL; }
+    fclose(f);
+
+    SwTables *t = (SwTables *)calloc(1, sizeof(SwTables));
+    /* swdatinit, SW:4732,4749,4756,4788 */
+    const double grav = 9.8066, secdy = 8.6400e4;
+    t->oneminus = 1.0 - 1.e-06;
+    t->heatfac = grav * secdy / (cpdair * 1.e2);
+
+    /* exp lookup table, SW:4640-4648 */
+    const double pade = 0.278, expeps = 1.e-20;
+    t->exp_tbl[0] = 1.0;
+    t->exp_tbl[NTBL] = expeps;
+    t->bpade = 1.0 / pade;
+    for (int itr = 1; itr <= NTBL - 1; ++itr) {
+        double tfn = (double)itr / (double)NTBL;
+        double tau_tbl = t->bpade * tfn / (1. - tfn);
+        t->exp_tbl[itr] = exp(-tau_tbl);
+        if (t->exp_tbl[itr] <= expeps) t->exp_tbl[itr] = expeps;
+    }
+
+    /* relative weights, SW:4655-4681 */
+    {
+        int igcsm = 0;
+        for (int ibnd = 0; ibnd < SW_NBND; ++ibnd) {
+            int iprsm = 0;
+            double wtsm[MG];
+            if (ngc[ibnd] < MG) {
+                for (int igc = 0; igc < ngc[ibnd]; ++igc) {
+                    double wtsum = 0.;
+                    for (int ipr = 0; ipr < ngn[igcsm]; ++ipr) { wtsum = wtsum + wt[iprsm]; ++iprsm; }
+                    ++igcsm;
+                    wtsm[igc] = wtsum;
+                }
+                for (int ig = 0; ig < MG; ++ig) {
+                    int ind = ibnd * MG + ig;
+                    t->rwgt[ind] = wt[ig] / wtsm[ngm[ind] - 1];
+                }
+            } else {
+                for (int ig = 0; ig < MG; ++ig) { ++igcsm; t->rwgt[ibnd * MG + ig] = 1.0; }
+            }
+        }
+    }
+
+    Cur c = {buf, buf + sz, real_bytes, 0};
+    for (int ib = 0; ib < SW_NBND; ++ib) {
+        SwBand *b = &t->b[ib];
+        int band = ib + SW_JPB1;
+        b->ng = ngc[ib];
+        b->nrowa = nspa[ib] * 65;
+        b->nrowb = nspb[ib] * 235;
+        b->nfor = nfor_b[ib];
+        b->nsf = nsf_b[ib];
+        if (c.p + 4 > c.end) { c.bad = 1; break; }
+        int32_t reclen; memcpy(&reclen, c.p, 4); c.p += 4;
+        const unsigned char *rec_end = c.p + reclen;
+        double *kao = NULL, *kbo = NULL, *selfo = NULL, *foro = NULL, *sflo = NULL;
+        double *raylo = NULL, *raylao = NULL, *raylbo = NULL, *o3ao = NULL, *o3bo = NULL;
+        double *ch4o = NULL, *h2oo = NULL, *co2o = NULL;
+        /* record field orders: SW:11379,11462,...,12365 */
+        switch (band) {
+        case 16: case 17: case 18: case 19: case 21: case 22: case 28:
+            b->rayl = rd_real(&c); b->strrat = rd_real(&c); b->layreffr = rd_int(&c);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); kbo = rd_arr(&c, (size_t)b->nrowb * MG);
+            if (band != 28) { selfo = rd_arr(&c, 10 * MG); foro = rd_arr(&c, b->nfor * MG); }
+            sflo = rd_arr(&c, MG * b->nsf);
+            break;
+        case 20:
+            b->rayl = rd_real(&c); b->layreffr = rd_int(&c); ch4o = rd_arr(&c, MG);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); kbo = rd_arr(&c, (size_t)b->nrowb * MG);
+            selfo = rd_arr(&c, 10 * MG); foro = rd_arr(&c, b->nfor * MG); sflo = rd_arr(&c, MG);
+            break;
+        case 23:
+            raylo = rd_arr(&c, MG); b->givfac = rd_real(&c); b->layreffr = rd_int(&c);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG);
+            selfo = rd_arr(&c, 10 * MG); foro = rd_arr(&c, b->nfor * MG); sflo = rd_arr(&c, MG);
+            break;
+        case 24:
+            raylao = rd_arr(&c, MG * 9); raylbo = rd_arr(&c, MG); b->strrat = rd_real(&c);
+            b->layreffr = rd_int(&c); o3ao = rd_arr(&c, MG); o3bo = rd_arr(&c, MG);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); kbo = rd_arr(&c, (size_t)b->nrowb * MG);
+            selfo = rd_arr(&c, 10 * MG); foro = rd_arr(&c, b->nfor * MG); sflo = rd_arr(&c, MG * 9);
+            break;
+        case 25:
+            raylo = rd_arr(&c, MG); b->layreffr = rd_int(&c); o3ao = rd_arr(&c, MG); o3bo = rd_arr(&c, MG);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); sflo = rd_arr(&c, MG);
+            break;
+        case 26:
+            raylo = rd_arr(&c, MG); sflo = rd_arr(&c, MG);
+            break;
+        case 27:
+            raylo = rd_arr(&c, MG); b->scalekur = rd_real(&c); b->layreffr = rd_int(&c);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); kbo = rd_arr(&c, (size_t)b->nrowb * MG);
+            sflo = rd_arr(&c, MG);
+            break;
+        case 29:
+            b->rayl = rd_real(&c); b->layreffr = rd_int(&c); h2oo = rd_arr(&c, MG); co2o = rd_arr(&c, MG);
+            kao = rd_arr(&c, (size_t)b->nrowa * MG); kbo = rd_arr(&c, (size_t)b->nrowb * MG);
+            selfo = rd_arr(&c, 10 * MG); foro = rd_arr(&c, b->nfor * MG); sflo = rd_arr(&c, MG);
+            break;
+        }
+        if (c.bad || c.p != rec_end) {
+            if (err) snprintf(err, errlen, "RRTMG_SW_DATA: bad record for band %d", band);
+            free(buf); return NULL;
+        }
+        c.p += 4; /* trailing marker */
+        /* cmbgb16s..cmbgb29, SW:5022-6065 */
+        if (kao) b->absa = reduce_w(kao, b->nrowa, ib, t->rwgt);
+        if (kbo) b->absb = reduce_w(kbo, b->nrowb, ib, t->rwgt);
+        if (selfo) b->selfref = reduce_w(selfo, 10, ib, t->rwgt);
+        if (foro) b->forref = reduce_w(foro, b->nfor, ib, t->rwgt);
+        if (sflo) b->sfluxref = reduce_g(sflo, b->nsf, ib, t->rwgt, 0);
+        if (raylo) b->rayl_g = reduce_g(raylo, 1, ib, t->rwgt, 1);
+        if (raylao) b->rayla = reduce_g(raylao, 9, ib, t->rwgt, 1);
+        if (raylbo) b->raylb = reduce_g(raylbo, 1, ib, t->rwgt, 1);
+        if (o3ao) b->abso3a = reduce_g(o3ao, 1, ib, t->rwgt, 1);
+        if (o3bo) b->abso3b = reduce_g(o3bo, 1, ib, t->rwgt, 1);
+        if (ch4o) b->absch4 = reduce_g(ch4o, 1, ib, t->rwgt, 1);
+        if (h2oo) b->absh2o = reduce_g(h2oo, 1, ib, t->rwgt, 1);
+        if (co2o) b->absco2 = reduce_g(co2o, 1, ib, t->rwgt, 1);
+        free(kao); free(kbo); free(selfo); free(foro); free(sflo); free(raylo); free(raylao);
+        free(raylbo); free(o3ao); free(o3bo); free(ch4o); free(h2oo); free(co2o);
+    }
+    free(buf);
+    if (c.bad) { if (err) snprintf(err, errlen, "RRTMG_SW_DATA: truncated"); return NULL; }
+    return t;
+}
+
+void sw_oracle_free(SwTables *t)
+{
+    if (!t) return;
+    for (int ib = 0; ib < SW_NBND; ++ib) {
+        SwBand *b = &t->b[ib];
+        free(b->absa); free(b->absb); free(b->selfref); free(b->forref); free(b->sfluxref);
+        free(b->rayl_g); free(b->rayla); free(b->raylb); free(b->abso3a); free(b->abso3b);
+        free(b->absch4); free(b->absh2o); free(b->absco2);
+    }
+    free(t);
+}
+
+const double *sw_oracle_table(const SwTables *t, int band, const char *name, int *n)
+{
+    if (!strcmp(name, "exp_tbl")) { *n = NTBL + 1; return t->exp_tbl; }
+    if (!strcmp(name, "rwgt")) { *n = SW_NBND * MG; return t->rwgt; }
+    const SwBand *b = &t->b[band - SW_JPB1];
+#define TB(nm, ptr, cnt) if (!strcmp(name, nm)) { *n = (ptr) ? (cnt) : 0; return (ptr); }
+    TB("absa", b->absa, b->ng * b->nrowa)
+    TB("absb", b->absb, b->ng * b->nrowb)
+    TB("selfref", b->selfref, b->ng * 10)
+    TB("forref", b->forref, b->ng * b->nfor)
+    TB("sfluxref", b->sfluxref, b->ng * b->nsf)
+    TB("rayl", b->rayl_g, b->ng)
+    TB("rayla", b->rayla, b->ng * 9)
+    TB("raylb", b->raylb, b->ng)
+    TB("abso3a", b->abso3a, b->ng)
+    TB("abso3b", b->abso3b, b->ng)
+    TB("absch4", b->absch4, b->ng)
+    TB("absh2o", b->absh2o, b->ng)
+    TB("absco2", b->absco2, b->ng)
+#undef TB
+    *n = 0;
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-column work state (1-based arrays like the Fortran)                  */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    int nlayers, laytrop, laylow;
+    int jp[MAXLAY], jt[MAXLAY], jt1[MAXLAY], indself[MAXLAY], indfor[MAXLAY];
+    double pavel[MAXLAY], tavel[MAXLAY], pz[MAXLAY], tz[MAXLAY], pdp[MAXLAY], coldry[MAXLAY];
+    double wkl[8][MAXLAY];
+    double colh2o[MAXLAY], colco2[MAXLAY], colo3[MAXLAY], coln2o[MAXLAY], colch4[MAXLAY], colo2[MAXLAY],
+        colmol[MAXLAY];
+    double fac00[MAXLAY], fac01[MAXLAY], fac10[MAXLAY], fac11[MAXLAY];
+    double selffac[MAXLAY], selffrac[MAXLAY], forfac[MAXLAY], forfrac[MAXLAY];
+    double taug[SW_NGPT][MAXLAY], taur[SW_NGPT][MAXLAY], sfluxzen[SW_NGPT];
+} SwCol;
+
+/* setcoef_sw, SW:2734-2990 */
+static void setcoef_sw(SwCol *c)
+{
+    const double stpfac = 296. / 1013.;
+    c->laytrop = 0;
+    c->laylow = 0;
+    for (int lay = 1; lay <= c->nlayers; ++lay) {
+        double plog = log(c->pavel[lay]);
+        c->jp[lay] = (int)(36. - 5 * (plog + 0.04));
+        if (c->jp[lay] < 1) c->jp[lay] = 1;
+        else if (c->jp[lay] > 58) c->jp[lay] = 58;
+        int jp1 = c->jp[lay] + 1;
+        double fp = 5. * (preflog[c->jp[lay] - 1] - plog);
+
+        c->jt[lay] = (int)(3. + (c->tavel[lay] - tref[c->jp[lay] - 1]) / 15.);
+        if (c->jt[lay] < 1) c->jt[lay] = 1;
+        else if (c->jt[lay] > 4) c->jt[lay] = 4;
+        double ft = ((c->tavel[lay] - tref[c->jp[lay] - 1]) / 15.) - (double)(c->jt[lay] - 3);
+        c->jt1[lay] = (int)(3. + (c->tavel[lay] - tref[jp1 - 1]) / 15.);
+        if (c->jt1[lay] < 1) c->jt1[lay] = 1;
+        else if (c->jt1[lay] > 4) c->jt1[lay] = 4;
+        double ft1 = ((c->tavel[lay] - tref[jp1 - 1]) / 15.) - (double)(c->jt1[lay] - 3);
+
+        double water = c->wkl[1][lay] / c->coldry[lay];
+        double scalefac = c->pavel[lay] * stpfac / c->tavel[lay];
+        double factor;
+        if (plog > 4.56) {
+            c->laytrop = c->laytrop + 1;
+            if (plog >= 6.62) c->laylow = c->laylow + 1;
+            c->forfac[lay] = scalefac / (1. + water);
+            factor = (332.0 - c->tavel[lay]) / 36.0;
+            int ifac = (int)factor;
+            c->indfor[lay] = ifac > 1 ? (ifac < 2 ? ifac : 2) : 1; /* min(2,max(1,int(factor))) */
+            c->forfrac[lay] = factor - (double)c->indfor[lay];
+            c->selffac[lay] = water * c->forfac[lay];
+            factor = (c->tavel[lay] - 188.0) / 7.2;
+            int is = (int)factor - 7;
+            c->indself[lay] = is > 1 ? (is < 9 ? is : 9) : 1;     /* min(9,max(1,int(factor)-7)) */
+            c->selffrac[lay] = factor - (double)(c->indself[lay] + 7);
+        } else {
+            c->forfac[lay] = scalefac / (1. + water);
+            factor = (c->tavel[lay] - 188.0) / 36.0;
+            c->indfor[lay] = 3;
+            c->forfrac[lay] = factor - 1.0;
+            c->selffac[lay] = 0.;
+            c->selffrac[lay] = 0.;
+            c->indself[lay] = 0;
+        }
+        c->colh2o[lay] = 1.e-20 * c->wkl[1][lay];
+        c->colco2[lay] = 1.e-20 * c->wkl[2][lay];
+        c->colo3[lay] = 1.e-20 * c->wkl[3][lay];
+        c->coln2o[lay] = 1.e-20 * c->wkl[4][lay];
+        c->colch4[lay] = 1.e-20 * c->wkl[6][lay];
+        c->colo2[lay] = 1.e-20 * c->wkl[7][lay];
+        c->colmol[lay] = 1.e-20 * c->coldry[lay] + c->colh2o[lay];
+        if (c->colco2[lay] == 0.) c->colco2[lay] = 1.e-32 * c->coldry[lay];
+        if (c->coln2o[lay] == 0.) c->coln2o[lay] = 1.e-32 * c->coldry[lay];
+        if (c->colch4[lay] == 0.) c->colch4[lay] = 1.e-32 * c->coldry[lay];
+        if (c->colo2[lay] == 0.) c->colo2[lay] = 1.e-32 * c->coldry[lay];
+        /* co2mult (SW:2922-2924) is computed by the reference but never read
+         * on the shortwave path; omitted. */
+        double compfp = 1. - fp;
+        c->fac10[lay] = compfp * ft;
+        c->fac00[lay] = compfp * (1. - ft);
+        c->fac11[lay] = fp * ft1;
+        c->fac01[lay] = fp * (1. - ft1);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* taumol_sw, SW:3081-4540                                                  */
+/* ------------------------------------------------------------------------ */
+#define ABSA(ind, ig) b->absa[(size_t)((ig)-1) * b->nrowa + ((ind)-1)]
+#define ABSB(ind, ig) b->absb[(size_t)((ig)-1) * b->nrowb + ((ind)-1)]
+#define SELF(i, ig) b->selfref[((ig)-1) * 10 + ((i)-1)]
+#define FORR(i, ig) b->forref[((ig)-1) * b->nfor + ((i)-1)]
+#define SFLUX(ig, js) b->sfluxref[((js)-1) * b->ng + ((ig)-1)]
+
+typedef struct {
+    double speccomb, fs;
+    int js;
+    double fac000, fac010, fac100, fac110, fac001, fac011, fac101, fac111;
+} Bin;
+
+/* binary-species interpolation factors, e.g. SW:3321-3334 */
+static Bin binary(const SwCol *c, int lay, double cola, double colb_scaled, double mult, double oneminus)
+{
+    Bin r;
+    r.speccomb = cola + colb_scaled;
+    double specparm = cola / r.speccomb;
+    if (specparm >= oneminus) specparm = oneminus;
+    double specmult = mult * (specparm);
+    r.js = 1 + (int)specmult;
+    r.fs = fmod(specmult, 1.);
+    r.fac000 = (1. - r.fs) * c->fac00[lay];
+    r.fac010 = (1. - r.fs) * c->fac10[lay];
+    r.fac100 = r.fs * c->fac00[lay];
+    r.fac110 = r.fs * c->fac10[lay];
+    r.fac001 = (1. - r.fs) * c->fac01[lay];
+    r.fac011 = (1. - r.fs) * c->fac11[lay];
+    r.fac101 = r.fs * c->fac01[lay];
+    r.fac111 = r.fs * c->fac11[lay];
+    return r;
+}
+
+#define SUM8A(q, ind0, ind1, ig)                                                                      \
+    ((q).fac000 * ABSA(ind0, ig) + (q).fac100 * ABSA((ind0) + 1, ig) + (q).fac010 * ABSA((ind0) + 9, ig) + \
+     (q).fac110 * ABSA((ind0) + 10, ig) + (q).fac001 * ABSA(ind1, ig) + (q).fac101 * ABSA((ind1) + 1, ig) + \
+     (q).fac011 * ABSA((ind1) + 9, ig) + (q).fac111 * ABSA((ind1) + 10, ig))
+#define SUM8B(q, ind0, ind1, ig)                                                                      \
+    ((q).fac000 * ABSB(ind0, ig) + (q).fac100 * ABSB((ind0) + 1, ig) + (q).fac010 * ABSB((ind0) + 5, ig) + \
+     (q).fac110 * ABSB((ind0) + 6, ig) + (q).fac001 * ABSB(ind1, ig) + (q).fac101 * ABSB((ind1) + 1, ig) + \
+     (q).fac011 * ABSB((ind1) + 5, ig) + (q).fac111 * ABSB((ind1) + 6, ig))
+#define SUM4A(ind0, ind1, ig)                                                                          \
+    (c->fac00[lay] * ABSA(ind0, ig) + c->fac10[lay] * ABSA((ind0) + 1, ig) + c->fac01[lay] * ABSA(ind1, ig) + \
+     c->fac11[lay] * ABSA((ind1) + 1, ig))
+#define SUM4B(ind0, ind1, ig)                                                                          \
+    (c->fac00[lay] * ABSB(ind0, ig) + c->fac10[lay] * ABSB((ind0) + 1, ig) + c->fac01[lay] * ABSB(ind1, ig) + \
+     c->fac11[lay] * ABSB((ind1) + 1, ig))
+#define SELFTERM(ig) (c->selffac[lay] * (SELF(inds, ig) + c->selffrac[lay] * (SELF(inds + 1, ig) - SELF(inds, ig))))
+#define FORTERM(ig) (c->forfac[lay] * (FORR(indf, ig) + c->forfrac[lay] * (FORR(indf + 1, ig) - FORR(indf, ig))))
+
+/* bands with binary species below laytrop and a single species above:
+ * taumol16 (SW:3293), 18 (SW:3507), 19, 22 (o2 continuum), 24 (o3 + rayleigh) */
+static void taumol_sw(const SwTables *t, SwCol *c)
+{
+    const int nl = c->nlayers, laytrop = c->laytrop;
+    const double oneminus = t->oneminus;
+    for (int ib = 0; ib < SW_NBND; ++ib) {
+        const SwBand *b = &t->b[ib];
+        const int band = ib + SW_JPB1;
+        const int g0 = ib == 0 ? 0 : ngs[ib - 1];
+        const int ng = b->ng;
+        int laysolfr;
+        const int lower_solar = !(band == 16 || band == 17 || band == 27 || band == 28 || band == 29);
+        /* bands 18-26 pick the solar-source layer in the lower loop (e.g. SW:3533-3538),
+         * bands 16,17,27,28,29 in the upper loop (e.g. SW:3363-3368). */
+        laysolfr = lower_solar ? laytrop : nl;
+
+        /* ---------------- lower atmosphere ---------------- */
+        for (int lay = 1; lay <= laytrop; ++lay) {
+            if (lower_solar && band != 26) {
+                if (c->jp[lay] < b->layreffr && c->jp[lay + 1] >= b->layreffr)
+                    laysolfr = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+            }
+            int inds = c->indself[lay], indf = c->indfor[lay];
+            int ind0, ind1;
+            double tauray;
+            Bin q;
+            switch (band) {
+            case 16: case 17: case 18: case 19: case 21: {
+                double colb = (band == 16 || band == 18) ? c->colch4[lay] : c->colco2[lay];
+                q = binary(c, lay, c->colh2o[lay], b->strrat * colb, 8., oneminus);
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + q.js;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + q.js;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] =
+                        q.speccomb * SUM8A(q, ind0, ind1, ig) + c->colh2o[lay] * (SELFTERM(ig) + FORTERM(ig));
+                    if (band != 16 && band != 17 && lay == laysolfr)
+                        c->sfluxzen[g0 + ig - 1] = SFLUX(ig, q.js) + q.fs * (SFLUX(ig, q.js + 1) - SFLUX(ig, q.js));
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 22: {
+                const double o2adj = 1.6;
+                double o2cont = 4.35e-4 * c->colo2[lay] / (350.0 * 2.0);
+                q = binary(c, lay, c->colh2o[lay], o2adj * b->strrat * c->colo2[lay], 8., oneminus);
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + q.js;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + q.js;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = q.speccomb * SUM8A(q, ind0, ind1, ig) +
+                                                c->colh2o[lay] * (SELFTERM(ig) + FORTERM(ig)) + o2cont;
+                    if (lay == laysolfr)
+                        c->sfluxzen[g0 + ig - 1] = SFLUX(ig, q.js) + q.fs * (SFLUX(ig, q.js + 1) - SFLUX(ig, q.js));
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 24: {
+                q = binary(c, lay, c->colh2o[lay], b->strrat * c->colo2[lay], 8., oneminus);
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + q.js;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + q.js;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    double ra0 = b->rayla[(q.js - 1) * ng + ig - 1], ra1 = b->rayla[q.js * ng + ig - 1];
+                    tauray = c->colmol[lay] * (ra0 + q.fs * (ra1 - ra0));
+                    c->taug[g0 + ig - 1][lay] = q.speccomb * SUM8A(q, ind0, ind1, ig) +
+                                                c->colo3[lay] * b->abso3a[ig - 1] +
+                                                c->colh2o[lay] * (SELFTERM(ig) + FORTERM(ig));
+                    if (lay == laysolfr)
+                        c->sfluxzen[g0 + ig - 1] = SFLUX(ig, q.js) + q.fs * (SFLUX(ig, q.js + 1) - SFLUX(ig, q.js));
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 28: {
+                q = binary(c, lay, c->colo3[lay], b->strrat * c->colo2[lay], 8., oneminus);
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + q.js;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + q.js;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = q.speccomb * SUM8A(q, ind0, ind1, ig);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 20: case 29: {
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + 1;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + 1;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    double minor = band == 20 ? c->colch4[lay] * b->absch4[ig - 1] : c->colco2[lay] * b->absco2[ig - 1];
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colh2o[lay] * ((SUM4A(ind0, ind1, ig)) + SELFTERM(ig) + FORTERM(ig)) + minor;
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                    if (band == 20 && lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                }
+                break;
+            }
+            case 23: {
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + 1;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + 1;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->rayl_g[ig - 1];
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colh2o[lay] * (b->givfac * SUM4A(ind0, ind1, ig) + SELFTERM(ig) + FORTERM(ig));
+                    if (lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 25: {
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + 1;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + 1;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->rayl_g[ig - 1];
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colh2o[lay] * SUM4A(ind0, ind1, ig) + c->colo3[lay] * b->abso3a[ig - 1];
+                    if (lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 26: {
+                for (int ig = 1; ig <= ng; ++ig) {
+                    if (lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                    c->taug[g0 + ig - 1][lay] = 0.;
+                    c->taur[g0 + ig - 1][lay] = c->colmol[lay] * b->rayl_g[ig - 1];
+                }
+                break;
+            }
+            case 27: {
+                ind0 = ((c->jp[lay] - 1) * 5 + (c->jt[lay] - 1)) * nspa[ib] + 1;
+                ind1 = (c->jp[lay] * 5 + (c->jt1[lay] - 1)) * nspa[ib] + 1;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->rayl_g[ig - 1];
+                    c->taug[g0 + ig - 1][lay] = c->colo3[lay] * SUM4A(ind0, ind1, ig);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            }
+        }
+
+        /* ---------------- upper atmosphere ---------------- */
+        for (int lay = laytrop + 1; lay <= nl; ++lay) {
+            if (!lower_solar) {
+                if (c->jp[lay - 1] < b->layreffr && c->jp[lay] >= b->layreffr) laysolfr = lay;
+            }
+            int indf = c->indfor[lay];
+            int ind0, ind1;
+            double tauray;
+            Bin q;
+            switch (band) {
+            case 16: case 18: case 19: {
+                double col = band == 19 ? c->colco2[lay] : c->colch4[lay];
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = col * SUM4B(ind0, ind1, ig);
+                    if (band == 16 && lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 17: case 21: {
+                q = binary(c, lay, c->colh2o[lay], b->strrat * c->colco2[lay], 4., oneminus);
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + q.js;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + q.js;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] =
+                        q.speccomb * SUM8B(q, ind0, ind1, ig) + c->colh2o[lay] * FORTERM(ig);
+                    if (band == 17 && lay == laysolfr)
+                        c->sfluxzen[g0 + ig - 1] = SFLUX(ig, q.js) + q.fs * (SFLUX(ig, q.js + 1) - SFLUX(ig, q.js));
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 20: {
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colh2o[lay] * (c->fac00[lay] * ABSB(ind0, ig) + c->fac10[lay] * ABSB(ind0 + 1, ig) +
+                                          c->fac01[lay] * ABSB(ind1, ig) + c->fac11[lay] * ABSB(ind1 + 1, ig) +
+                                          FORTERM(ig)) +
+                        c->colch4[lay] * b->absch4[ig - 1];
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 22: {
+                const double o2adj = 1.6;
+                double o2cont = 4.35e-4 * c->colo2[lay] / (350.0 * 2.0);
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = c->colo2[lay] * o2adj * SUM4B(ind0, ind1, ig) + o2cont;
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 23: case 26: {
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = 0.;
+                    c->taur[g0 + ig - 1][lay] = c->colmol[lay] * b->rayl_g[ig - 1];
+                }
+                break;
+            }
+            case 24: {
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->raylb[ig - 1];
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colo2[lay] * SUM4B(ind0, ind1, ig) + c->colo3[lay] * b->abso3b[ig - 1];
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 25: {
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->rayl_g[ig - 1];
+                    c->taug[g0 + ig - 1][lay] = c->colo3[lay] * b->abso3b[ig - 1];
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 27: {
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    tauray = c->colmol[lay] * b->rayl_g[ig - 1];
+                    c->taug[g0 + ig - 1][lay] = c->colo3[lay] * SUM4B(ind0, ind1, ig);
+                    if (lay == laysolfr) c->sfluxzen[g0 + ig - 1] = b->scalekur * SFLUX(ig, 1);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 28: {
+                q = binary(c, lay, c->colo3[lay], b->strrat * c->colo2[lay], 4., oneminus);
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + q.js;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + q.js;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] = q.speccomb * SUM8B(q, ind0, ind1, ig);
+                    if (lay == laysolfr)
+                        c->sfluxzen[g0 + ig - 1] = SFLUX(ig, q.js) + q.fs * (SFLUX(ig, q.js + 1) - SFLUX(ig, q.js));
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            case 29: {
+                ind0 = ((c->jp[lay] - 13) * 5 + (c->jt[lay] - 1)) * nspb[ib] + 1;
+                ind1 = ((c->jp[lay] - 12) * 5 + (c->jt1[lay] - 1)) * nspb[ib] + 1;
+                tauray = c->colmol[lay] * b->rayl;
+                for (int ig = 1; ig <= ng; ++ig) {
+                    c->taug[g0 + ig - 1][lay] =
+                        c->colco2[lay] * SUM4B(ind0, ind1, ig) + c->colh2o[lay] * b->absh2o[ig - 1];
+                    if (lay == laysolfr) c->sfluxzen[g0 + ig - 1] = SFLUX(ig, 1);
+                    c->taur[g0 + ig - 1][lay] = tauray;
+                }
+                break;
+            }
+            }
+        }
+    }
+}
+
+/* exponential via lookup table or small-argument expansion, e.g. SW:8459-8466 */
+static inline double exp_lookup(const SwTables *t, double ze1)
+{
+    if (ze1 <= 0.06) return 1. - ze1 + 0.5 * ze1 * ze1;
+    double tblind = ze1 / (t->bpade + ze1);
+    int itind = (int)(10000.0 * tblind + 0.5);
+    return t->exp_tbl[itind];
+}
+
+/* reftra_sw, SW:2422-2701 (kmodts = 2, PIFM) */
+static void reftra_sw(const SwTables *t, int nlayers, const int *lrtchk, const double *pgg, double prmuz,
+                      const double *ptau, const double *pw, double *pref, double *prefd, double *ptra,
+                      double *ptrad)
+{
+    const double eps = 1.e-08;
+    const double zwcrit = 0.9999995;
+    for (int jk = 1; jk <= nlayers; ++jk) {
+        if (!lrtchk[jk]) {
+            pref[jk] = 0.; ptra[jk] = 1.; prefd[jk] = 0.; ptrad[jk] = 1.;
+            continue;
+        }
+        double zto1 = ptau[jk], zw = pw[jk], zg = pgg[jk];
+        double zg3 = 3. * zg;
+        double zgamma1 = (8. - zw * (5. + zg3)) * 0.25;
+        double zgamma2 = 3. * (zw * (1. - zg)) * 0.25;
+        double zgamma3 = (2. - zg3 * prmuz) * 0.25;
+        double zgamma4 = 1. - zgamma3;
+        double zq = zg / (1. - zg);
+        double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
+        double zwo = zw / denom;
+        if (zwo >= zwcrit) {
+            /* conservative scattering, SW:2560-2600 */
+            double za = zgamma1 * prmuz;
+            double za1 = za - zgamma3;
+            double zgt = zgamma1 * zto1;
+            double ze1 = fmin(zto1 / prmuz, 500.);
+            double ze2 = exp_lookup(t, ze1);
+            pref[jk] = (zgt - za1 * (1. - ze2)) / (1. + zgt);
+            ptra[jk] = 1. - pref[jk];
+            prefd[jk] = zgt / (1. + zgt);
+            ptrad[jk] = 1. - prefd[jk];
+            if (ze2 == 1.0) { pref[jk] = 0.0; ptra[jk] = 1.0; prefd[jk] = 0.0; ptrad[jk] = 1.0; }
+        } else {
+            /* non-conservative scattering, SW:2602-2693 */
+            double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
+            double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
+            double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+            double zrp = zrk * prmuz;
+            double zrp1 = 1. + zrp;
+            double zrm1 = 1. - zrp;
+            double zrk2 = 2. * zrk;
+            double zrpp = 1. - zrp * zrp;
+            double zrkg = zrk + zgamma1;
+            double zr1 = zrm1 * (za2 + zrk * zgamma3);
+            double zr2 = zrp1 * (za2 - zrk * zgamma3);
+            double zr3 = zrk2 * (zgamma3 - za2 * prmuz);
+            double zr4 = zrpp * zrkg;
+            double zr5 = zrpp * (zrk - zgamma1);
+            double zt1 = zrp1 * (za1 + zrk * zgamma4);
+            double zt2 = zrm1 * (za1 - zrk * zgamma4);
+            double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
+            double zt4 = zr4, zt5 = zr5;
+            double zbeta = (zgamma1 - zrk) / zrkg;
+            double ze1 = fmin(zrk * zto1, 500.);
+            double ze2 = fmin(zto1 / prmuz, 500.);
+            double zem1 = exp_lookup(t, ze1);
+            double zep1 = 1. / zem1;
+            double zem2 = exp_lookup(t, ze2);
+            double zep2 = 1. / zem2;
+            double zdenr = zr4 * zep1 + zr5 * zem1;
+            double zdent = zt4 * zep1 + zt5 * zem1;
+            if (zdenr >= -eps && zdenr <= eps) {
+                pref[jk] = eps;
+                ptra[jk] = zem2;
+            } else {
+                pref[jk] = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
+                ptra[jk] = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
+            }
+            double zemm = zem1 * zem1;
+            double zdend = 1. / ((1. - zbeta * zemm) * zrkg);
+            prefd[jk] = zgamma2 * (1. - zemm) * zdend;
+            ptrad[jk] = zrk2 * zem1 * zdend;
+        }
+    }
+}
+
+/* vrtqdr_sw, SW:7922-8046.  All arrays 1-based, size klev+1. */
+static void vrtqdr_sw(int klev, const double *pref, const double *prefd, const double *ptra, const double *ptrad,
+                      const double *pdbt, double *prdnd, double *prup, double *prupd, const double *ptdbt,
+                      double *pfd, double *pfu)
+{
+    double ztdn[MAXLAY + 2];
+    double zreflect = 1. / (1. - prefd[klev + 1] * prefd[klev]);
+    prup[klev] = pref[klev] +
+                 (ptrad[klev] * ((ptra[klev] - pdbt[klev]) * prefd[klev + 1] + pdbt[klev] * pref[klev + 1])) * zreflect;
+    prupd[klev] = prefd[klev] + ptrad[klev] * ptrad[klev] * prefd[klev + 1] * zreflect;
+    for (int jk = 1; jk <= klev - 1; ++jk) {
+        int ikp = klev + 1 - jk, ikx = ikp - 1;
+        zreflect = 1. / (1. - prupd[ikp] * prefd[ikx]);
+        prup[ikx] = pref[ikx] +
+                    (ptrad[ikx] * ((ptra[ikx] - pdbt[ikx]) * prupd[ikp] + pdbt[ikx] * prup[ikp])) * zreflect;
+        prupd[ikx] = prefd[ikx] + ptrad[ikx] * ptrad[ikx] * prupd[ikp] * zreflect;
+    }
+    ztdn[1] = 1.;
+    prdnd[1] = 0.;
+    ztdn[2] = ptra[1];
+    prdnd[2] = prefd[1];
+    for (int jk = 2; jk <= klev; ++jk) {
+        int ikp = jk + 1;
+        zreflect = 1. / (1. - prefd[jk] * prdnd[jk]);
+        ztdn[ikp] = ptdbt[jk] * ptra[jk] +
+                    (ptrad[jk] * ((ztdn[jk] - ptdbt[jk]) + ptdbt[jk] * pref[jk] * prdnd[jk])) * zreflect;
+        prdnd[ikp] = prefd[jk] + ptrad[jk] * ptrad[jk] * prdnd[jk] * zreflect;
+    }
+    for (int jk = 1; jk <= klev + 1; ++jk) {
+        zreflect = 1. / (1. - prdnd[jk] * prupd[jk]);
+        pfu[jk] = (ptdbt[jk] * prup[jk] + (ztdn[jk] - ptdbt[jk]) * prupd[jk]) * zreflect;
+        pfd[jk] = ptdbt[jk] + (ztdn[jk] - ptdbt[jk] + ptdbt[jk] * prup[jk] * prdnd[jk]) * zreflect;
+    }
+}
+
+typedef struct {
+    double bbfd[MAXLAY + 2], bbfu[MAXLAY + 2], bbcd[MAXLAY + 2], bbcu[MAXLAY + 2];
+    double uvfd[MAXLAY + 2], uvcd[MAXLAY + 2], nifd[MAXLAY + 2], nicd[MAXLAY + 2];
+    double bbfddir[MAXLAY + 2], bbcddir[MAXLAY + 2], uvfddir[MAXLAY + 2], uvcddir[MAXLAY + 2];
+    double nifddir[MAXLAY + 2], nicddir[MAXLAY + 2];
+} SwFlux;
+
+/* spcvmc_sw, SW:8083-8658, for a cloud-free column: every McICA cloud
+ * fraction is 0 so lrtchkcld is false everywhere, zclear = 1, zcloud = 0 and
+ * the "total sky" R/T and direct-beam terms equal the clear ones exactly
+ * (1*x + 0*y with finite y).  taug/taur/sfluxzen come from taumol_sw, which
+ * the reference recomputes inside each call (SW:8335) with identical result.
+ * ptaua/pasya/pomga: [SW_NBND][MAXLAY] 1-based layers. */
+static void spcvmc_sw(const SwTables *t, const SwCol *c, const double *palbd, const double *palbp,
+                      const double (*ptaua)[MAXLAY], const double (*pasya)[MAXLAY], const double (*pomga)[MAXLAY],
+                      double prmu0, const double *adjflux, SwFlux *f)
+{
+    const int klev = c->nlayers;
+    int lrtchkclr[MAXLAY + 2];
+    double zdbtc[MAXLAY + 2], ztdbtc[MAXLAY + 2], zdbtc_nodel[MAXLAY + 2], ztdbtc_nodel[MAXLAY + 2];
+    double zgcc[MAXLAY + 2], zomcc[MAXLAY + 2], ztauc[MAXLAY + 2];
+    double zrefc[MAXLAY + 2], zrefdc[MAXLAY + 2], ztrac[MAXLAY + 2], ztradc[MAXLAY + 2];
+    double zrdndc[MAXLAY + 2], zrupc[MAXLAY + 2], zrupdc[MAXLAY + 2];
+    double zcd[MAXLAY + 2], zcu[MAXLAY + 2];
+    memset(f, 0, sizeof(*f));
+
+    int iw = 0;
+    for (int jb = SW_JPB1; jb <= SW_JPB1 + SW_NBND - 1; ++jb) {
+        int ibm = jb - 15;
+        int igt = ngc[ibm - 1];
+        for (int jg = 1; jg <= igt; ++jg) {
+            iw = iw + 1;
+            double zincflx = adjflux[ibm - 1] * c->sfluxzen[iw - 1] * prmu0;
+            ztdbtc[1] = 1.0;
+            ztdbtc_nodel[1] = 1.0;
+            zdbtc[klev + 1] = 0.0;
+            ztrac[klev + 1] = 0.0;
+            ztradc[klev + 1] = 0.0;
+            zrefc[klev + 1] = palbp[ibm - 1];
+            zrefdc[klev + 1] = palbd[ibm - 1];
+            zrupc[klev + 1] = palbp[ibm - 1];
+            zrupdc[klev + 1] = palbd[ibm - 1];
+            for (int jk = 1; jk <= klev; ++jk) {
+                int ikl = klev + 1 - jk;
+                lrtchkclr[jk] = 1;
+                /* clear-sky optical parameters including aerosols, SW:8443-8446 */
+                ztauc[jk] = c->taur[iw - 1][ikl] + c->taug[iw - 1][ikl] + ptaua[ibm - 1][ikl];
+                zomcc[jk] = c->taur[iw - 1][ikl] * 1.0 + ptaua[ibm - 1][ikl] * pomga[ibm - 1][ikl];
+                zgcc[jk] = pasya[ibm - 1][ikl] * pomga[ibm - 1][ikl] * ptaua[ibm - 1][ikl] / zomcc[jk];
+                zomcc[jk] = zomcc[jk] / ztauc[jk];
+                /* pre-delta-scaling direct beam, SW:8459-8469 */
+                double ze1 = ztauc[jk] / prmu0;
+                double zdbtmc = exp_lookup(t, ze1);
+                zdbtc_nodel[jk] = zdbtmc;
+                ztdbtc_nodel[jk + 1] = zdbtc_nodel[jk] * ztdbtc_nodel[jk];
+                /* delta scaling, SW:8492-8501 */
+                double zf = zgcc[jk] * zgcc[jk];
+                double zwf = zomcc[jk] * zf;
+                ztauc[jk] = (1.0 - zwf) * ztauc[jk];
+                double denom = fmax((1.0 - zwf), 1.0E-30);
+                zomcc[jk] = (zomcc[jk] - zwf) / denom;
+                denom = fmax((1.0 - zf), 1.0E-30);
+                zgcc[jk] = (zgcc[jk] - zf) / denom;
+            }
+            reftra_sw(t, klev, lrtchkclr, zgcc, prmu0, ztauc, zomcc, zrefc, zrefdc, ztrac, ztradc);
+            for (int jk = 1; jk <= klev; ++jk) {
+                /* direct beam transmittance after scaling, SW:8568-8578 */
+                double ze1 = ztauc[jk] / prmu0;
+                double zdbtmc = exp_lookup(t, ze1);
+                zdbtc[jk] = zdbtmc;
+                ztdbtc[jk + 1] = zdbtc[jk] * ztdbtc[jk];
+            }
+            vrtqdr_sw(klev, zrefc, zrefdc, ztrac, ztradc, zdbtc, zrdndc, zrupc, zrupdc, ztdbtc, zcd, zcu);
+            /* spectral accumulation, SW:8617-8650; total == clear without cloud */
+            for (int jk = 1; jk <= klev + 1; ++jk) {
+                int ikl = klev + 2 - jk;
+                f->bbfu[ikl] = f->bbfu[ikl] + zincflx * zcu[jk];
+                f->bbfd[ikl] = f->bbfd[ikl] + zincflx * zcd[jk];
+                f->bbcu[ikl] = f->bbcu[ikl] + zincflx * zcu[jk];
+                f->bbcd[ikl] = f->bbcd[ikl] + zincflx * zcd[jk];
+                f->bbfddir[ikl] = f->bbfddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                f->bbcddir[ikl] = f->bbcddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                if (ibm >= 10 && ibm <= 13) {
+                    f->uvcd[ikl] = f->uvcd[ikl] + zincflx * zcd[jk];
+                    f->uvfd[ikl] = f->uvfd[ikl] + zincflx * zcd[jk];
+                    f->uvcddir[ikl] = f->uvcddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                    f->uvfddir[ikl] = f->uvfddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                } else if (ibm == 14 || ibm <= 9) {
+                    f->nicd[ikl] = f->nicd[ikl] + zincflx * zcd[jk];
+                    f->nifd[ikl] = f->nifd[ikl] + zincflx * zcd[jk];
+                    f->nicddir[ikl] = f->nicddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                    f->nifddir[ikl] = f->nifddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                }
+            }
+        }
+    }
+}
+
+/* rrtmg_sw, SW:8740-9490 (+ inatm_sw, SW:9520-9873) for one column */
+int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out)
+{
+    const int nlayers = in->nlay;
+    if (nlayers + 2 > MAXLAY || in->dyofyr > 0) return 1;
+    SwCol *c = (SwCol *)malloc(sizeof(SwCol));
+    static const double avogad = 6.02214199e+23, grav = 9.8066, amd = 28.9660, amw = 18.0160;
+    const double rrsw_scon = 1.36822e+03;
+    const double zepzen = 1.e-10;
+    c->nlayers = nlayers;
+    /* inatm_sw */
+    double adjflx = in->adjes;
+    double adjflux[SW_NBND];
+    for (int ib = 0; ib < SW_NBND; ++ib) {
+        double solvar = in->scon / rrsw_scon;
+        adjflux[ib] = adjflx * solvar;
+    }
+    c->pz[0] = in->plev[0];
+    c->tz[0] = in->tlev[0];
+    for (int l = 1; l <= nlayers; ++l) {
+        c->pavel[l] = in->play[l - 1];
+        c->tavel[l] = in->tlay[l - 1];
+        c->pz[l] = in->plev[l];
+        c->tz[l] = in->tlev[l];
+        c->pdp[l] = c->pz[l - 1] - c->pz[l];
+        for (int m = 0; m < 8; ++m) c->wkl[m][l] = 0.0;
+        c->wkl[1][l] = in->h2ovmr[l - 1];
+        c->wkl[2][l] = in->co2vmr[l - 1];
+        c->wkl[3][l] = in->o3vmr[l - 1];
+        c->wkl[4][l] = in->n2ovmr[l - 1];
+        c->wkl[6][l] = in->ch4vmr[l - 1];
+        c->wkl[7][l] = in->o2vmr[l - 1];
+        double amm = (1. - c->wkl[1][l]) * amd + c->wkl[1][l] * amw;
+        c->coldry[l] = (c->pz[l - 1] - c->pz[l]) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + c->wkl[1][l]));
+    }
+    for (int l = 1; l <= nlayers; ++l)
+        for (int m = 1; m <= 7; ++m) c->wkl[m][l] = c->coldry[l] * c->wkl[m][l];
+    c->jp[nlayers + 1] = 0; /* jp(lay+1) is read at lay = laytrop <= nlayers-1 in practice */
+
+    setcoef_sw(c);
+    taumol_sw(t, c);
+
+    double cossza = in->coszen;
+    if (cossza <= zepzen) cossza = zepzen;
+    double albdir[SW_NBND], albdif[SW_NBND];
+    for (int ib = 0; ib < 9; ++ib) { albdir[ib] = in->aldir; albdif[ib] = in->aldif; }
+    albdir[SW_NBND - 1] = in->aldir;
+    albdif[SW_NBND - 1] = in->aldif;
+    for (int ib = 9; ib < 13; ++ib) { albdir[ib] = in->asdir; albdif[ib] = in->asdif; }
+
+    /* ztaua, zasya, zomga, ztauacln (SW:9343-9352, iaer = 10) */
+    double(*pt)[MAXLAY] = (double(*)[MAXLAY])malloc(4 * SW_NBND * MAXLAY * sizeof(double));
+    double(*ta)[MAXLAY] = pt, (*as)[MAXLAY] = pt + SW_NBND, (*om)[MAXLAY] = pt + 2 * SW_NBND,
+    (*cl)[MAXLAY] = pt + 3 * SW_NBND;
+    for (int ib = 0; ib < SW_NBND; ++ib)
+        for (int i = 1; i <= nlayers; ++i) {
+            ta[ib][i] = in->tauaer[ib * nlayers + i - 1];
+            cl[ib][i] = 0.0;
+            as[ib][i] = in->asmaer[ib * nlayers + i - 1];
+            om[ib][i] = in->ssaaer[ib * nlayers + i - 1];
+        }
+
+    SwFlux *f = (SwFlux *)malloc(sizeof(SwFlux));
+    spcvmc_sw(t, c, albdif, albdir, (const double(*)[MAXLAY])ta, (const double(*)[MAXLAY])as,
+              (const double(*)[MAXLAY])om, cossza, adjflux, f);
+    double swnflx[MAXLAY + 2], swnflxc[MAXLAY + 2];
+    for (int i = 1; i <= nlayers + 1; ++i) {
+        out->swuflxc[i - 1] = f->bbcu[i];
+        out->swdflxc[i - 1] = f->bbcd[i];
+        out->swuflx[i - 1] = f->bbfu[i];
+        out->swdflx[i - 1] = f->bbfd[i];
+        double dirdflux = f->bbfddir[i];
+        double difdflux = out->swdflx[i - 1] - dirdflux;
+        if (out->swdkdir) out->swdkdir[i - 1] = dirdflux;
+        if (out->swdkdif) out->swdkdif[i - 1] = difdflux;
+        double dirdnuv = f->uvfddir[i], difdnuv = f->uvfd[i] - dirdnuv;
+        if (out->sibvisdir) out->sibvisdir[i - 1] = dirdnuv;
+        if (out->sibvisdif) out->sibvisdif[i - 1] = difdnuv;
+        double dirdnir = f->nifddir[i], difdnir = f->nifd[i] - dirdnir;
+        if (out->sibnirdir) out->sibnirdir[i - 1] = dirdnir;
+        if (out->sibnirdif) out->sibnirdif[i - 1] = difdnir;
+    }
+    for (int i = 1; i <= nlayers + 1; ++i) {
+        swnflxc[i] = out->swdflxc[i - 1] - out->swuflxc[i - 1];
+        swnflx[i] = out->swdflx[i - 1] - out->swuflx[i - 1];
+    }
+    for (int i = 1; i <= nlayers; ++i) {
+        double zdpgcp = t->heatfac / c->pdp[i];
+        out->swhrc[i - 1] = (swnflxc[i + 1] - swnflxc[i]) * zdpgcp;
+        out->swhr[i - 1] = (swnflx[i + 1] - swnflx[i]) * zdpgcp;
+    }
+    out->swhrc[nlayers - 1] = 0.;
+    out->swhr[nlayers - 1] = 0.;
+
+    if (in->clean_atm_diag > 0) {
+        /* second call with aerosol optical depth removed, SW:9436-9472 */
+        spcvmc_sw(t, c, albdif, albdir, (const double(*)[MAXLAY])cl, (const double(*)[MAXLAY])as,
+                  (const double(*)[MAXLAY])om, cossza, adjflux, f);
+        for (int i = 1; i <= nlayers + 1; ++i) {
+            out->swuflxcln[i - 1] = f->bbfu[i];
+            out->swdflxcln[i - 1] = f->bbfd[i];
+        }
+    } else {
+        for (int i = 1; i <= nlayers + 1; ++i) { out->swuflxcln[i - 1] = 0.0; out->swdflxcln[i - 1] = 0.0; }
+    }
+    free(f); free(pt); free(c);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* O3 climatology, LW:12704-12840 (INIRAD / O3DATA)                         */
+/* ------------------------------------------------------------------------ */
+void oracle_inirad(double *o3prof, const double *plev, int nk)
+{
+    /* plev[0..nk+1] (kts..kte+2), o3prof[0..nk] (kts..kte+1) */
+    static const double o3sum[31] = {
+        5.297E-8, 5.852E-8, 6.579E-8, 7.505E-8, 8.577E-8, 9.895E-8, 1.175E-7, 1.399E-7, 1.677E-7, 2.003E-7,
+        2.571E-7, 3.325E-7, 4.438E-7, 6.255E-7, 8.168E-7, 1.036E-6, 1.366E-6, 1.855E-6, 2.514E-6, 3.240E-6,
+        4.033E-6, 4.854E-6, 5.517E-6, 6.089E-6, 6.689E-6, 1.106E-5, 1.462E-5, 1.321E-5, 9.856E-6, 5.960E-6,
+        5.960E-6};
+    static const double ppsum[31] = {
+        955.890, 850.532, 754.599, 667.742, 589.841, 519.421, 455.480, 398.085, 347.171, 301.735, 261.310,
+        225.360, 193.419, 165.490, 141.032, 120.125, 102.689, 87.829, 75.123, 64.306, 55.086, 47.209, 40.535,
+        34.795, 29.865, 19.122, 9.277, 4.660, 2.421, 1.294, 0.647};
+    static const double o3win[31] = {
+        4.629E-8, 4.686E-8, 5.017E-8, 5.613E-8, 6.871E-8, 8.751E-8, 1.138E-7, 1.516E-7, 2.161E-7, 3.264E-7,
+        4.968E-7, 7.338E-7, 1.017E-6, 1.308E-6, 1.625E-6, 2.011E-6, 2.516E-6, 3.130E-6, 3.840E-6, 4.703E-6,
+        5.486E-6, 6.289E-6, 6.993E-6, 7.494E-6, 8.197E-6, 9.632E-6, 1.113E-5, 1.146E-5, 9.389E-6, 6.135E-6,
+        6.135E-6};
+    static const double ppwin[31] = {
+        955.747, 841.783, 740.199, 649.538, 568.404, 495.815, 431.069, 373.464, 322.354, 277.190, 237.635,
+        203.433, 174.070, 148.949, 127.408, 108.915, 93.114, 79.551, 67.940, 58.072, 49.593, 42.318, 36.138,
+        30.907, 26.362, 16.423, 7.583, 3.620, 1.807, 0.938, 0.469};
+    double o3ann[31], ppwrkh[32];
+    o3ann[0] = 0.5 * (o3sum[0] + o3win[0]);
+    for (int k = 1; k < 31; ++k)
+        o3ann[k] = o3win[k - 1] + (o3win[k] - o3win[k - 1]) / (ppwin[k] - ppwin[k - 1]) * (ppsum[k] - ppwin[k - 1]);
+    for (int k = 1; k < 31; ++k) o3ann[k] = 0.5 * (o3ann[k] + o3sum[k]);
+    ppwrkh[0] = 1100.;
+    for (int k = 1; k < 31; ++k) ppwrkh[k] = (ppsum[k] + ppsum[k - 1]) / 2.;
+    ppwrkh[31] = 0.;
+    for (int k = 0; k <= nk; ++k) {
+        o3prof[k] = 0.;
+        for (int jj = 0; jj < 31; ++jj) {
+            double pb1 = (-(plev[k] - ppwrkh[jj]) >= 0.) ? 0. : plev[k] - ppwrkh[jj];
+            double pb2 = (-(plev[k] - ppwrkh[jj + 1]) >= 0.) ? 0. : plev[k] - ppwrkh[jj + 1];
+            double pt1 = (-(plev[k + 1] - ppwrkh[jj]) >= 0.) ? 0. : plev[k + 1] - ppwrkh[jj];
+            double pt2 = (-(plev[k + 1] - ppwrkh[jj + 1]) >= 0.) ? 0. : plev[k + 1] - ppwrkh[jj + 1];
+            o3prof[k] = o3prof[k] + (pb2 - pb1 - pt2 + pt1) * o3ann[jj];
+        }
+        o3prof[k] = o3prof[k] / (plev[k] - plev[k + 1]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* RRTMG_SWRAD over a tile, SW:10320-11207 (cloud-free, WRF-Chem aerosol)   */
+/* ------------------------------------------------------------------------ */
+static const double wavemin[SW_NBND] = {3.077, 2.500, 2.150, 1.942, 1.626, 1.299, 1.242,
+                                        0.778, 0.625, 0.442, 0.345, 0.263, 0.200, 3.846};
+static const double wavemax[SW_NBND] = {3.846, 3.077, 2.500, 2.150, 1.942, 1.626, 1.299,
+                                        1.242, 0.778, 0.625, 0.442, 0.345, 0.263, 12.195};
+
+int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, char *err, int errlen)
+{
+    const int ni = in->ime - in->ims + 1, nkm = in->kme - in->kms + 1;
+    const int nk = in->kte - in->kts + 1;
+    const int nlay = nk + 1;
+    const size_t sj3 = (size_t)ni * nkm, sj3f = (size_t)ni * (nkm + 2);
+#define I3(i, k, j) ((size_t)((j) - in->jms) * sj3 + (size_t)((k) - in->kms) * ni + ((i) - in->ims))
+#define I3F(i, k, j) ((size_t)((j) - in->jms) * sj3f + (size_t)((k) - in->kms) * ni + ((i) - in->ims))
+#define I2(i, j) ((size_t)((j) - in->jms) * ni + ((i) - in->ims))
+    const double co2 = 379.e-6, ch4 = 1774.e-9, n2o = 319.e-9, o2 = 0.209488;
+    const double amdw = 1.607793, amdo = 0.603461;
+    const double thresh = 1.e-9;
+    if (nlay + 2 > MAXLAY) return 1;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(80 * MAXLAY));
+    double *play = w, *plev = play + MAXLAY, *tlay = plev + MAXLAY, *tlev = tlay + MAXLAY;
+    double *h2ovmr = tlev + MAXLAY, *o3vmr = h2ovmr + MAXLAY, *co2vmr = o3vmr + MAXLAY, *ch4vmr = co2vmr + MAXLAY;
+    double *n2ovmr = ch4vmr + MAXLAY, *o2vmr = n2ovmr + MAXLAY, *o3mmr = o2vmr + MAXLAY;
+    double *tauaer = o3mmr + MAXLAY, *ssaaer = tauaer + 14 * MAXLAY, *asmaer = ssaaer + 14 * MAXLAY;
+    double *o_ = asmaer + 14 * MAXLAY;
+    double *swuflx = o_, *swdflx = o_ + MAXLAY, *swhr = o_ + 2 * MAXLAY, *swuflxc = o_ + 3 * MAXLAY,
+           *swdflxc = o_ + 4 * MAXLAY, *swhrc = o_ + 5 * MAXLAY, *swuflxcln = o_ + 6 * MAXLAY,
+           *swdflxcln = o_ + 7 * MAXLAY;
+    double *vd = o_ + 8 * MAXLAY;
+    int rc = 0;
+    for (int j = in->jts; j <= in->jte && !rc; ++j)
+        for (int i = in->its; i <= in->ite && !rc; ++i) {
+            double coszrs = in->xcoszen[I2(i, j)];
+            if (out->coszr) out->coszr[I2(i, j)] = coszrs;
+            if (!(coszrs <= 0.0)) {
+                /* 1-D profiles, SW:10340-10390, 10628-10656 */
+                for (int k = 0; k <= nk; ++k) {
+                    plev[k] = in->p8w[I3(i, in->kts + k, j)] / 100.;
+                    tlev[k] = in->t8w[I3(i, in->kts + k, j)];
+                }
+                for (int k = 0; k < nk; ++k) {
+                    double qv = in->qv3d[I3(i, in->kts + k, j)];
+                    qv = qv > 0. ? qv : 0.;
+                    qv = qv > 1.E-12 ? qv : 1.E-12;
+                    play[k] = in->p3d[I3(i, in->kts + k, j)] / 100.;
+                    tlay[k] = in->t3d[I3(i, in->kts + k, j)];
+                    h2ovmr[k] = qv * amdw;
+                    co2vmr[k] = co2; o2vmr[k] = o2; ch4vmr[k] = ch4; n2ovmr[k] = n2o;
+                }
+                play[nk] = 0.5 * plev[nk];
+                tlay[nk] = tlev[nk] + 0.0;
+                plev[nk + 1] = 1.0e-5;
+                tlev[nk + 1] = tlev[nk] + 0.0;
+                h2ovmr[nk] = h2ovmr[nk - 1];
+                co2vmr[nk] = co2vmr[nk - 1]; o2vmr[nk] = o2vmr[nk - 1];
+                ch4vmr[nk] = ch4vmr[nk - 1]; n2ovmr[nk] = n2ovmr[nk - 1];
+                oracle_inirad(o3mmr, plev, nk);
+                for (int k = 0; k <= nk; ++k) o3vmr[k] = o3mmr[k] * amdo;
+                double alb = in->albedo[I2(i, j)];
+                /* aerosol defaults then wavelength -> band mapping, SW:10974-11023 */
+                for (int nb = 0; nb < SW_NBND; ++nb)
+                    for (int k = 0; k <= nk; ++k) {
+                        tauaer[nb * nlay + k] = 0.; ssaaer[nb * nlay + k] = 1.; asmaer[nb * nlay + k] = 0.;
+                    }
+                if (in->aer_ra_feedback == 1) {
+                    for (int nb = 0; nb < SW_NBND; ++nb) {
+                        double wavemid = 0.5 * (wavemin[nb] + wavemax[nb]);
+                        for (int k = 0; k < nk; ++k) {
+                            size_t q = I3(i, in->kts + k, j);
+                            if (in->tauaer300[q] > thresh && in->tauaer999[q] > thresh) {
+                                double ang = log(in->tauaer300[q] / in->tauaer999[q]) / log(999. / 300.);
+                                tauaer[nb * nlay + k] = in->tauaer400[q] * pow(0.4 / wavemid, ang);
+                                double slope = (in->waer600[q] - in->waer400[q]) / .2;
+                                double s = slope * (wavemid - .6) + in->waer600[q];
+                                if (s < 0.4) s = 0.4;
+                                if (s >= 1.0) s = 1.0;
+                                ssaaer[nb * nlay + k] = s;
+                                slope = (in->gaer600[q] - in->gaer400[q]) / .2;
+                                double a = slope * (wavemid - .6) + in->gaer600[q];
+                                if (a < 0.5) a = 0.5;
+                                if (a >= 1.0) a = 1.0;
+                                asmaer[nb * nlay + k] = a;
+                            }
+                        }
+                    }
+                    /* column optical-depth guard, SW:11026-11047 */
+                    for (int nb = 0; nb < SW_NBND && !rc; ++nb) {
+                        double slope = 0.;
+                        for (int k = 0; k < nk; ++k) slope = slope + tauaer[nb * nlay + k];
+                        if (slope < 0.) {
+                            if (err)
+                                snprintf(err, errlen,
+                                         "ERROR: Negative total optical depth of %8.2f at point i,j,nb=%5d%5d%5d",
+                                         slope, i, j, nb + 1);
+                            rc = 2;
+                        } else if (slope > 6.) {
+                            for (int k = 0; k < nk; ++k) tauaer[nb * nlay + k] = tauaer[nb * nlay + k] * 6.0 / slope;
+                        }
+                    }
+                    if (rc) break;
+                }
+                SwColumnIn ci = {nlay, play, plev, tlay, tlev, in->tsk[I2(i, j)], h2ovmr, o3vmr, co2vmr, ch4vmr,
+                                 n2ovmr, o2vmr, alb, alb, alb, alb, coszrs, 1.0, in->solcon, 0,
+                                 tauaer, ssaaer, asmaer, in->clean_atm_diag};
+                SwColumnOut co = {swuflx, swdflx, swhr, swuflxc, swdflxc, swhrc, swuflxcln, swdflxcln,
+                                  vd, vd + MAXLAY, vd + 2 * MAXLAY, vd + 3 * MAXLAY, vd + 4 * MAXLAY, vd + 5 * MAXLAY};
+                if (sw_oracle_rrtmg_sw(t, &ci, &co)) { rc = 1; break; }
+                /* outputs, SW:11125-11172 (kte+2 in WRF == index nk+1 here) */
+                size_t q2 = I2(i, j);
+                if (out->gsw) out->gsw[q2] = swdflx[0] - swuflx[0];
+                if (out->swcf)
+                    out->swcf[q2] = (swdflx[nk + 1] - swuflx[nk + 1]) - (swdflxc[nk + 1] - swuflxc[nk + 1]);
+                if (out->swupt) {
+                    out->swupt[q2] = swuflx[nk + 1]; out->swuptc[q2] = swuflxc[nk + 1];
+                    out->swuptcln[q2] = swuflxcln[nk + 1]; out->swdnt[q2] = swdflx[nk + 1];
+                    out->swdntc[q2] = swdflxc[nk + 1]; out->swdntcln[q2] = swdflxcln[nk + 1];
+                    out->swupb[q2] = swuflx[0]; out->swupbc[q2] = swuflxc[0]; out->swupbcln[q2] = swuflxcln[0];
+                    out->swdnb[q2] = swdflx[0]; out->swdnbc[q2] = swdflxc[0]; out->swdnbcln[q2] = swdflxcln[0];
+                    if (out->swvisdir) {
+                        out->swvisdir[q2] = vd[0]; out->swvisdif[q2] = vd[MAXLAY];
+                        out->swnirdir[q2] = vd[2 * MAXLAY]; out->swnirdif[q2] = vd[3 * MAXLAY];
+                    }
+                }
+                if (out->swddir) {
+                    out->swddir[q2] = vd[4 * MAXLAY];
+                    out->swddni[q2] = out->swddir[q2] / coszrs;
+                    out->swddif[q2] = vd[5 * MAXLAY];
+                }
+                if (out->swupflx)
+                    for (int k = 0; k <= nk + 1; ++k) {
+                        size_t q = I3F(i, in->kts + k, j);
+                        out->swupflx[q] = swuflx[k]; out->swupflxc[q] = swuflxc[k]; out->swupflxcln[q] = swuflxcln[k];
+                        out->swdnflx[q] = swdflx[k]; out->swdnflxc[q] = swdflxc[k]; out->swdnflxcln[q] = swdflxcln[k];
+                    }
+                if (out->rthratensw)
+                    for (int k = 0; k < nk; ++k) {
+                        double tten = swhr[k] / 86400.;
+                        out->rthratensw[I3(i, in->kts + k, j)] = tten / in->pi3d[I3(i, in->kts + k, j)];
+                    }
+            } else {
+                size_t q2 = I2(i, j);
+                if (out->swupt) {
+                    out->swupt[q2] = 0.; out->swuptc[q2] = 0.; out->swuptcln[q2] = 0.; out->swdnt[q2] = 0.;
+                    out->swdntc[q2] = 0.; out->swdntcln[q2] = 0.; out->swupb[q2] = 0.; out->swupbc[q2] = 0.;
+                    out->swupbcln[q2] = 0.; out->swdnb[q2] = 0.; out->swdnbc[q2] = 0.; out->swdnbcln[q2] = 0.;
+                    if (out->swvisdir) {
+                        out->swvisdir[q2] = 0.; out->swvisdif[q2] = 0.; out->swnirdir[q2] = 0.; out->swnirdif[q2] = 0.;
+                    }
+                }
+                if (out->swddir) { out->swddir[q2] = 0.; out->swddni[q2] = 0.; out->swddif[q2] = 0.; }
+                if (out->swcf) out->swcf[q2] = 0.;
+            }
+        }
+    free(w);
+    return rc;
+#undef I3
+#undef I3F
+#undef I2
+}
