@@ -1,0 +1,119 @@
+/*
+ * include/rrtmg_hip.h -- C ABI of the MI355X column-radiation engine.
+ *
+ * Drop-in boundary for WRF-Chem v3.9.1's patched RRTMG double call
+ * (douglowe/WRFChem-ARC-Interactions).  Each entry point replaces one Fortran
+ * module procedure of the reference; the thin ISO_C_BINDING shims in
+ * wrfchem-arc-interactions_amd/fortran/ keep the reference's procedure names
+ * and argument lists and forward to these symbols.
+ *
+ *   rrtmg_hip_sw_init   <- rrtmg_swinit + rrtmg_swlookuptable + rrtmg_sw_ini
+ *                          phys/module_ra_rrtmg_sw.F:11211-11293, 4571-4698
+ *   rrtmg_hip_swrad     <- RRTMG_SWRAD           module_ra_rrtmg_sw.F:9901-11207
+ *                          (call site phys/module_radiation_driver.F:1944-2001)
+ *   rrtmg_hip_lw_init   <- rrtmg_lwinit + rrtmg_lwlookuptable + rrtmg_lw_ini
+ *                          phys/module_ra_rrtmg_lw.F:12845-12930, 7862-8009
+ *   rrtmg_hip_lwrad     <- RRTMG_LWRAD           module_ra_rrtmg_lw.F:11451-12700
+ *                          (call site phys/module_radiation_driver.F:1528-1577)
+ *   rrtmg_hip_finalize  (no reference counterpart; frees device tables)
+ *
+ * Conventions
+ *  - plain pointers and sizes only; arrays stay in WRF memory order:
+ *      3-D  (ims:ime, kms:kme, jms:jme), i fastest      (SW:9959)
+ *      2-D  (ims:ime, jms:jme)
+ *      flux profiles (ims:ime, kms:kme+2, jms:jme)      (SW:10099)
+ *  - real_bytes selects the width of every REAL array (8 for a -r8 build,
+ *    4 for stock WRF); all arithmetic is fp64 on the device either way.
+ *  - mem = 0: pointers are host memory, the call stages them through HBM and
+ *    is synchronous.  mem = 1: pointers are device (HBM) addresses, work is
+ *    enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
+ *    returns without synchronising.
+ *  - an OPTIONAL Fortran argument that is not PRESENT is passed as NULL.
+ *  - return value 0 = ok; nonzero = fatal, with the text the reference would
+ *    hand to wrf_error_fatal in `err` (the Fortran shim calls wrf_error_fatal).
+ *  - re-entrant after init: module tables are read-only; each call uses only
+ *    its own stream and workspace (DRV:975-982 calls this from an OpenMP tile
+ *    loop).
+ */
+#ifndef RRTMG_HIP_H
+#define RRTMG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTMG_HIP_ERRLEN 256
+
+/* Read RRTMG_SW_DATA (Fortran unformatted, one record per band, field order
+ * of sw_kgb16..29, SW:11379-12366), reduce 224 -> 112 g-points (cmbgb16s..29),
+ * build the exponential lookup table and upload everything to `device`.
+ * data_real_bytes: word size of the REALs in the file (4: RRTMG_SW_DATA,
+ * 8: RRTMG_SW_DATA_DBL).  cpdair: WRF's cp (module_model_constants). */
+int rrtmg_hip_sw_init(const char *data_path, int data_real_bytes, double cpdair, int device, char *err);
+
+typedef struct rrtmg_hip_swrad_args {
+    /* dimensions (SW:9937-9939) */
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    int real_bytes;          /* 4 or 8 */
+    int mem;                 /* 0 host pointers, 1 device pointers */
+    void *stream;            /* hipStream_t, used when mem = 1 */
+    /* scalars / flags */
+    double solcon;           /* SOLCON */
+    int aer_ra_feedback;     /* 0/1 */
+    int clean_atm_diag;      /* <=0: CLN outputs are 0 (SW:9473-9478) */
+    int icloud;              /* must be 0 this release (cloud-free path) */
+    int o3input;             /* 2 = use o33d inside the model domain */
+    /* inputs, 2-D */
+    const void *xcoszen, *albedo, *tsk;
+    /* inputs, 3-D */
+    const void *t3d, *t8w, *p3d, *p8w, *pi3d, *qv3d;
+    const void *o33d;                                        /* optional */
+    const void *tauaer300, *tauaer400, *tauaer600, *tauaer999;   /* optional unless aer_ra_feedback */
+    const void *gaer300, *gaer400, *gaer600, *gaer999;
+    const void *waer300, *waer400, *waer600, *waer999;
+    /* outputs, 3-D */
+    void *rthratensw;                                        /* INOUT: written for daylit columns only */
+    /* outputs, 2-D */
+    void *coszr, *gsw, *swcf;
+    void *swupt, *swuptc, *swuptcln, *swdnt, *swdntc, *swdntcln;    /* optional as a group */
+    void *swupb, *swupbc, *swupbcln, *swdnb, *swdnbc, *swdnbcln;
+    void *swvisdir, *swvisdif, *swnirdir, *swnirdif;                /* optional */
+    void *swddir, *swddni, *swddif;
+    /* optional flux profiles (ims:ime, kms:kme+2, jms:jme) */
+    void *swupflx, *swupflxc, *swupflxcln, *swdnflx, *swdnflxc, *swdnflxcln;
+} rrtmg_hip_swrad_args;
+
+int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);
+
+/* mem = 1 calls do not synchronise; this does (hipDeviceSynchronize), and
+ * returns nonzero with the reference's message if any of them raised the
+ * "Negative total optical depth" fatal (SW:11031-11033) on the device. */
+int rrtmg_hip_sw_status(char *err);
+
+/* Host-only helpers used by the CPU tests of the init path (no device). */
+int rrtmg_hip_sw_reduce_tables(const char *data_path, int data_real_bytes, double cpdair, double *k_out,
+                               long long k_cap, long long *k_len, double *exp_out, char *err);
+int rrtmg_hip_sw_table_info(const char *data_path, int data_real_bytes, int g, int *fields16, double *dfields10,
+                            char *err);
+
+/* bytes of device workspace a mem=0 call stages (diagnostic) */
+long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *args);
+
+/* Per-tile sums used for the multi-GPU gather: sums over the
+ * tile of the 12 SW TOA/surface fluxes + the clean-minus-aerosol TOA
+ * difference + daylit-column count, written to out[16] (device memory when
+ * mem = 1).  Field order: swupt,swuptc,swuptcln,swdnt,swdntc,swdntcln,
+ * swupb,swupbc,swupbcln,swdnb,swdnbc,swdnbcln, (swuptcln-swupt), ncol_day,
+ * ncol, 0. */
+int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *args, double *out16, char *err);
+
+int rrtmg_hip_finalize(void);
+
+/* version / build info: "rrtmg_hip <ver> gfx950" */
+const char *rrtmg_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

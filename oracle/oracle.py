@@ -100,3 +100,49 @@ class SwOracle:
         if self.h:
             lib().sw_oracle_free(self.h)
             self.h = None
+
+
+class SwTileIn(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("ims", "ime", "jms", "jme", "kms", "kme",
+                                         "its", "ite", "jts", "jte", "kts", "kte")]
+                + [(n, dp) for n in ("xcoszen", "albedo", "tsk", "t3d", "t8w", "p3d", "p8w", "pi3d", "qv3d",
+                                     "tauaer300", "tauaer400", "tauaer600", "tauaer999",
+                                     "gaer300", "gaer400", "gaer600", "gaer999",
+                                     "waer300", "waer400", "waer600", "waer999")]
+                + [("solcon", C.c_double), ("aer_ra_feedback", C.c_int), ("clean_atm_diag", C.c_int)])
+
+
+SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",
+               "swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
+               "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln",
+               "swvisdir", "swvisdif", "swnirdir", "swnirdif", "swddir", "swddni", "swddif",
+               "swupflx", "swupflxc", "swupflxcln", "swdnflx", "swdnflxc", "swdnflxcln"]
+
+
+class SwTileOut(C.Structure):
+    _fields_ = [(n, dp) for n in SW_TILE_OUT]
+
+
+def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedback, clean_atm_diag, outputs: dict):
+    """RRTMG_SWRAD restatement on a tile; arrays/outputs are float64 numpy in WRF order."""
+    ti = SwTileIn()
+    for n in ("ims", "ime", "jms", "jme", "kms", "kme", "its", "ite", "jts", "jte", "kts", "kte"):
+        setattr(ti, n, int(dims[n]))
+    keep = []
+    for n, _t in SwTileIn._fields_:
+        if _t is dp and arrays.get(n) is not None:
+            a = np.ascontiguousarray(arrays[n], dtype=np.float64)
+            keep.append(a)
+            setattr(ti, n, _p(a))
+    ti.solcon = float(solcon)
+    ti.aer_ra_feedback = int(aer_ra_feedback)
+    ti.clean_atm_diag = int(clean_atm_diag)
+    to = SwTileOut()
+    for n in SW_TILE_OUT:
+        if outputs.get(n) is not None:
+            assert outputs[n].dtype == np.float64 and outputs[n].flags["C_CONTIGUOUS"]
+            setattr(to, n, _p(outputs[n]))
+    err = C.create_string_buffer(256)
+    rc = lib().sw_oracle_swrad_tile(orc.h, C.byref(ti), C.byref(to), err, 256)
+    if rc:
+        raise RuntimeError(err.value.decode() or f"sw_oracle_swrad_tile rc={rc}")

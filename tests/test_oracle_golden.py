@@ -1,0 +1,59 @@
+"""CPU: the oracle (C restatement) against fixtures produced by the REFERENCE
+Fortran itself (tools/make_golden.py, oracle/_ref).  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["sw_cols_k40", "sw_cols_k50_variant"])
+def test_sw_column_solver_matches_reference_bitwise(sw_oracle, oracle_mod, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cols = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    out = sw_oracle.rrtmg_sw(cols, clean=1)
+    for n in oracle_mod.SW_COL_OUT:
+        np.testing.assert_array_equal(out[n], g["ref_" + n], err_msg=n)
+
+
+def test_sw_reference_fixture_physics(sw_oracle):
+    """sanity of the fixture itself: invariants the reference relies on."""
+    g = np.load(os.path.join(GOLD, "sw_cols_k40.npz"))
+    # cloud-free column: clear-sky == all-sky (SW:8428,8556)
+    np.testing.assert_array_equal(g["ref_swuflx"], g["ref_swuflxc"])
+    np.testing.assert_array_equal(g["ref_swdflx"], g["ref_swdflxc"])
+    # clean-sky surface downward flux exceeds the polluted one
+    assert (g["ref_swdflxcln"][:, 0] > g["ref_swdflx"][:, 0]).all()
+    # top extra layer has zero heating (SW:9433-9434)
+    assert (g["ref_swhr"][:, -1] == 0).all()
+
+
+def test_sw_clean_equals_allsky_without_aerosol(sw_oracle):
+    g = np.load(os.path.join(GOLD, "sw_cols_k50_variant.npz"))
+    cols = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    # columns ::5 of the variant fixture carry no aerosol: call #1 == call #2
+    np.testing.assert_array_equal(g["ref_swuflx"][::5], g["ref_swuflxcln"][::5])
+    out = sw_oracle.rrtmg_sw({k: v[::5] for k, v in cols.items()}, clean=0)
+    assert (out["swuflxcln"] == 0).all() and (out["swdflxcln"] == 0).all()   # SW:9473-9478
+
+
+def test_sw_init_reduction_matches_reference(sw_oracle):
+    """rrtmg_sw_ini / cmbgbNN: strided sample + checksum of the reference's reduced tables."""
+    g = np.load(os.path.join(GOLD, "sw_reduced_tables.npz"))
+    parts = [sw_oracle.table(16, "exp_tbl"), sw_oracle.table(16, "rwgt")]
+    order = {16: ["absa", "absb", "selfref", "forref", "sfluxref"], 17: None, 18: None, 19: None,
+             20: ["absa", "absb", "selfref", "forref", "sfluxref", "absch4"], 21: None, 22: None,
+             23: ["absa", "selfref", "forref", "sfluxref", "rayl"],
+             24: ["absa", "absb", "selfref", "forref", "sfluxref", "rayla", "raylb", "abso3a", "abso3b"],
+             25: ["absa", "sfluxref", "rayl", "abso3a", "abso3b"], 26: ["sfluxref", "rayl"],
+             27: ["absa", "absb", "sfluxref", "rayl"], 28: ["absa", "absb", "sfluxref"],
+             29: ["absa", "absb", "selfref", "forref", "sfluxref", "absh2o", "absco2"]}
+    for band in range(16, 30):
+        for name in order[band] or order[16]:
+            parts.append(sw_oracle.table(band, name))
+    d = np.concatenate(parts)
+    assert d.size == int(g["n"])
+    np.testing.assert_array_equal(d[::int(g["stride"])], g["sample"])
+    np.testing.assert_array_equal(d[:10001], g["exp_tbl"])
+    assert d.sum() == float(g["total"])

@@ -1,0 +1,294 @@
+// C ABI of the engine (include/rrtmg_hip.h).  No CPU fallback: every entry
+// point fails loudly if the device or the HIP path is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmg_hip.h"
+#include "rrtmg_common.h"
+#include "rrtmg_state.h"
+#include "sw_kernel.h"
+
+namespace rrtmg {
+
+SwState &sw_state()
+{
+    static SwState s;
+    return s;
+}
+
+namespace {
+
+std::mutex g_init_mutex;
+
+int fail(char *err, const std::string &msg)
+{
+    if (err) {
+        std::strncpy(err, msg.c_str(), RRTMG_HIP_ERRLEN - 1);
+        err[RRTMG_HIP_ERRLEN - 1] = 0;
+    }
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(err, std::string("rrtmg_hip: ") + #expr + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// per-call staging of a mem=0 (host pointer) tile
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
+    hipError_t in(const void *host, size_t bytes, hipStream_t s, const void **dev)
+    {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return e;
+        bufs.push_back(d);
+        *dev = d;
+        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
+    }
+    hipError_t out(void *host, size_t bytes, hipStream_t s, void **dev, bool preload)
+    {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return e;
+        bufs.push_back(d);
+        *dev = d;
+        // INOUT semantics: the routine writes only its tile / daylit columns
+        return preload ? hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    }
+};
+
+}  // namespace
+}  // namespace rrtmg
+
+using namespace rrtmg;
+
+extern "C" const char *rrtmg_hip_version(void) { return "rrtmg_hip 0.1 gfx950"; }
+
+extern "C" int rrtmg_hip_sw_init(const char *data_path, int data_real_bytes, double cpdair, int device, char *err)
+{
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    SwState &st = sw_state();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(err, "rrtmg_hip_sw_init: no HIP device visible (the engine has no CPU path)");
+    HIPCHK(hipSetDevice(device));
+    std::string msg;
+    SwHostTables host;
+    if (sw_build_tables(data_path, data_real_bytes, cpdair, host, msg)) return fail(err, msg);
+    if (st.dK) { (void)hipFree(st.dK); (void)hipFree(st.dExp); (void)hipFree(st.dG); st.dK = st.dExp = st.dG = nullptr; }
+    HIPCHK(hipMalloc(&st.dK, host.K.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&st.dExp, host.exp_tbl.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&st.dG, host.gdesc.size() * sizeof(GDesc)));
+    HIPCHK(hipMemcpy(st.dK, host.K.data(), host.K.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st.dExp, host.exp_tbl.data(), host.exp_tbl.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(st.dG, host.gdesc.data(), host.gdesc.size() * sizeof(GDesc), hipMemcpyHostToDevice));
+    HIPCHK(sw_upload_constants(nullptr));
+    if (!st.dStatus) HIPCHK(hipMalloc(&st.dStatus, sizeof(int)));
+    HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
+    st.dev.K = static_cast<const double *>(st.dK);
+    st.dev.exp_tbl = static_cast<const double *>(st.dExp);
+    st.dev.gdesc = static_cast<const GDesc *>(st.dG);
+    st.dev.bpade = host.bpade;
+    st.dev.heatfac = host.heatfac;
+    st.dev.oneminus = host.oneminus;
+    st.host = std::move(host);
+    st.device = device;
+    st.ready = true;
+    return 0;
+}
+
+// host-side reduced tables for parity tests of the init path (no device needed)
+extern "C" int rrtmg_hip_sw_reduce_tables(const char *data_path, int data_real_bytes, double cpdair,
+                                          double *k_out, long long k_cap, long long *k_len,
+                                          double *exp_out, char *err)
+{
+    std::string msg;
+    SwHostTables host;
+    if (sw_build_tables(data_path, data_real_bytes, cpdair, host, msg)) return fail(err, msg);
+    if (k_len) *k_len = (long long)host.K.size();
+    if (k_out) {
+        if ((long long)host.K.size() > k_cap) return fail(err, "rrtmg_hip_sw_reduce_tables: buffer too small");
+        std::memcpy(k_out, host.K.data(), host.K.size() * sizeof(double));
+    }
+    if (exp_out) std::memcpy(exp_out, host.exp_tbl.data(), host.exp_tbl.size() * sizeof(double));
+    return 0;
+}
+
+// table lookups by (band, name) into the packed layout, for the same tests
+extern "C" int rrtmg_hip_sw_table_info(const char *data_path, int data_real_bytes, int g, int *fields /*[16]*/,
+                                       double *dfields /*[10]*/, char *err)
+{
+    std::string msg;
+    static SwHostTables host;
+    static std::string cached;
+    if (cached != data_path) {
+        host = SwHostTables{};
+        if (sw_build_tables(data_path, data_real_bytes, 1004.5, host, msg)) return fail(err, msg);
+        cached = data_path;
+    }
+    if (g < 0 || g >= SW_NGPT) return fail(err, "g out of range");
+    const GDesc &d = host.gdesc[g];
+    int f[16] = {d.band, d.ig, d.ng, d.lo.off_major, d.up.off_major, d.off_self, d.off_for, d.off_sflux,
+                 d.off_rayla, d.nsf, d.layreffr, d.solar_kind, d.uvband, (int)d.lo.cfg, (int)d.up.cfg, 0};
+    std::memcpy(fields, f, sizeof f);
+    double df[10] = {d.lo.strrat, d.up.strrat, d.lo.mfac, d.up.mfac, d.lo.minorabs, d.up.minorabs,
+                     d.lo.rayl, d.up.rayl, d.scalekur, 0};
+    std::memcpy(dfields, df, sizeof df);
+    return 0;
+}
+
+extern "C" long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *a)
+{
+    const long long ni = a->ime - a->ims + 1, nk = a->kme - a->kms + 1, nj = a->jme - a->jms + 1;
+    const long long n2 = ni * nj * a->real_bytes, n3 = ni * nk * nj * a->real_bytes;
+    return 3 * n2 + 6 * n3 + (a->aer_ra_feedback ? 8 * n3 : 0) + n3 + 22 * n2;
+}
+
+extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
+{
+    SwState &st = sw_state();
+    if (!st.ready) return fail(err, "rrtmg_hip_swrad: rrtmg_hip_sw_init has not been called");
+    if (a->real_bytes != 4 && a->real_bytes != 8) return fail(err, "rrtmg_hip_swrad: real_bytes must be 4 or 8");
+    if (a->icloud != 0)
+        return fail(err, "rrtmg_hip_swrad: icloud /= 0 (McICA cloudy columns) is not implemented in this release");
+    const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
+    const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk = a->kte - a->kts + 1;
+    if (ni_t <= 0 || nj_t <= 0 || nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
+        a->jte > a->jme || a->kts < a->kms || a->kte + 1 > a->kme)
+        return fail(err, "rrtmg_hip_swrad: inconsistent tile / memory dimensions");
+    if (nk + 2 > 64) return fail(err, "rrtmg_hip_swrad: more than 62 model layers are not supported");
+    if (a->aer_ra_feedback == 1 &&
+        !(a->tauaer300 && a->tauaer400 && a->tauaer600 && a->tauaer999 && a->gaer300 && a->gaer400 && a->gaer600 &&
+          a->gaer999 && a->waer300 && a->waer400 && a->waer600 && a->waer999))
+        return fail(err, "Warning: missing fields required for aerosol radiation");   // SW:10287-10305
+    if (sw_lds_bytes(nk) > 160 * 1024) return fail(err, "rrtmg_hip_swrad: column does not fit LDS");
+    HIPCHK(hipSetDevice(st.device));
+
+    hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
+    const size_t rb = a->real_bytes;
+    const size_t n2 = (size_t)ni_m * nj_m * rb, n3 = (size_t)ni_m * nk_m * nj_m * rb,
+                 n3f = (size_t)ni_m * (nk_m + 2) * nj_m * rb;
+
+    SwKernelArgs k{};
+    k.ims = a->ims; k.jms = a->jms; k.kms = a->kms; k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
+    k.its = a->its; k.jts = a->jts; k.kts = a->kts; k.ni_t = ni_t; k.nj_t = nj_t; k.nk = nk;
+    k.real4 = a->real_bytes == 4;
+    k.aer_ra_feedback = a->aer_ra_feedback; k.clean = a->clean_atm_diag; k.o3input = a->o3input;
+    k.solcon = a->solcon;
+    k.tab = st.dev;
+
+    Staging stg;
+    int *d_status = static_cast<int *>(st.dStatus);
+    if (a->mem != 1) HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), stream));
+    k.status = d_status;
+
+    struct OutCopy { void *host; void *dev; size_t bytes; };
+    std::vector<OutCopy> outs;
+    if (a->mem == 1) {
+        k.xcoszen = a->xcoszen; k.albedo = a->albedo; k.tsk = a->tsk;
+        k.t3d = a->t3d; k.t8w = a->t8w; k.p3d = a->p3d; k.p8w = a->p8w; k.pi3d = a->pi3d; k.qv3d = a->qv3d;
+        k.o33d = a->o33d;
+        k.tauaer300 = a->tauaer300; k.tauaer400 = a->tauaer400; k.tauaer600 = a->tauaer600; k.tauaer999 = a->tauaer999;
+        k.gaer400 = a->gaer400; k.gaer600 = a->gaer600; k.waer400 = a->waer400; k.waer600 = a->waer600;
+        k.rthratensw = a->rthratensw; k.coszr = a->coszr; k.gsw = a->gsw; k.swcf = a->swcf;
+        k.swupt = a->swupt; k.swuptc = a->swuptc; k.swuptcln = a->swuptcln; k.swdnt = a->swdnt;
+        k.swdntc = a->swdntc; k.swdntcln = a->swdntcln; k.swupb = a->swupb; k.swupbc = a->swupbc;
+        k.swupbcln = a->swupbcln; k.swdnb = a->swdnb; k.swdnbc = a->swdnbc; k.swdnbcln = a->swdnbcln;
+        k.swvisdir = a->swvisdir; k.swvisdif = a->swvisdif; k.swnirdir = a->swnirdir; k.swnirdif = a->swnirdif;
+        k.swddir = a->swddir; k.swddni = a->swddni; k.swddif = a->swddif;
+        k.swupflx = a->swupflx; k.swupflxc = a->swupflxc; k.swupflxcln = a->swupflxcln;
+        k.swdnflx = a->swdnflx; k.swdnflxc = a->swdnflxc; k.swdnflxcln = a->swdnflxcln;
+    } else {
+#define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
+#define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
+#define OUT(f, bytes)                                                           \
+    do {                                                                        \
+        HIPCHK(stg.out(a->f, bytes, stream, &k.f, true));                       \
+        if (a->f) outs.push_back({a->f, k.f, bytes});                           \
+    } while (0)
+        IN2(xcoszen); IN2(albedo); IN2(tsk);
+        IN3(t3d); IN3(t8w); IN3(p3d); IN3(p8w); IN3(pi3d); IN3(qv3d); IN3(o33d);
+        if (a->aer_ra_feedback == 1) {
+            IN3(tauaer300); IN3(tauaer400); IN3(tauaer600); IN3(tauaer999);
+            IN3(gaer400); IN3(gaer600); IN3(waer400); IN3(waer600);
+        }
+        OUT(rthratensw, n3); OUT(coszr, n2); OUT(gsw, n2); OUT(swcf, n2);
+        OUT(swupt, n2); OUT(swuptc, n2); OUT(swuptcln, n2); OUT(swdnt, n2); OUT(swdntc, n2); OUT(swdntcln, n2);
+        OUT(swupb, n2); OUT(swupbc, n2); OUT(swupbcln, n2); OUT(swdnb, n2); OUT(swdnbc, n2); OUT(swdnbcln, n2);
+        OUT(swvisdir, n2); OUT(swvisdif, n2); OUT(swnirdir, n2); OUT(swnirdif, n2);
+        OUT(swddir, n2); OUT(swddni, n2); OUT(swddif, n2);
+        OUT(swupflx, n3f); OUT(swupflxc, n3f); OUT(swupflxcln, n3f);
+        OUT(swdnflx, n3f); OUT(swdnflxc, n3f); OUT(swdnflxcln, n3f);
+#undef IN2
+#undef IN3
+#undef OUT
+    }
+    if (!(k.xcoszen && k.albedo && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
+        return fail(err, "rrtmg_hip_swrad: a required input array is NULL");
+    if (a->swupt && !(a->swuptc && a->swuptcln && a->swdnt && a->swdntc && a->swdntcln && a->swupb && a->swupbc &&
+                      a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
+        return fail(err, "rrtmg_hip_swrad: the twelve TOA/surface flux arrays must be passed together");
+
+    HIPCHK(sw_launch(k, ni_t * nj_t, stream));
+
+    if (a->mem != 1) {
+        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
+        int status = 0;
+        HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (status != 0) {
+            const int col = status - 1;
+            char m[RRTMG_HIP_ERRLEN];
+            std::snprintf(m, sizeof m, "ERROR: Negative total optical depth at point i,j=%5d%5d",
+                          a->its + col % ni_t, a->jts + col / ni_t);   // SW:11031-11033
+            return fail(err, m);
+        }
+    }
+    // mem = 1: nothing synchronises here; rrtmg_hip_sw_status() reports a fatal raised on the device
+    return 0;
+}
+
+extern "C" int rrtmg_hip_sw_status(char *err)
+{
+    SwState &st = sw_state();
+    if (!st.ready) return fail(err, "rrtmg_hip_sw_status: rrtmg_hip_sw_init has not been called");
+    HIPCHK(hipSetDevice(st.device));
+    HIPCHK(hipDeviceSynchronize());
+    int status = 0;
+    HIPCHK(hipMemcpy(&status, st.dStatus, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
+    if (status != 0) {
+        char m[RRTMG_HIP_ERRLEN];
+        std::snprintf(m, sizeof m, "ERROR: Negative total optical depth at tile column %d", status - 1);
+        return fail(err, m);
+    }
+    return 0;
+}
+
+extern "C" int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *, double *, char *err)
+{
+    return fail(err, "rrtmg_hip_sw_tile_sums: not implemented yet");
+}
+
+extern "C" int rrtmg_hip_finalize(void)
+{
+    SwState &st = sw_state();
+    if (st.dK) { (void)hipFree(st.dK); (void)hipFree(st.dExp); (void)hipFree(st.dG); }
+    if (st.dStatus) (void)hipFree(st.dStatus);
+    st.dK = st.dExp = st.dG = st.dStatus = nullptr;
+    st.ready = false;
+    return 0;
+}

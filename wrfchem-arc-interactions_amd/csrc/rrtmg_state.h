@@ -1,0 +1,30 @@
+// Host-side state of the engine: tables built at init, device copies.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "rrtmg_common.h"
+
+namespace rrtmg {
+
+struct SwHostTables {
+    std::vector<double> K;
+    std::vector<double> exp_tbl;
+    std::vector<GDesc> gdesc;
+    double bpade = 0, heatfac = 0, oneminus = 0;
+};
+
+// sw_tables.hip
+int sw_build_tables(const char *path, int real_bytes, double cpdair, SwHostTables &out, std::string &err);
+
+struct SwState {
+    bool ready = false;
+    int device = 0;
+    SwHostTables host;
+    SwDeviceTables dev{};
+    void *dK = nullptr, *dExp = nullptr, *dG = nullptr, *dStatus = nullptr;
+};
+
+SwState &sw_state();
+
+}  // namespace rrtmg

@@ -1,0 +1,740 @@
+// Shortwave column kernel: RRTMG_SWRAD + rrtmg_sw (aerosol and clean-sky
+// calls in one launch) for gfx950.
+//
+// Reference path (phys/module_ra_rrtmg_sw.F): RRTMG_SWRAD preprocessing
+// SW:10320-11071, inatm_sw SW:9735-9790, setcoef_sw SW:2734-2990, taumol_sw
+// SW:3081-4540, spcvmc_sw SW:8344-8650, reftra_sw SW:2422-2701, vrtqdr_sw
+// SW:7922-8046, rrtmg_sw post-processing SW:9391-9486, outputs SW:11125-11197.
+//
+// Mapping (MI355X-first, not the reference's loop nest):
+//   * one 256-thread workgroup per daylit column; blockIdx is remapped so that
+//     the workgroups of one XCD walk consecutive i (they share the 64-B sectors
+//     of the (i,k,j) state in that XCD's L2).
+//   * prologue: lanes = layers.  Gathers the column, builds the 1-D profile,
+//     O3 climatology, column amounts and the setcoef interpolation factors once
+//     and leaves them in LDS; aerosol wavelength->band mapping into LDS.
+//   * main phase: lanes = g-points.  Wave w handles g-chunk (w&1) of pass
+//     (w>>1): pass 0 = with aerosol, pass 1 = clean sky.  Gas optics are
+//     evaluated by one data-driven formula (per-g descriptor) so the 14 bands
+//     never diverge.  The vertical adding recurrence is sequential in k per
+//     lane; to avoid a per-lane, per-level fp64 store of the whole profile
+//     (43 KB per wave), the upward sweep keeps only every 4th level in LDS
+//     and the downward sweep recomputes the layer reflectances block by block
+//     (register-resident, statically indexed).
+//   * per-level spectral sums (SW:8629-8634) are wave reductions; the two
+//     chunk waves of a pass meet in LDS; the epilogue (lanes = levels) forms
+//     net fluxes, heating rates and writes the WRF arrays.
+// No MFMA: there is no contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+
+#include "rrtmg_common.h"
+#include "sw_kernel.h"
+
+namespace rrtmg {
+
+namespace {
+
+constexpr int BLK = 4;            // layers per recompute block
+constexpr int CHUNK = 56;         // g-points per wave (112 = 2 x 56)
+constexpr int NTHREADS = 256;
+
+// reference atmosphere, SW:3019-3045 (preflog is 6.96 - 0.2*i)
+__constant__ double c_tref[59] = {
+    2.9420e+02, 2.8799e+02, 2.7894e+02, 2.6925e+02, 2.5983e+02, 2.5017e+02, 2.4077e+02, 2.3179e+02,
+    2.2306e+02, 2.1578e+02, 2.1570e+02, 2.1570e+02, 2.1570e+02, 2.1706e+02, 2.1858e+02, 2.2018e+02,
+    2.2174e+02, 2.2328e+02, 2.2479e+02, 2.2655e+02, 2.2834e+02, 2.3113e+02, 2.3401e+02, 2.3703e+02,
+    2.4022e+02, 2.4371e+02, 2.4726e+02, 2.5085e+02, 2.5457e+02, 2.5832e+02, 2.6216e+02, 2.6606e+02,
+    2.6999e+02, 2.7340e+02, 2.7536e+02, 2.7568e+02, 2.7372e+02, 2.7163e+02, 2.6955e+02, 2.6593e+02,
+    2.6211e+02, 2.5828e+02, 2.5360e+02, 2.4854e+02, 2.4348e+02, 2.3809e+02, 2.3206e+02, 2.2603e+02,
+    2.2000e+02, 2.1435e+02, 2.0887e+02, 2.0340e+02, 1.9792e+02, 1.9290e+02, 1.8809e+02, 1.8329e+02,
+    1.7849e+02, 1.7394e+02, 1.7212e+02};
+__constant__ double c_preflog[59] = {
+    6.9600e+00, 6.7600e+00, 6.5600e+00, 6.3600e+00, 6.1600e+00, 5.9600e+00, 5.7600e+00, 5.5600e+00,
+    5.3600e+00, 5.1600e+00, 4.9600e+00, 4.7600e+00, 4.5600e+00, 4.3600e+00, 4.1600e+00, 3.9600e+00,
+    3.7600e+00, 3.5600e+00, 3.3600e+00, 3.1600e+00, 2.9600e+00, 2.7600e+00, 2.5600e+00, 2.3600e+00,
+    2.1600e+00, 1.9600e+00, 1.7600e+00, 1.5600e+00, 1.3600e+00, 1.1600e+00, 9.6000e-01, 7.6000e-01,
+    5.6000e-01, 3.6000e-01, 1.6000e-01, -4.0000e-02, -2.4000e-01, -4.4000e-01, -6.4000e-01, -8.4000e-01,
+    -1.0400e+00, -1.2400e+00, -1.4400e+00, -1.6400e+00, -1.8400e+00, -2.0400e+00, -2.2400e+00, -2.4400e+00,
+    -2.6400e+00, -2.8400e+00, -3.0400e+00, -3.2400e+00, -3.4400e+00, -3.6400e+00, -3.8400e+00, -4.0400e+00,
+    -4.2400e+00, -4.4400e+00, -4.6400e+00};
+// O3 climatology of INIRAD/O3DATA, LW:12730-12756 (annual mean built on the host)
+__constant__ double c_o3ann[31];
+__constant__ double c_ppwrkh[32];
+// band mid wavelengths (um) of the 14 SW intervals, from wavemin/wavemax SW:10080-10085
+__constant__ double c_wavemid[SW_NBND];
+
+__device__ __forceinline__ double ldr(const void *p, size_t idx, int real4)
+{
+    return real4 ? (double)reinterpret_cast<const float *>(p)[idx] : reinterpret_cast<const double *>(p)[idx];
+}
+__device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
+{
+    if (real4) reinterpret_cast<float *>(p)[idx] = (float)v;
+    else reinterpret_cast<double *>(p)[idx] = v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// transmittance by lookup table or small-argument expansion (SW:8459-8466, 2575-2581)
+__device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze1)
+{
+    double tblind = ze1 / (tb.bpade + ze1);
+    int itind = (int)(10000.0 * tblind + 0.5);
+    itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
+    double tv = tb.exp_tbl[itind];
+    double sv = 1. - ze1 + 0.5 * ze1 * ze1;
+    return ze1 <= 0.06 ? sv : tv;
+}
+
+struct RT {
+    double ref, refd, tra, trad, dbt;
+};
+
+// reftra_sw, PIFM (kmodts = 2), SW:2526-2699, for one layer
+__device__ __forceinline__ void reftra(const SwDeviceTables &tb, double zto1, double zw, double zg, double prmuz,
+                                       RT &o)
+{
+    const double eps = 1.e-08, zwcrit = 0.9999995;
+    double zg3 = 3. * zg;
+    double zgamma1 = (8. - zw * (5. + zg3)) * 0.25;
+    double zgamma2 = 3. * (zw * (1. - zg)) * 0.25;
+    double zgamma3 = (2. - zg3 * prmuz) * 0.25;
+    double zgamma4 = 1. - zgamma3;
+    double zq = zg / (1. - zg);
+    double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
+    double zwo = zw / denom;
+    if (zwo >= zwcrit) {
+        // conservative scattering, SW:2560-2600
+        double za = zgamma1 * prmuz;
+        double za1 = za - zgamma3;
+        double zgt = zgamma1 * zto1;
+        double ze1 = fmin(zto1 / prmuz, 500.);
+        double ze2 = exp_lookup(tb, ze1);
+        double r = (zgt - za1 * (1. - ze2)) / (1. + zgt);
+        double rd = zgt / (1. + zgt);
+        bool one = (ze2 == 1.0);
+        o.ref = one ? 0.0 : r;
+        o.tra = one ? 1.0 : 1. - r;
+        o.refd = one ? 0.0 : rd;
+        o.trad = one ? 1.0 : 1. - rd;
+    } else {
+        double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
+        double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
+        double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        double zrp = zrk * prmuz;
+        double zrp1 = 1. + zrp;
+        double zrm1 = 1. - zrp;
+        double zrk2 = 2. * zrk;
+        double zrpp = 1. - zrp * zrp;
+        double zrkg = zrk + zgamma1;
+        double zr1 = zrm1 * (za2 + zrk * zgamma3);
+        double zr2 = zrp1 * (za2 - zrk * zgamma3);
+        double zr3 = zrk2 * (zgamma3 - za2 * prmuz);
+        double zr4 = zrpp * zrkg;
+        double zr5 = zrpp * (zrk - zgamma1);
+        double zt1 = zrp1 * (za1 + zrk * zgamma4);
+        double zt2 = zrm1 * (za1 - zrk * zgamma4);
+        double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
+        double zbeta = (zgamma1 - zrk) / zrkg;
+        double ze1 = fmin(zrk * zto1, 500.);
+        double ze2 = fmin(zto1 / prmuz, 500.);
+        double zem1 = exp_lookup(tb, ze1);
+        double zep1 = 1. / zem1;
+        double zem2 = exp_lookup(tb, ze2);
+        double zep2 = 1. / zem2;
+        double zdenr = zr4 * zep1 + zr5 * zem1;
+        double zdent = zr4 * zep1 + zr5 * zem1;
+        bool small = (zdenr >= -eps && zdenr <= eps);
+        double r = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
+        double t = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
+        o.ref = small ? eps : r;
+        o.tra = small ? zem2 : t;
+        double zemm = zem1 * zem1;
+        double zdend = 1. / ((1. - zbeta * zemm) * zrkg);
+        o.refd = zgamma2 * (1. - zemm) * zdend;
+        o.trad = zrk2 * zem1 * zdend;
+    }
+}
+
+// LDS image of one column (all arrays indexed by 0-based layer, bottom -> top)
+struct ColView {
+    double *fac00, *fac01, *fac10, *fac11;
+    double *selffac, *selffrac, *forfac, *forfrac;
+    double *col;        // [SP_COUNT][nlp]
+    double *colmol, *pdp;
+    double *taer, *waer, *gaer;   // [14][nlp]
+    int *rb0, *rb1, *inds, *indf, *jp;   // row bases (0-based), continuum rows, jp
+    double *ckpt;       // [4 waves][nck][2][64]
+    double *flux;       // [4 waves][nlev][2]
+    double *sfc;        // [4 waves][8] surface-only sums
+    int nlp;            // padded layer count (multiple of BLK)
+};
+
+__device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nlev)
+{
+    ColView v;
+    v.nlp = nlp;
+    double *p = base;
+    v.fac00 = p; p += nlp; v.fac01 = p; p += nlp; v.fac10 = p; p += nlp; v.fac11 = p; p += nlp;
+    v.selffac = p; p += nlp; v.selffrac = p; p += nlp; v.forfac = p; p += nlp; v.forfrac = p; p += nlp;
+    v.col = p; p += SP_COUNT * nlp;
+    v.colmol = p; p += nlp; v.pdp = p; p += nlp;
+    v.taer = p; p += SW_NBND * nlp; v.waer = p; p += SW_NBND * nlp; v.gaer = p; p += SW_NBND * nlp;
+    v.ckpt = p; p += 4 * nck * 2 * 64;
+    v.flux = p; p += 4 * nlev * 2;
+    v.sfc = p; p += 4 * 8;
+    int *q = reinterpret_cast<int *>(p);
+    v.rb0 = q; q += nlp; v.rb1 = q; q += nlp; v.inds = q; q += nlp; v.indf = q; q += nlp; v.jp = q; q += nlp + 1;
+    return v;
+}
+
+struct LaneG {   // per-lane (g-point) constants
+    GRegime lo, up;
+    int ng, off_self, off_for, band, off_rayla;
+};
+
+// gaseous + Rayleigh optical depth of layer k for this lane's g-point: the
+// 14 taumolNN routines (SW:3293-4540) as one data-driven expression
+__device__ __forceinline__ void gas_optics(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
+                                           bool lower, double &taug, double &taur)
+{
+    const GRegime &R = lower ? L.lo : L.up;
+    const uint32_t cf = R.cfg;
+    const int nlp = c.nlp;
+    const int spa = (cf >> CFG_SPA_SHIFT) & 7, spb = (cf >> CFG_SPB_SHIFT) & 7, spm = (cf >> CFG_SPM_SHIFT) & 7;
+    const int nsp = (cf >> CFG_NSP_SHIFT) & 15;
+    const double colA = c.col[spa * nlp + k], colB = c.col[spb * nlp + k], colM = c.col[spm * nlp + k];
+    const double colh2o = c.col[SP_H2O * nlp + k];
+    double speccomb = colA, fs = 0.;
+    int jsi = 0;
+    if (cf & CFG_BINARY) {
+        // SW:3321-3326
+        speccomb = colA + R.strrat * colB;
+        double specparm = colA / speccomb;
+        specparm = specparm >= tb.oneminus ? tb.oneminus : specparm;
+        double specmult = ((cf & CFG_MULT4) ? 4. : 8.) * specparm;
+        jsi = (int)specmult;
+        fs = specmult - (double)jsi;
+    }
+    const double f00 = c.fac00[k], f10 = c.fac10[k], f01 = c.fac01[k], f11 = c.fac11[k];
+    const double omf = 1. - fs;
+    const int ng = L.ng;
+    const double *K0 = tb.K + R.off_major + (size_t)(c.rb0[k] * nsp + jsi) * ng;
+    const double *K1 = tb.K + R.off_major + (size_t)(c.rb1[k] * nsp + jsi) * ng;
+    const int dT = nsp * ng;
+    // SW:3342-3350 (8-point) / SW:3374-3378 (4-point: fs = 0, zero-weight terms are exact)
+    double S = (omf * f00) * K0[0] + (fs * f00) * K0[ng] + (omf * f10) * K0[dT] + (fs * f10) * K0[dT + ng] +
+               (omf * f01) * K1[0] + (fs * f01) * K1[ng] + (omf * f11) * K1[dT] + (fs * f11) * K1[dT + ng];
+    double major = (cf & CFG_MAJOR) ? (speccomb * R.mfac) * S : 0.;
+    // continua, SW:3351-3357
+    double cont = 0.;
+    if (cf & (CFG_SELF | CFG_FOR)) {
+        const double *Sf = tb.K + L.off_self + (size_t)c.inds[k] * ng;
+        const double *Ff = tb.K + L.off_for + (size_t)c.indf[k] * ng;
+        double s0 = Sf[0], s1 = Sf[ng], f0 = Ff[0], f1 = Ff[ng];
+        double selft = (cf & CFG_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
+        double fort = (cf & CFG_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
+        cont = colh2o * (selft + fort);
+    }
+    double t = major + colM * R.minorabs + cont;
+    if (cf & CFG_O2CONT) t += 4.35e-4 * c.col[SP_O2 * nlp + k] / (350.0 * 2.0);   // SW:3933
+    taug = t;
+    double rayl = R.rayl;
+    if (cf & CFG_RAYL24) {   // SW:4130-4131
+        const double *Ra = tb.K + L.off_rayla + (size_t)jsi * ng;
+        double r0 = Ra[0], r1 = Ra[ng];
+        rayl = r0 + fs * (r1 - r0);
+    }
+    taur = c.colmol[k] * rayl;
+}
+
+// optical properties of layer k as seen by the two-stream solver (spcvmc_sw
+// layer preparation, SW:8443-8501) followed by reftra and the delta-scaled
+// direct-beam transmittance (SW:8568-8578).  dbt_nodel: unscaled direct beam
+// (SW:8459-8469), only requested by the aerosol pass on its way down.
+template <bool NODEL>
+__device__ __forceinline__ void layer_rt(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
+                                         bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel)
+{
+    double taug, taur;
+    gas_optics(tb, c, L, k, lower, taug, taur);
+    const int ia = L.band * c.nlp + k;
+    const double ta = aer_on ? c.taer[ia] : 0.0;   // clean call: ztauacln = 0 (SW:9346), omega/g unchanged
+    const double wa = c.waer[ia], ga = c.gaer[ia];
+    double ztauc = taur + taug + ta;
+    double zomcc = taur * 1.0 + ta * wa;
+    double zgcc = ga * wa * ta / zomcc;
+    zomcc = zomcc / ztauc;
+    if (NODEL) dbt_nodel = exp_lookup(tb, ztauc / prmu0);
+    double zf = zgcc * zgcc;
+    double zwf = zomcc * zf;
+    ztauc = (1.0 - zwf) * ztauc;
+    zomcc = (zomcc - zwf) / fmax((1.0 - zwf), 1.0E-30);
+    zgcc = (zgcc - zf) / fmax((1.0 - zf), 1.0E-30);
+    reftra(tb, ztauc, zomcc, zgcc, prmu0, o);
+    o.dbt = exp_lookup(tb, ztauc / prmu0);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelArgs a)
+{
+    extern __shared__ double lds[];
+    const SwDeviceTables &tb = a.tab;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nk = a.nk, nlay = nk + 1, nlev = nlay + 1;
+    const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
+    ColView c = carve(lds, nlp, nblk, nlev);
+
+    // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
+    int col;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        col = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int it = col % a.ni_t, jt = col / a.ni_t;            // position inside the tile
+    const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt);
+    const size_t k0 = (size_t)(a.kts - a.kms);
+    const size_t i2 = j0 * a.ni_m + i0;
+    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m, sjf = (size_t)a.ni_m * (a.nk_m + 2);
+    const size_t base3 = j0 * sj + k0 * sk + i0, base3f = j0 * sjf + k0 * sk + i0;
+    const int r4 = a.real4;
+
+    const double coszrs = ldr(a.xcoszen, i2, r4);
+    if (tid == 0 && a.coszr) str(a.coszr, i2, r4, coszrs);
+    if (coszrs <= 0.0) {
+        // night column, SW:11173-11197: zero the 2-D fluxes, leave gsw / rthratensw untouched
+        if (tid == 0) {
+            if (a.swupt) {
+                str(a.swupt, i2, r4, 0.); str(a.swuptc, i2, r4, 0.); str(a.swuptcln, i2, r4, 0.);
+                str(a.swdnt, i2, r4, 0.); str(a.swdntc, i2, r4, 0.); str(a.swdntcln, i2, r4, 0.);
+                str(a.swupb, i2, r4, 0.); str(a.swupbc, i2, r4, 0.); str(a.swupbcln, i2, r4, 0.);
+                str(a.swdnb, i2, r4, 0.); str(a.swdnbc, i2, r4, 0.); str(a.swdnbcln, i2, r4, 0.);
+                if (a.swvisdir) {
+                    str(a.swvisdir, i2, r4, 0.); str(a.swvisdif, i2, r4, 0.);
+                    str(a.swnirdir, i2, r4, 0.); str(a.swnirdif, i2, r4, 0.);
+                }
+            }
+            if (a.swddir) { str(a.swddir, i2, r4, 0.); str(a.swddni, i2, r4, 0.); str(a.swddif, i2, r4, 0.); }
+            if (a.swcf) str(a.swcf, i2, r4, 0.);
+        }
+        return;
+    }
+
+    // ======================= prologue: lanes = layers =======================
+    bool lowerp = false;
+    if (tid < nlp) {
+        const int k = tid;
+        if (k < nlay) {
+            // 1-D profile, SW:10340-10390, 10628-10656 (extra layer to 1e-5 mb on top)
+            const bool top = (k == nk);
+            const int km = top ? nk - 1 : k;
+            double plev_b = ldr(a.p8w, base3 + (size_t)k * sk, r4) / 100.;
+            double plev_t = top ? 1.0e-5 : ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4) / 100.;
+            double pavel = top ? 0.5 * plev_b : ldr(a.p3d, base3 + (size_t)k * sk, r4) / 100.;
+            double tavel = top ? ldr(a.t8w, base3 + (size_t)k * sk, r4) + 0.0 : ldr(a.t3d, base3 + (size_t)k * sk, r4);
+            double qv = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
+            qv = fmax(0., qv);
+            qv = fmax(qv, 1.E-12);
+            const double amdw = 1.607793, amdo = 0.603461;
+            double h2ovmr = qv * amdw;
+            // O3 climatology, O3DATA LW:12806-12836
+            double o3mmr = 0.;
+            for (int jj = 0; jj < 31; ++jj) {
+                double pb1 = (-(plev_b - c_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj];
+                double pb2 = (-(plev_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj + 1];
+                double pt1 = (-(plev_t - c_ppwrkh[jj]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj];
+                double pt2 = (-(plev_t - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj + 1];
+                o3mmr = o3mmr + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
+            }
+            o3mmr = o3mmr / (plev_b - plev_t);
+            double o3vmr = o3mmr * amdo;
+            if (a.o33d && a.o3input == 2) {   // SW:10661-10680
+                if (!top) {
+                    o3vmr = ldr(a.o33d, base3 + (size_t)k * sk, r4);
+                } else {
+                    // o31d(kte) - o3mmr(kte)*amdo + o3mmr(k)*amdo needs the climatology of the layer below
+                    double pb_b = ldr(a.p8w, base3 + (size_t)(nk - 1) * sk, r4) / 100.;
+                    double o3b = 0.;
+                    for (int jj = 0; jj < 31; ++jj) {
+                        double pb1 = (-(pb_b - c_ppwrkh[jj]) >= 0.) ? 0. : pb_b - c_ppwrkh[jj];
+                        double pb2 = (-(pb_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : pb_b - c_ppwrkh[jj + 1];
+                        double pt1 = (-(plev_b - c_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj];
+                        double pt2 = (-(plev_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj + 1];
+                        o3b = o3b + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
+                    }
+                    o3b = o3b / (pb_b - plev_b);
+                    double v = ldr(a.o33d, base3 + (size_t)(nk - 1) * sk, r4) - o3b * amdo + o3mmr * amdo;
+                    o3vmr = v <= 0. ? o3mmr * amdo : v;
+                }
+            }
+            // inatm_sw, SW:9777-9779 and SW:9810-9814
+            const double avogad = 6.02214199e+23, grav = 9.8066, amd = 28.9660, amw = 18.0160;
+            const double co2 = 379.e-6, ch4 = 1774.e-9, o2 = 0.209488;
+            double pdp = plev_b - plev_t;
+            double amm = (1. - h2ovmr) * amd + h2ovmr * amw;
+            double coldry = (plev_b - plev_t) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + h2ovmr));
+            double wh2o = coldry * h2ovmr, wco2 = coldry * co2, wo3 = coldry * o3vmr, wch4 = coldry * ch4,
+                   wo2 = coldry * o2;
+            // setcoef_sw, SW:2850-2987
+            const double stpfac = 296. / 1013.;
+            double plog = log(pavel);
+            int jp = (int)(36. - 5 * (plog + 0.04));
+            jp = jp < 1 ? 1 : (jp > 58 ? 58 : jp);
+            int jp1 = jp + 1;
+            double fp = 5. * (c_preflog[jp - 1] - plog);
+            double d0 = (tavel - c_tref[jp - 1]) / 15.;
+            int jtt = (int)(3. + d0);
+            jtt = jtt < 1 ? 1 : (jtt > 4 ? 4 : jtt);
+            double ft = d0 - (double)(jtt - 3);
+            double d1 = (tavel - c_tref[jp1 - 1]) / 15.;
+            int jt1 = (int)(3. + d1);
+            jt1 = jt1 < 1 ? 1 : (jt1 > 4 ? 4 : jt1);
+            double ft1 = d1 - (double)(jt1 - 3);
+            double water = wh2o / coldry;
+            double scalefac = pavel * stpfac / tavel;
+            lowerp = plog > 4.56;
+            double forfac = scalefac / (1. + water), forfrac, selffac = 0., selffrac = 0.;
+            int indfor, indself = 1;
+            if (lowerp) {
+                double factor = (332.0 - tavel) / 36.0;
+                int ifac = (int)factor;
+                indfor = ifac > 1 ? (ifac < 2 ? ifac : 2) : 1;
+                forfrac = factor - (double)indfor;
+                selffac = water * forfac;
+                factor = (tavel - 188.0) / 7.2;
+                int is = (int)factor - 7;
+                indself = is > 1 ? (is < 9 ? is : 9) : 1;
+                selffrac = factor - (double)(indself + 7);
+            } else {
+                double factor = (tavel - 188.0) / 36.0;
+                indfor = 3;
+                forfrac = factor - 1.0;
+            }
+            double colh2o = 1.e-20 * wh2o, colco2 = 1.e-20 * wco2, colo3 = 1.e-20 * wo3, colch4 = 1.e-20 * wch4,
+                   colo2 = 1.e-20 * wo2;
+            double colmol = 1.e-20 * coldry + colh2o;
+            if (colco2 == 0.) colco2 = 1.e-32 * coldry;
+            if (colch4 == 0.) colch4 = 1.e-32 * coldry;
+            if (colo2 == 0.) colo2 = 1.e-32 * coldry;
+            double compfp = 1. - fp;
+            c.fac10[k] = compfp * ft;
+            c.fac00[k] = compfp * (1. - ft);
+            c.fac11[k] = fp * ft1;
+            c.fac01[k] = fp * (1. - ft1);
+            c.selffac[k] = selffac; c.selffrac[k] = selffrac; c.forfac[k] = forfac; c.forfrac[k] = forfrac;
+            c.col[SP_H2O * nlp + k] = colh2o; c.col[SP_CO2 * nlp + k] = colco2; c.col[SP_O3 * nlp + k] = colo3;
+            c.col[SP_CH4 * nlp + k] = colch4; c.col[SP_O2 * nlp + k] = colo2; c.col[SP_ZERO * nlp + k] = 0.;
+            c.colmol[k] = colmol; c.pdp[k] = pdp;
+            c.jp[k] = jp;
+            // 0-based row bases of the k-tables: ind0-js, ind1-js of SW:3335-3336 (lower), SW:3369-3370 (upper)
+            c.rb0[k] = lowerp ? ((jp - 1) * 5 + (jtt - 1)) : ((jp - 13) * 5 + (jtt - 1));
+            c.rb1[k] = lowerp ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
+            c.inds[k] = indself - 1;
+            c.indf[k] = indfor - 1;
+        } else {
+            // identity padding layers above the real top: never evaluated, keep LDS defined
+            c.fac00[k] = c.fac01[k] = c.fac10[k] = c.fac11[k] = 0.;
+            c.selffac[k] = c.selffrac[k] = c.forfac[k] = c.forfrac[k] = 0.;
+            for (int s = 0; s < SP_COUNT; ++s) c.col[s * nlp + k] = 0.;
+            c.colmol[k] = 0.; c.pdp[k] = 1.;
+            c.jp[k] = 0; c.rb0[k] = c.rb1[k] = 0; c.inds[k] = c.indf[k] = 0;
+        }
+    }
+    if (tid == 0) c.jp[nlp] = 0;
+    // laytrop = number of layers with ln(p) > 4.56 (SW:2890)
+    const int laytrop = __syncthreads_count(lowerp ? 1 : 0);
+
+    // aerosol: defaults, then 300/400/600/999 nm -> 14 bands (SW:10974-11023)
+    for (int item = tid; item < SW_NBND * nlp; item += NTHREADS) {
+        const int nb = item / nlp, k = item - nb * nlp;
+        double tau = 0., ssa = 1., asy = 0.;
+        if (a.aer_ra_feedback == 1 && k < nk) {
+            const size_t q = base3 + (size_t)k * sk;
+            const double t300 = ldr(a.tauaer300, q, r4), t999 = ldr(a.tauaer999, q, r4);
+            if (t300 > 1.e-9 && t999 > 1.e-9) {
+                const double wavemid = c_wavemid[nb];
+                double ang = log(t300 / t999) / log(999. / 300.);
+                tau = ldr(a.tauaer400, q, r4) * pow(0.4 / wavemid, ang);
+                const double w4 = ldr(a.waer400, q, r4), w6 = ldr(a.waer600, q, r4);
+                double slope = (w6 - w4) / .2;
+                ssa = slope * (wavemid - .6) + w6;
+                if (ssa < 0.4) ssa = 0.4;
+                if (ssa >= 1.0) ssa = 1.0;
+                const double g4 = ldr(a.gaer400, q, r4), g6 = ldr(a.gaer600, q, r4);
+                slope = (g6 - g4) / .2;
+                asy = slope * (wavemid - .6) + g6;
+                if (asy < 0.5) asy = 0.5;
+                if (asy >= 1.0) asy = 1.0;
+            }
+        }
+        c.taer[item] = tau; c.waer[item] = ssa; c.gaer[item] = asy;
+    }
+    __syncthreads();
+    // column optical-depth guard per band (SW:11026-11047): sequential sum as in the reference
+    if (a.aer_ra_feedback == 1 && tid < SW_NBND) {
+        double slope = 0.;
+        for (int k = 0; k < nk; ++k) slope = slope + c.taer[tid * nlp + k];
+        if (slope < 0.) {
+            atomicMax(a.status, 1 + col);   // fatal in the reference ("Negative total optical depth")
+        } else if (slope > 6.) {
+            for (int k = 0; k < nk; ++k) c.taer[tid * nlp + k] = c.taer[tid * nlp + k] * 6.0 / slope;
+        }
+    }
+    __syncthreads();
+
+    // ======================= main phase: lanes = g-points =======================
+    const int chunk = wave & 1, pass = wave >> 1;
+    const bool aer_on = (pass == 0);
+    const bool active = lane < CHUNK;
+    const int g = chunk * CHUNK + (active ? lane : CHUNK - 1);
+    const GDesc gd = tb.gdesc[g];
+    LaneG L;
+    L.lo = gd.lo; L.up = gd.up; L.ng = gd.ng; L.off_self = gd.off_self; L.off_for = gd.off_for;
+    L.band = gd.band; L.off_rayla = gd.off_rayla;
+
+    double *flux = c.flux + (size_t)wave * nlev * 2;
+    if (pass == 1 && a.clean <= 0) {
+        // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
+        for (int l = lane; l < nlev; l += 64) { flux[2 * l] = 0.; flux[2 * l + 1] = 0.; }
+    } else {
+        const double prmu0 = coszrs <= 1.e-10 ? 1.e-10 : coszrs;   // SW:9254-9255
+        // solar source at the layer selected per band (SW:3363-3380, 3533-3538, 4297) -> incoming flux
+        double sfluxzen;
+        {
+            int laysolfr;
+            if (gd.solar_kind == SOL_UPPER) {
+                laysolfr = nlay;   // 1-based, as in the reference
+                for (int lay = laytrop + 1; lay <= nlay; ++lay)
+                    if (c.jp[lay - 2] < gd.layreffr && c.jp[lay - 1] >= gd.layreffr) laysolfr = lay;
+            } else {
+                laysolfr = laytrop;
+                if (gd.solar_kind == SOL_LOWER)
+                    for (int lay = 1; lay <= laytrop; ++lay)
+                        if (c.jp[lay - 1] < gd.layreffr && c.jp[lay] >= gd.layreffr)
+                            laysolfr = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+            }
+            const int ks = laysolfr - 1;
+            const bool lowers = (laysolfr <= laytrop);
+            const GRegime &R = lowers ? gd.lo : gd.up;
+            int jsi = 0;
+            double fs = 0.;
+            if (gd.nsf > 1) {
+                const int spa = (R.cfg >> CFG_SPA_SHIFT) & 7, spb = (R.cfg >> CFG_SPB_SHIFT) & 7;
+                double colA = c.col[spa * nlp + ks], colB = c.col[spb * nlp + ks];
+                double speccomb = colA + R.strrat * colB;
+                double specparm = colA / speccomb;
+                specparm = specparm >= tb.oneminus ? tb.oneminus : specparm;
+                double specmult = ((R.cfg & CFG_MULT4) ? 4. : 8.) * specparm;
+                jsi = (int)specmult;
+                fs = specmult - (double)jsi;
+            }
+            const double *Sf = tb.K + gd.off_sflux + (size_t)jsi * gd.ng;
+            double s0 = Sf[0];
+            double s1 = gd.nsf > 1 ? Sf[gd.ng] : s0;
+            sfluxzen = gd.nsf > 1 ? s0 + fs * (s1 - s0) : gd.scalekur * s0;
+        }
+        const double adjflux = 1.0 * (a.solcon / 1.36822e+03);   // adjes = 1, dyofyr = 0 (SW:10623-10626, 9735-9739)
+        const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
+        const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
+
+        // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
+        double *ck = c.ckpt + (size_t)wave * nblk * 2 * 64;
+        double rup = alb, rupd = alb;
+        for (int k = 0; k < nlay; ++k) {
+            if ((k & (BLK - 1)) == 0) {
+                ck[((k / BLK) * 2 + 0) * 64 + lane] = rup;
+                ck[((k / BLK) * 2 + 1) * 64 + lane] = rupd;
+            }
+            RT rt;
+            double dummy;
+            layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy);
+            // vrtqdr_sw, SW:7997-8015
+            double zreflect = 1. / (1. - rupd * rt.refd);
+            double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
+            double nrupd = rt.refd + rt.trad * rt.trad * rupd * zreflect;
+            rup = nrup; rupd = nrupd;
+        }
+
+        // ---- downward sweep by blocks: recompute the block's layers, then descend ----
+        double tdn = 1., rdnd = 0., tdbt = 1., tdbt_nodel = 1.;
+        for (int b = nblk - 1; b >= 0; --b) {
+            RT rt[BLK];
+            double dn[BLK], ru[BLK + 1], rud[BLK + 1];
+            ru[0] = ck[(b * 2 + 0) * 64 + lane];
+            rud[0] = ck[(b * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < BLK; ++j) {
+                const int k = b * BLK + j;
+                if (k < nlay) {
+                    if (aer_on) layer_rt<true>(tb, c, L, k, k < laytrop, true, prmu0, rt[j], dn[j]);
+                    else { layer_rt<false>(tb, c, L, k, k < laytrop, false, prmu0, rt[j], dn[j]); dn[j] = 1.; }
+                } else {
+                    rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
+                }
+                double zreflect = 1. / (1. - rud[j] * rt[j].refd);
+                ru[j + 1] = rt[j].ref + (rt[j].trad * ((rt[j].tra - rt[j].dbt) * rud[j] + rt[j].dbt * ru[j])) * zreflect;
+                rud[j + 1] = rt[j].refd + rt[j].trad * rt[j].trad * rud[j] * zreflect;
+            }
+#pragma unroll
+            for (int j = BLK - 1; j >= 0; --j) {
+                const int l = b * BLK + j + 1;   // level at the top of layer k = b*BLK + j
+                if (l <= nlay) {
+                    // fluxes at level l, SW:8038-8044
+                    double zreflect = 1. / (1. - rdnd * rud[j + 1]);
+                    double fu = (tdbt * ru[j + 1] + (tdn - tdbt) * rud[j + 1]) * zreflect;
+                    double fd = tdbt + (tdn - tdbt + tdbt * ru[j + 1] * rdnd) * zreflect;
+                    double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
+                    if (lane == 0) { flux[2 * l] = su; flux[2 * l + 1] = sd; }
+                }
+                // through layer k, SW:8026-8034 and SW:8578
+                double zreflect = 1. / (1. - rt[j].refd * rdnd);
+                double ntdn = tdbt * rt[j].tra + (rt[j].trad * ((tdn - tdbt) + tdbt * rt[j].ref * rdnd)) * zreflect;
+                double nrdnd = rt[j].refd + rt[j].trad * rt[j].trad * rdnd * zreflect;
+                tdn = ntdn; rdnd = nrdnd;
+                tdbt = rt[j].dbt * tdbt;
+                tdbt_nodel = dn[j] * tdbt_nodel;
+            }
+        }
+        {   // surface level
+            double zreflect = 1. / (1. - rdnd * alb);
+            double fu = (tdbt * alb + (tdn - tdbt) * alb) * zreflect;
+            double fd = tdbt + (tdn - tdbt + tdbt * alb * rdnd) * zreflect;
+            double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
+            if (lane == 0) { flux[0] = su; flux[1] = sd; }
+            if (pass == 0) {
+                // surface-only direct / UV-visible / near-IR sums (SW:8633-8647 at ikl = 1)
+                const double uv = gd.uvband ? zincflx : 0., ni = gd.uvband ? 0. : zincflx;
+                double dirbb = wave_sum(zincflx * tdbt_nodel);
+                double uvfd = wave_sum(uv * fd), uvdir = wave_sum(uv * tdbt_nodel);
+                double nifd = wave_sum(ni * fd), nidir = wave_sum(ni * tdbt_nodel);
+                if (lane == 0) {
+                    double *s = c.sfc + wave * 8;
+                    s[0] = dirbb; s[1] = uvfd; s[2] = uvdir; s[3] = nifd; s[4] = nidir;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ======================= epilogue: lanes = levels =======================
+    const double *fA0 = c.flux, *fA1 = c.flux + (size_t)nlev * 2, *fC0 = c.flux + (size_t)2 * nlev * 2,
+                 *fC1 = c.flux + (size_t)3 * nlev * 2;
+    if (tid < nlev) {
+        const int l = tid;
+        const double up = fA0[2 * l] + fA1[2 * l], dn = fA0[2 * l + 1] + fA1[2 * l + 1];
+        const double upc = fC0[2 * l] + fC1[2 * l], dnc = fC0[2 * l + 1] + fC1[2 * l + 1];
+        if (a.swupflx) {   // (i, kts:kte+2, j), SW:11156-11165; clear == total without cloud
+            const size_t q = base3f + (size_t)l * sk;
+            str(a.swupflx, q, r4, up); str(a.swupflxc, q, r4, up); str(a.swupflxcln, q, r4, upc);
+            str(a.swdnflx, q, r4, dn); str(a.swdnflxc, q, r4, dn); str(a.swdnflxcln, q, r4, dnc);
+        }
+        if (l < nk && a.rthratensw) {
+            // heating rate of layer l, SW:9428-9434, then SW:11167-11170
+            const double up1 = fA0[2 * (l + 1)] + fA1[2 * (l + 1)], dn1 = fA0[2 * (l + 1) + 1] + fA1[2 * (l + 1) + 1];
+            const double net0 = dn - up, net1 = dn1 - up1;
+            const double zdpgcp = tb.heatfac / c.pdp[l];
+            const double swhr = (net1 - net0) * zdpgcp;
+            const double tten = swhr / 86400.;
+            str(a.rthratensw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
+        }
+        if (l == 0) {
+            if (a.gsw) str(a.gsw, i2, r4, dn - up);
+            if (a.swupt) {
+                str(a.swupb, i2, r4, up); str(a.swupbc, i2, r4, up); str(a.swupbcln, i2, r4, upc);
+                str(a.swdnb, i2, r4, dn); str(a.swdnbc, i2, r4, dn); str(a.swdnbcln, i2, r4, dnc);
+            }
+            const double *s0 = c.sfc, *s1 = c.sfc + 8;
+            const double dirbb = s0[0] + s1[0], uvfd = s0[1] + s1[1], uvdir = s0[2] + s1[2], nifd = s0[3] + s1[3],
+                         nidir = s0[4] + s1[4];
+            if (a.swupt && a.swvisdir) {
+                str(a.swvisdir, i2, r4, uvdir); str(a.swvisdif, i2, r4, uvfd - uvdir);
+                str(a.swnirdir, i2, r4, nidir); str(a.swnirdif, i2, r4, nifd - nidir);
+            }
+            if (a.swddir) {
+                str(a.swddir, i2, r4, dirbb);
+                str(a.swddni, i2, r4, dirbb / coszrs);
+                str(a.swddif, i2, r4, dn - dirbb);
+            }
+        }
+        if (l == nlay) {
+            if (a.swcf) str(a.swcf, i2, r4, (dn - up) - (dn - up));   // SW:11126: clear == total without cloud
+            if (a.swupt) {
+                str(a.swupt, i2, r4, up); str(a.swuptc, i2, r4, up); str(a.swuptcln, i2, r4, upc);
+                str(a.swdnt, i2, r4, dn); str(a.swdntc, i2, r4, dn); str(a.swdntcln, i2, r4, dnc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+size_t sw_lds_bytes(int nk)
+{
+    const int nlay = nk + 1, nlev = nlay + 1;
+    const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND) + (size_t)4 * nblk * 2 * 64 + (size_t)4 * nlev * 2 + 32;
+    size_t ni = (size_t)nlp * 5 + 1;
+    return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
+}
+
+hipError_t sw_upload_constants(hipStream_t)
+{
+    // O3DATA annual profile, LW:12758-12790
+    static const double o3sum[31] = {
+        5.297E-8, 5.852E-8, 6.579E-8, 7.505E-8, 8.577E-8, 9.895E-8, 1.175E-7, 1.399E-7, 1.677E-7, 2.003E-7,
+        2.571E-7, 3.325E-7, 4.438E-7, 6.255E-7, 8.168E-7, 1.036E-6, 1.366E-6, 1.855E-6, 2.514E-6, 3.240E-6,
+        4.033E-6, 4.854E-6, 5.517E-6, 6.089E-6, 6.689E-6, 1.106E-5, 1.462E-5, 1.321E-5, 9.856E-6, 5.960E-6,
+        5.960E-6};
+    static const double ppsum[31] = {
+        955.890, 850.532, 754.599, 667.742, 589.841, 519.421, 455.480, 398.085, 347.171, 301.735, 261.310,
+        225.360, 193.419, 165.490, 141.032, 120.125, 102.689, 87.829, 75.123, 64.306, 55.086, 47.209, 40.535,
+        34.795, 29.865, 19.122, 9.277, 4.660, 2.421, 1.294, 0.647};
+    static const double o3win[31] = {
+        4.629E-8, 4.686E-8, 5.017E-8, 5.613E-8, 6.871E-8, 8.751E-8, 1.138E-7, 1.516E-7, 2.161E-7, 3.264E-7,
+        4.968E-7, 7.338E-7, 1.017E-6, 1.308E-6, 1.625E-6, 2.011E-6, 2.516E-6, 3.130E-6, 3.840E-6, 4.703E-6,
+        5.486E-6, 6.289E-6, 6.993E-6, 7.494E-6, 8.197E-6, 9.632E-6, 1.113E-5, 1.146E-5, 9.389E-6, 6.135E-6,
+        6.135E-6};
+    static const double ppwin[31] = {
+        955.747, 841.783, 740.199, 649.538, 568.404, 495.815, 431.069, 373.464, 322.354, 277.190, 237.635,
+        203.433, 174.070, 148.949, 127.408, 108.915, 93.114, 79.551, 67.940, 58.072, 49.593, 42.318, 36.138,
+        30.907, 26.362, 16.423, 7.583, 3.620, 1.807, 0.938, 0.469};
+    double o3ann[31], ppwrkh[32];
+    o3ann[0] = 0.5 * (o3sum[0] + o3win[0]);
+    for (int k = 1; k < 31; ++k)
+        o3ann[k] = o3win[k - 1] + (o3win[k] - o3win[k - 1]) / (ppwin[k] - ppwin[k - 1]) * (ppsum[k] - ppwin[k - 1]);
+    for (int k = 1; k < 31; ++k) o3ann[k] = 0.5 * (o3ann[k] + o3sum[k]);
+    ppwrkh[0] = 1100.;
+    for (int k = 1; k < 31; ++k) ppwrkh[k] = (ppsum[k] + ppsum[k - 1]) / 2.;
+    ppwrkh[31] = 0.;
+    static const double wavemin[SW_NBND] = {3.077, 2.500, 2.150, 1.942, 1.626, 1.299, 1.242,
+                                            0.778, 0.625, 0.442, 0.345, 0.263, 0.200, 3.846};
+    static const double wavemax[SW_NBND] = {3.846, 3.077, 2.500, 2.150, 1.942, 1.626, 1.299,
+                                            1.242, 0.778, 0.625, 0.442, 0.345, 0.263, 12.195};
+    double wavemid[SW_NBND];
+    for (int i = 0; i < SW_NBND; ++i) wavemid[i] = 0.5 * (wavemin[i] + wavemax[i]);
+    hipError_t e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_o3ann), o3ann, sizeof o3ann)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ppwrkh), ppwrkh, sizeof ppwrkh)) != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_wavemid), wavemid, sizeof wavemid);
+}
+
+hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream)
+{
+    const size_t lds = sw_lds_bytes(a.nk);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sw_column_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sw_column_kernel, dim3(ncol), dim3(NTHREADS), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace rrtmg
