@@ -727,11 +727,12 @@ hipError_t sw_upload_constants(hipStream_t)
 hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream)
 {
     const size_t lds = sw_lds_bytes(a.nk);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sw_column_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static size_t attr_bytes = 0;   // grow-only opt-in for > 64 KB of dynamic LDS
+    if (lds > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_column_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_bytes = lds;
     }
     hipLaunchKernelGGL(sw_column_kernel, dim3(ncol), dim3(NTHREADS), lds, stream, a);
     return hipGetLastError();

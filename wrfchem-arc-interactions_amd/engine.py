@@ -57,6 +57,13 @@ def load_library(path: str | None = None):
         if not os.path.exists(p):
             raise ImportError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(the engine has no CPU fallback)")
+        try:
+            # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1; load it first so that
+            # the engine binds to the SAME HIP runtime instance (two runtimes in one process cannot
+            # both own the device, and torch tensors must be visible to our stream).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(p)
         lib.rrtmg_hip_version.restype = C.c_char_p
         lib.rrtmg_hip_sw_init.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_char_p]
