@@ -108,6 +108,11 @@ long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *args);
  * ncol, 0. */
 int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *args, double *out16, char *err);
 
+/* Device for this process: RRTMG_HIP_DEVICE, else the MPI/SLURM local rank
+ * (OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID,
+ * SLURM_LOCALID, LOCAL_RANK) modulo the visible device count, else 0. */
+int rrtmg_hip_pick_device(void);
+
 int rrtmg_hip_finalize(void);
 
 /* version / build info: "rrtmg_hip <ver> gfx950" */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -76,6 +77,20 @@ struct Staging {
 using namespace rrtmg;
 
 extern "C" const char *rrtmg_hip_version(void) { return "rrtmg_hip 0.1 gfx950"; }
+
+// rank -> device map for an MPI job with one rank per GPU (the reference runs one RRTMG per MPI patch)
+extern "C" int rrtmg_hip_pick_device(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;
+    const char *vars[] = {"RRTMG_HIP_DEVICE", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK",
+                          "MPI_LOCALRANKID", "SLURM_LOCALID", "LOCAL_RANK"};
+    for (const char *v : vars) {
+        const char *e = std::getenv(v);
+        if (e && *e) return std::atoi(e) % ndev;
+    }
+    return 0;
+}
 
 extern "C" int rrtmg_hip_sw_init(const char *data_path, int data_real_bytes, double cpdair, int device, char *err)
 {

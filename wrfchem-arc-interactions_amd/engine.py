@@ -79,7 +79,7 @@ def load_library(path: str | None = None):
 
 
 EXPORTS = ["rrtmg_hip_sw_init", "rrtmg_hip_swrad", "rrtmg_hip_sw_status", "rrtmg_hip_swrad_staging_bytes",
-           "rrtmg_hip_sw_tile_sums", "rrtmg_hip_finalize", "rrtmg_hip_version",
+           "rrtmg_hip_sw_tile_sums", "rrtmg_hip_finalize", "rrtmg_hip_pick_device", "rrtmg_hip_version",
            "rrtmg_hip_sw_reduce_tables", "rrtmg_hip_sw_table_info"]
 
 
