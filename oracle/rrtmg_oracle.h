@@ -108,6 +108,63 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
  * bottom->top, o3prof[kte-kts+2] out (mass mixing ratio). */
 void oracle_inirad(double *o3prof, const double *plev, int nlay_model);
 
+/* ------------------------------ longwave ------------------------------- */
+#define LW_NBND 16
+#define LW_NGPT 140
+
+typedef struct LwTables LwTables;
+
+/* rrtmg_lwlookuptable + rrtmg_lw_ini (LW:12876-12930, LW:7862-8009) */
+LwTables *lw_oracle_load(const char *path, int real_bytes, double cpdair, char *err, int errlen);
+void lw_oracle_free(LwTables *t);
+/* name: absa, absb, selfref, forref, fracrefa, fracrefb, kam0..2, kbm0..1, gv0..1,
+ *       exp_tbl, tau_tbl, tfn_tbl (band ignored) ; band = 1..16 */
+const double *lw_oracle_table(const LwTables *t, int band, const char *name, int *n);
+
+/* one cloud-free column of rrtmg_lw (LW:10578-11062): gas-only ("clean") call
+ * and gas+aerosol call.  Arrays bottom->top; tauaer [LW_NBND][nlay].
+ * Outputs: flux arrays [nlay+1], heating [nlay]. */
+typedef struct {
+    int nlay;
+    const double *play, *plev, *tlay, *tlev;
+    double tsfc;
+    const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
+    const double *cfc11vmr, *cfc12vmr, *cfc22vmr, *ccl4vmr;
+    const double *emis;      /* [LW_NBND] */
+    const double *tauaer;
+    int clean_atm_diag;
+} LwColumnIn;
+
+typedef struct {
+    double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *uflxcln, *dflxcln;
+} LwColumnOut;
+
+int lw_oracle_rrtmg_lw(const LwTables *t, const LwColumnIn *in, LwColumnOut *out);
+
+/* NLAYERS of rrtmg_lwinit (LW:12861) */
+int lw_oracle_nlayers(int kme, double p_top_pa);
+
+/* RRTMG_LWRAD over a tile (LW:11451-12700), cloud-free path, fp64 WRF arrays */
+typedef struct {
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    int nlayers;                                             /* module variable set by rrtmg_lwinit */
+    const double *emiss, *tsk;                               /* 2-D */
+    const double *t3d, *t8w, *p3d, *p8w, *pi3d, *qv3d;       /* 3-D */
+    const double *tauaerlw[LW_NBND];                         /* tauaerlw1..16 */
+    int aer_ra_feedback, clean_atm_diag;
+} LwTileIn;
+
+typedef struct {
+    double *rthratenlw;                                      /* 3-D */
+    double *glw, *olr, *lwcf;                                /* 2-D */
+    double *lwupt, *lwuptc, *lwuptcln, *lwdnt, *lwdntc, *lwdntcln;
+    double *lwupb, *lwupbc, *lwupbcln, *lwdnb, *lwdnbc, *lwdnbcln;
+    double *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;   /* (i,kms:kme+2,j) */
+} LwTileOut;
+
+int lw_oracle_lwrad_tile(const LwTables *t, const LwTileIn *in, LwTileOut *out, char *err, int errlen);
+
 #ifdef __cplusplus
 }
 #endif

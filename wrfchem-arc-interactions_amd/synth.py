@@ -266,3 +266,75 @@ def make_wrf_state(ni, nj, nk, seed=20260002, night_fraction=0.0, aerosol=True,
         for b in range(1, 17):
             st.a3[f"tauaerlw{b}"] = np.zeros((nj, kme, ni))
     return st
+
+
+# --------------------------------------------------------------------------
+# RRTMG_LW_DATA: record schema in READ order (lw_kgb01..16, LW:13021-14387)
+# --------------------------------------------------------------------------
+_KA9, _KA1 = (9, 5, 13, NO), (5, 13, NO)
+_KB5, _KB1 = (5, 5, 47, NO), (5, 47, NO)
+_SF = [("selfrefo", (10, NO)), ("forrefo", (4, NO))]
+LW_RECORDS = [
+    (1, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1),
+         ("kao_mn2", (19, NO)), ("kbo_mn2", (19, NO))] + _SF),
+    (2, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1)] + _SF),
+    (3, [("fracrefao", (NO, 9)), ("fracrefbo", (NO, 5)), ("kao", _KA9), ("kbo", _KB5),
+         ("kao_mn2o", (9, 19, NO)), ("kbo_mn2o", (5, 19, NO))] + _SF),
+    (4, [("fracrefao", (NO, 9)), ("fracrefbo", (NO, 5)), ("kao", _KA9), ("kbo", _KB5)] + _SF),
+    (5, [("fracrefao", (NO, 9)), ("fracrefbo", (NO, 5)), ("kao", _KA9), ("kbo", _KB5),
+         ("kao_mo3", (9, 19, NO)), ("ccl4o", (NO,))] + _SF),
+    (6, [("fracrefao", (NO,)), ("kao", _KA1), ("kao_mco2", (19, NO)), ("cfc11adjo", (NO,)), ("cfc12o", (NO,))] + _SF),
+    (7, [("fracrefao", (NO, 9)), ("fracrefbo", (NO,)), ("kao", _KA9), ("kbo", _KB1),
+         ("kao_mco2", (9, 19, NO)), ("kbo_mco2", (19, NO))] + _SF),
+    (8, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1),
+         ("kao_mco2", (19, NO)), ("kbo_mco2", (19, NO)), ("kao_mn2o", (19, NO)), ("kbo_mn2o", (19, NO)),
+         ("kao_mo3", (19, NO)), ("cfc12o", (NO,)), ("cfc22adjo", (NO,))] + _SF),
+    (9, [("fracrefao", (NO, 9)), ("fracrefbo", (NO,)), ("kao", _KA9), ("kbo", _KB1),
+         ("kao_mn2o", (9, 19, NO)), ("kbo_mn2o", (19, NO))] + _SF),
+    (10, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1)] + _SF),
+    (11, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1),
+          ("kao_mo2", (19, NO)), ("kbo_mo2", (19, NO))] + _SF),
+    (12, [("fracrefao", (NO, 9)), ("kao", _KA9)] + _SF),
+    (13, [("fracrefao", (NO, 9)), ("fracrefbo", (NO,)), ("kao", _KA9), ("kao_mco2", (9, 19, NO)),
+          ("kao_mco", (9, 19, NO)), ("kbo_mo3", (19, NO))] + _SF),
+    (14, [("fracrefao", (NO,)), ("fracrefbo", (NO,)), ("kao", _KA1), ("kbo", _KB1)] + _SF),
+    (15, [("fracrefao", (NO, 9)), ("kao", _KA9), ("kao_mn2", (9, 19, NO))] + _SF),
+    (16, [("fracrefao", (NO, 9)), ("fracrefbo", (NO,)), ("kao", _KA9), ("kbo", _KB1)] + _SF),
+]
+# typical major-species amounts (1e20 molec/cm2 per layer) below / above the tropopause
+_LW_AMOUNT = {1: (10., 0.03), 2: (10., 0.03), 3: (10., 0.5), 4: (10., 0.5), 5: (10., 0.5), 6: (10., 1.),
+              7: (10., 5e-3), 8: (10., 5e-3), 9: (10., 1e-2), 10: (10., 0.03), 11: (10., 0.03), 12: (10., 1.),
+              13: (10., 1.), 14: (2., 2.), 15: (1e-2, 1.), 16: (10., 1e-2)}
+_LW_MINOR = {"kao_mn2": 3e4, "kbo_mn2": 3e4, "kao_mn2o": 2e-3, "kbo_mn2o": 2e-3, "kao_mo3": 1e-3, "kbo_mo3": 5e-3,
+             "kao_mco2": 2.0, "kbo_mco2": 2.0, "kao_mo2": 3e3, "kbo_mo2": 3e2, "kao_mco": 1e-3,
+             "ccl4o": 5e-7, "cfc11adjo": 1.3e-6, "cfc12o": 2.8e-6, "cfc22adjo": 9e-7}
+
+
+def make_lw_tables(seed: int = 20260003) -> dict:
+    rng = np.random.default_rng(seed)
+    out = {}
+    for band, fields in LW_RECORDS:
+        rec = {}
+        lo_amt, hi_amt = _LW_AMOUNT[band]
+        for name, shape in fields:
+            if name in ("fracrefao", "fracrefbo"):
+                w = rng.uniform(0.3, 1.7, size=shape) * np.exp(-0.12 * np.arange(NO)).reshape((NO,) + (1,) * (len(shape) - 1))
+                rec[name] = w / w.sum(axis=0, keepdims=True)
+            elif name == "kao":
+                rec[name] = _ktable(rng, shape, lo_amt)
+            elif name == "kbo":
+                rec[name] = _ktable(rng, shape, hi_amt)
+            elif name == "selfrefo":
+                rec[name] = _ktable(rng, shape, 3e2)      # selffac carries colh2o * water * scalefac
+            elif name == "forrefo":
+                rec[name] = _ktable(rng, shape, 3e2)
+            else:
+                rec[name] = 0.1 * _ktable(rng, shape, _LW_MINOR[name])
+        out[band] = rec
+    return out
+
+
+def write_lw_data(path, seed: int = 20260003, real_bytes: int = 8) -> dict:
+    tables = make_lw_tables(seed)
+    write_fortran_records(path, LW_RECORDS, tables, real_bytes)
+    return tables
