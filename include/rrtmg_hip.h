@@ -108,6 +108,46 @@ long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *args);
  * ncol, 0. */
 int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *args, double *out16, char *err);
 
+/* ------------------------------- longwave -------------------------------- */
+
+/* Read RRTMG_LW_DATA (record field order of lw_kgb01..16, LW:13021-14387),
+ * reduce 256 -> 140 g-points (cmbgb1..16), build the exp / tfn lookup tables,
+ * upload.  p_top_pa and kme fix NLAYERS = kme + nint(p_top*0.01/4) - 1, the
+ * model layers plus the 4-mb buffer layers up to 0 mb (LW:12861). */
+int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, double cpdair, double p_top_pa, int kme,
+                      int device, char *err);
+int rrtmg_hip_lw_nlayers(int kme, double p_top_pa);
+
+typedef struct rrtmg_hip_lwrad_args {
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    int real_bytes;
+    int mem;
+    void *stream;
+    int aer_ra_feedback, clean_atm_diag, icloud, o3input;
+    /* inputs, 2-D */
+    const void *emiss, *tsk;
+    /* inputs, 3-D */
+    const void *t3d, *t8w, *p3d, *p8w, *pi3d, *qv3d;
+    const void *o33d;                    /* optional */
+    const void *tauaerlw[16];            /* tauaerlw1..16, optional unless aer_ra_feedback */
+    /* outputs */
+    void *rthratenlw;                    /* 3-D */
+    void *glw, *olr, *lwcf;              /* 2-D */
+    void *lwupt, *lwuptc, *lwuptcln, *lwdnt, *lwdntc, *lwdntcln;   /* optional as a group */
+    void *lwupb, *lwupbc, *lwupbcln, *lwdnb, *lwdnbc, *lwdnbcln;
+    void *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;   /* optional, (i,kms:kme+2,j) */
+} rrtmg_hip_lwrad_args;
+
+int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *args, char *err);
+int rrtmg_hip_lw_status(char *err);
+int rrtmg_hip_lw_finalize(void);
+/* host-only helpers for the CPU tests of the init path */
+int rrtmg_hip_lw_reduce_tables(const char *data_path, int data_real_bytes, double cpdair, double *k_out,
+                               long long k_cap, long long *k_len, double *exp_out, double *tfn_out, char *err);
+int rrtmg_hip_lw_table_info(const char *data_path, int data_real_bytes, int g, int *fields24, double *dfields8,
+                            char *err);
+
 /* Device for this process: RRTMG_HIP_DEVICE, else the MPI/SLURM local rank
  * (OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID,
  * SLURM_LOCALID, LOCAL_RANK) modulo the visible device count, else 0. */

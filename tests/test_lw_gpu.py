@@ -1,0 +1,116 @@
+"""GPU parity tests: RRTMG_LWRAD through the HIP C-ABI against the CPU oracle.
+Tolerance as for the shortwave (tests/test_sw_gpu.py): |hip - oracle| <= 1e-9*|oracle| + 1e-9."""
+import numpy as np
+import pytest
+
+from helpers import SENTINEL, compare_sw
+from helpers_lw import run_hip_lwrad, run_oracle_lwrad
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+ATOL = 1e-9
+P_TOP = 5000.0
+
+
+@pytest.fixture(scope="module")
+def lw_table_file(tmp_path_factory, wa):
+    p = tmp_path_factory.mktemp("tables_lw") / "RRTMG_LW_DATA"
+    wa.synth.write_lw_data(str(p), seed=20260003, real_bytes=8)
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def lw_oracle(oracle_mod, lw_table_file):
+    from oracle import oracle_lw
+    return oracle_lw.LwOracle(lw_table_file)
+
+
+def _init(wa, lw_table_file, nk):
+    import torch
+    assert torch.cuda.is_available()
+    eng = wa.engine_lw
+    eng.rrtmg_lwinit(P_TOP, lw_table_file, kme=nk + 1, device=0)
+    return eng, eng.lw_nlayers(nk + 1, P_TOP)
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed", [(8, 5, 40, 1), (4, 3, 50, 2), (3, 2, 28, 3), (3, 2, 60, 4)])
+def test_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed):
+    eng, nlay = _init(wa, lw_table_file, nk)
+    assert nlay == nk + 13
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260200 + seed)
+    got = run_hip_lwrad(eng, st)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay)
+    worst = compare_sw(got, ref, RTOL, ATOL)
+    assert worst < 1e-8
+    np.testing.assert_array_equal(got["lwuptc"], got["lwupt"])      # cloud-free: clear == all-sky
+    assert (got["lwcf"] == 0).all()
+    assert (got["olr"] == got["lwupt"]).all() and (got["glw"] == got["lwdnb"]).all()
+
+
+def test_lw_host_pointer_mode_equals_device_mode(hip_lib, wa, lw_table_file):
+    eng, _ = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(5, 3, 40, seed=20260211)
+    a = run_hip_lwrad(eng, st, device=True)
+    b = run_hip_lwrad(eng, st, device=False)
+    for n in a:
+        np.testing.assert_array_equal(a[n], b[n], err_msg=n)
+
+
+def test_lw_clean_off_and_no_aerosol(hip_lib, wa, lw_table_file, lw_oracle):
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(4, 2, 40, seed=20260212)
+    got = run_hip_lwrad(eng, st, clean=0)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, clean=0)
+    compare_sw(got, ref, RTOL, ATOL)
+    for n in ("lwuptcln", "lwdntcln", "lwupbcln", "lwdnbcln"):
+        assert (got[n] == 0).all()                                  # LW:11028-11033
+    got = run_hip_lwrad(eng, st, aer=0)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, aer=0)
+    compare_sw(got, ref, RTOL, ATOL)
+    np.testing.assert_array_equal(got["lwuptcln"], got["lwupt"])    # taua == 0: call #1 == call #2
+
+
+def test_lw_tile_inside_larger_memory_window_and_real4(hip_lib, wa, lw_table_file, lw_oracle):
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(9, 6, 40, seed=20260213)
+    tile = dict(its=2, ite=8, jts=3, jte=5)
+    got = run_hip_lwrad(eng, st, tile=tile)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, tile=tile)
+    compare_sw(got, ref, RTOL, ATOL)
+    mask = np.ones((st.nj, st.ni), bool)
+    mask[2:5, 1:8] = False
+    assert (got["glw"][mask] == SENTINEL).all()
+    for d in (st.a2, st.a3):
+        for n in d:
+            d[n] = d[n].astype(np.float32).astype(np.float64)
+    got = run_hip_lwrad(eng, st, real_bytes=4)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay)
+    compare_sw(got, ref, 3e-7, 1e-6)
+
+
+def test_lw_negative_aod_is_fatal(hip_lib, wa, lw_table_file):
+    eng, _ = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(3, 2, 40, seed=20260214)
+    for b in range(1, 17):
+        st.a3[f"tauaerlw{b}"][1, :, 1] = 1e-6
+    st.a3["tauaerlw5"][1, :, 1] = -0.5
+    with pytest.raises(eng.WrfFatal, match="Negative total lw optical depth"):
+        run_hip_lwrad(eng, st)
+
+
+def test_lw_full_size_properties(hip_lib, wa, lw_table_file):
+    eng, _ = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(200, 100, 40, seed=20260215)
+    got = run_hip_lwrad(eng, st, profiles=False)
+    assert np.isfinite(got["olr"]).all() and (got["olr"] > 50).all() and (got["olr"] < 600).all()
+    # surface upward flux ~ eps*sigma*Tsk^4 + (1-eps)*down within the synthetic Planck tables' scale: monotone in tsk
+    c = np.corrcoef(st.a2["tsk"].ravel(), got["lwupb"].ravel())[0, 1]
+    assert c > 0.5
+    perm = np.random.default_rng(1).permutation(st.ni)
+    st2 = wa.synth.make_wrf_state(200, 100, 40, seed=20260215)
+    for d in (st2.a2, st2.a3):
+        for n in d:
+            d[n] = np.ascontiguousarray(d[n][..., perm])
+    got2 = run_hip_lwrad(eng, st2, profiles=False)
+    for n in ("olr", "glw", "lwuptcln"):
+        np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)

@@ -1,0 +1,285 @@
+// Longwave entry points of the C ABI (include/rrtmg_hip.h).  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmg_hip.h"
+#include "lw_common.h"
+#include "lw_kernel.h"
+#include "lw_ref_tables.h"
+#include "lw_state.h"
+
+namespace rrtmg {
+
+LwState &lw_state()
+{
+    static LwState s;
+    return s;
+}
+
+namespace {
+
+std::mutex g_lw_mutex;
+
+int failw(char *err, const std::string &msg)
+{
+    if (err) {
+        std::strncpy(err, msg.c_str(), RRTMG_HIP_ERRLEN - 1);
+        err[RRTMG_HIP_ERRLEN - 1] = 0;
+    }
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return failw(err, std::string("rrtmg_hip: ") + #expr + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
+    hipError_t in(const void *host, size_t bytes, hipStream_t s, const void **dev)
+    {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return e;
+        bufs.push_back(d);
+        *dev = d;
+        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
+    }
+    hipError_t out(void *host, size_t bytes, hipStream_t s, void **dev)
+    {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return e;
+        bufs.push_back(d);
+        *dev = d;
+        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);   // INOUT: only the tile is rewritten
+    }
+};
+
+template <class T>
+hipError_t upload(void **dptr, const std::vector<T> &v)
+{
+    if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+    hipError_t e = hipMalloc(dptr, v.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+}  // namespace rrtmg
+
+using namespace rrtmg;
+
+extern "C" int rrtmg_hip_lw_nlayers(int kme, double p_top_pa)
+{
+    // NLAYERS = kme + nint(p_top*0.01/deltap) - 1 with deltap = 4 mb, LW:12861
+    return kme + (int)std::lround(p_top_pa * 0.01 / 4.) - 1;
+}
+
+extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, double cpdair, double p_top_pa, int kme,
+                                 int device, char *err)
+{
+    std::lock_guard<std::mutex> lock(g_lw_mutex);
+    LwState &st = lw_state();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return failw(err, "rrtmg_hip_lw_init: no HIP device visible (the engine has no CPU path)");
+    HIPCHK(hipSetDevice(device));
+    std::string msg;
+    LwHostTables host;
+    if (lw_build_tables(data_path, data_real_bytes, cpdair, host, msg)) return failw(err, msg);
+    HIPCHK(upload(&st.dK, host.K));
+    HIPCHK(upload(&st.dExp, host.exp_tbl));
+    HIPCHK(upload(&st.dTfn, host.tfn_tbl));
+    HIPCHK(upload(&st.dPlk, host.totplnk));
+    HIPCHK(upload(&st.dChi, host.chi_mls));
+    HIPCHK(upload(&st.dG, host.gdesc));
+    HIPCHK(lw_upload_constants(LWREF_PREFLOG, LWREF_TREF));
+    if (!st.dStatus) HIPCHK(hipMalloc(&st.dStatus, sizeof(int)));
+    HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
+    st.dev.K = static_cast<const double *>(st.dK);
+    st.dev.exp_tbl = static_cast<const double *>(st.dExp);
+    st.dev.tfn_tbl = static_cast<const double *>(st.dTfn);
+    st.dev.totplnk = static_cast<const double *>(st.dPlk);
+    st.dev.chi_mls = static_cast<const double *>(st.dChi);
+    st.dev.gdesc = static_cast<const LwGDesc *>(st.dG);
+    st.dev.bpade = host.bpade; st.dev.heatfac = host.heatfac; st.dev.fluxfac = host.fluxfac;
+    st.dev.oneminus = host.oneminus;
+    st.host = std::move(host);
+    st.device = device;
+    st.nlayers = rrtmg_hip_lw_nlayers(kme, p_top_pa);
+    st.ready = true;
+    return 0;
+}
+
+extern "C" int rrtmg_hip_lw_reduce_tables(const char *data_path, int data_real_bytes, double cpdair, double *k_out,
+                                          long long k_cap, long long *k_len, double *exp_out, double *tfn_out, char *err)
+{
+    std::string msg;
+    LwHostTables host;
+    if (lw_build_tables(data_path, data_real_bytes, cpdair, host, msg)) return failw(err, msg);
+    if (k_len) *k_len = (long long)host.K.size();
+    if (k_out) {
+        if ((long long)host.K.size() > k_cap) return failw(err, "rrtmg_hip_lw_reduce_tables: buffer too small");
+        std::memcpy(k_out, host.K.data(), host.K.size() * sizeof(double));
+    }
+    if (exp_out) std::memcpy(exp_out, host.exp_tbl.data(), host.exp_tbl.size() * sizeof(double));
+    if (tfn_out) std::memcpy(tfn_out, host.tfn_tbl.data(), host.tfn_tbl.size() * sizeof(double));
+    return 0;
+}
+
+extern "C" int rrtmg_hip_lw_table_info(const char *data_path, int data_real_bytes, int g, int *fields /*[24]*/,
+                                       double *dfields /*[8]*/, char *err)
+{
+    std::string msg;
+    static LwHostTables host;
+    static std::string cached;
+    if (cached != data_path) {
+        host = LwHostTables{};
+        if (lw_build_tables(data_path, data_real_bytes, 1004.5, host, msg)) return failw(err, msg);
+        cached = data_path;
+    }
+    if (g < 0 || g >= LW_NGPT) return failw(err, "g out of range");
+    const LwGDesc &d = host.gdesc[g];
+    int f[24] = {d.band, d.ig, d.ng, d.off_self, d.off_for, d.lo.off_major, d.up.off_major, d.lo.off_frac, d.up.off_frac,
+                 (int)d.lo.cfg, (int)d.up.cfg,
+                 d.lo.minor[0].off, d.lo.minor[1].off, d.lo.minor[2].off, d.up.minor[0].off, d.up.minor[1].off,
+                 d.lo.minor[0].nsp, d.lo.minor[1].nsp, d.lo.minor[2].nsp, d.up.minor[0].nsp, d.up.minor[1].nsp, 0, 0, 0};
+    std::memcpy(fields, f, sizeof f);
+    double df[8] = {d.lo.fracconst, d.up.fracconst, d.lo.halo_coef[0], d.lo.halo_coef[1], d.up.halo_coef[0],
+                    d.up.halo_coef[1], d.up.postscale, d.delwave};
+    std::memcpy(dfields, df, sizeof df);
+    return 0;
+}
+
+extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
+{
+    LwState &st = lw_state();
+    if (!st.ready) return failw(err, "rrtmg_hip_lwrad: rrtmg_hip_lw_init has not been called");
+    if (a->real_bytes != 4 && a->real_bytes != 8) return failw(err, "rrtmg_hip_lwrad: real_bytes must be 4 or 8");
+    if (a->icloud != 0)
+        return failw(err, "rrtmg_hip_lwrad: icloud /= 0 (McICA cloudy columns) is not implemented in this release");
+    const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
+    const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk = a->kte - a->kts + 1;
+    if (ni_t <= 0 || nj_t <= 0 || nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
+        a->jte > a->jme || a->kts < a->kms || a->kte + 1 > a->kme)
+        return failw(err, "rrtmg_hip_lwrad: inconsistent tile / memory dimensions");
+    const int nl = st.nlayers;
+    if (nl < nk + 1 || nl > 200) return failw(err, "rrtmg_hip_lwrad: NLAYERS from rrtmg_hip_lw_init does not fit this tile");
+    if (lw_lds_bytes(nl) > 160 * 1024 - 64) return failw(err, "rrtmg_hip_lwrad: column does not fit LDS");
+    if (a->aer_ra_feedback == 1)
+        for (int b = 0; b < 16; ++b)
+            if (!a->tauaerlw[b]) return failw(err, "Warning: missing fields required for aerosol radiation");   // LW:11823-11845
+    HIPCHK(hipSetDevice(st.device));
+    hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
+    const size_t rb = a->real_bytes;
+    const size_t n2 = (size_t)ni_m * nj_m * rb, n3 = (size_t)ni_m * nk_m * nj_m * rb,
+                 n3f = (size_t)ni_m * (nk_m + 2) * nj_m * rb;
+
+    LwKernelArgs k{};
+    k.ims = a->ims; k.jms = a->jms; k.kms = a->kms; k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
+    k.its = a->its; k.jts = a->jts; k.kts = a->kts; k.ni_t = ni_t; k.nj_t = nj_t; k.nk = nk;
+    k.nlayers = nl;
+    k.real4 = a->real_bytes == 4;
+    k.aer_ra_feedback = a->aer_ra_feedback; k.clean = a->clean_atm_diag; k.o3input = a->o3input;
+    k.tab = st.dev;
+    k.status = static_cast<int *>(st.dStatus);
+    Staging stg;
+    if (a->mem != 1) HIPCHK(hipMemsetAsync(st.dStatus, 0, sizeof(int), stream));
+    struct OutCopy { void *host; void *dev; size_t bytes; };
+    std::vector<OutCopy> outs;
+    if (a->mem == 1) {
+        k.emiss = a->emiss; k.tsk = a->tsk;
+        k.t3d = a->t3d; k.t8w = a->t8w; k.p3d = a->p3d; k.p8w = a->p8w; k.pi3d = a->pi3d; k.qv3d = a->qv3d; k.o33d = a->o33d;
+        for (int b = 0; b < 16; ++b) k.tauaerlw[b] = a->tauaerlw[b];
+        k.rthratenlw = a->rthratenlw; k.glw = a->glw; k.olr = a->olr; k.lwcf = a->lwcf;
+        k.lwupt = a->lwupt; k.lwuptc = a->lwuptc; k.lwuptcln = a->lwuptcln; k.lwdnt = a->lwdnt; k.lwdntc = a->lwdntc;
+        k.lwdntcln = a->lwdntcln; k.lwupb = a->lwupb; k.lwupbc = a->lwupbc; k.lwupbcln = a->lwupbcln;
+        k.lwdnb = a->lwdnb; k.lwdnbc = a->lwdnbc; k.lwdnbcln = a->lwdnbcln;
+        k.lwupflx = a->lwupflx; k.lwupflxc = a->lwupflxc; k.lwupflxcln = a->lwupflxcln;
+        k.lwdnflx = a->lwdnflx; k.lwdnflxc = a->lwdnflxc; k.lwdnflxcln = a->lwdnflxcln;
+    } else {
+#define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
+#define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
+#define OUT(f, bytes)                                             \
+    do {                                                          \
+        HIPCHK(stg.out(a->f, bytes, stream, &k.f));               \
+        if (a->f) outs.push_back({a->f, k.f, bytes});             \
+    } while (0)
+        IN2(emiss); IN2(tsk);
+        IN3(t3d); IN3(t8w); IN3(p3d); IN3(p8w); IN3(pi3d); IN3(qv3d); IN3(o33d);
+        if (a->aer_ra_feedback == 1)
+            for (int b = 0; b < 16; ++b) HIPCHK(stg.in(a->tauaerlw[b], n3, stream, &k.tauaerlw[b]));
+        OUT(rthratenlw, n3); OUT(glw, n2); OUT(olr, n2); OUT(lwcf, n2);
+        OUT(lwupt, n2); OUT(lwuptc, n2); OUT(lwuptcln, n2); OUT(lwdnt, n2); OUT(lwdntc, n2); OUT(lwdntcln, n2);
+        OUT(lwupb, n2); OUT(lwupbc, n2); OUT(lwupbcln, n2); OUT(lwdnb, n2); OUT(lwdnbc, n2); OUT(lwdnbcln, n2);
+        OUT(lwupflx, n3f); OUT(lwupflxc, n3f); OUT(lwupflxcln, n3f);
+        OUT(lwdnflx, n3f); OUT(lwdnflxc, n3f); OUT(lwdnflxcln, n3f);
+#undef IN2
+#undef IN3
+#undef OUT
+    }
+    if (!(k.emiss && k.tsk && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
+        return failw(err, "rrtmg_hip_lwrad: a required input array is NULL");
+    if (a->lwupt && !(a->lwuptc && a->lwuptcln && a->lwdnt && a->lwdntc && a->lwdntcln && a->lwupb && a->lwupbc &&
+                      a->lwupbcln && a->lwdnb && a->lwdnbc && a->lwdnbcln))
+        return failw(err, "rrtmg_hip_lwrad: the twelve TOA/surface flux arrays must be passed together");
+    if (a->lwupflx && !(a->lwupflxc && a->lwupflxcln && a->lwdnflx && a->lwdnflxc && a->lwdnflxcln))
+        return failw(err, "rrtmg_hip_lwrad: the six flux profile arrays must be passed together");
+
+    HIPCHK(lw_launch(k, ni_t * nj_t, stream));
+
+    if (a->mem != 1) {
+        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
+        int status = 0;
+        HIPCHK(hipMemcpyAsync(&status, st.dStatus, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (status != 0) {
+            const int col = status - 1;
+            char m[RRTMG_HIP_ERRLEN];
+            std::snprintf(m, sizeof m, "ERROR: Negative total lw optical depth at point i,j=%5d%5d",
+                          a->its + col % ni_t, a->jts + col / ni_t);   // LW:12613-12615
+            return failw(err, m);
+        }
+    }
+    return 0;
+}
+
+extern "C" int rrtmg_hip_lw_status(char *err)
+{
+    LwState &st = lw_state();
+    if (!st.ready) return failw(err, "rrtmg_hip_lw_status: rrtmg_hip_lw_init has not been called");
+    HIPCHK(hipSetDevice(st.device));
+    HIPCHK(hipDeviceSynchronize());
+    int status = 0;
+    HIPCHK(hipMemcpy(&status, st.dStatus, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
+    if (status != 0) {
+        char m[RRTMG_HIP_ERRLEN];
+        std::snprintf(m, sizeof m, "ERROR: Negative total lw optical depth at tile column %d", status - 1);
+        return failw(err, m);
+    }
+    return 0;
+}
+
+extern "C" int rrtmg_hip_lw_finalize(void)
+{
+    LwState &st = lw_state();
+    void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus};
+    for (void **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    st.ready = false;
+    return 0;
+}

@@ -1,0 +1,702 @@
+// Longwave column kernel: RRTMG_LWRAD + rrtmg_lw (gas-only "clean" call and
+// gas+aerosol call in one launch) for gfx950.
+//
+// Reference path (phys/module_ra_rrtmg_lw.F): RRTMG_LWRAD preprocessing
+// LW:12149-12298 (buffer layers to 0 mb), aerosol copy LW:12576-12630, inatm
+// LW:11248-11300, setcoef LW:3540-3808, taugb1..16 LW:4712-7828, rtrnmc
+// LW:3135-3410, rrtmg_lw LW:10996-11060, outputs LW:12646-12692.
+//
+// Mapping: one 192-thread workgroup per column.  Prologue with lanes = layers
+// (profile, O3, column amounts, setcoef, Planck functions, the "too abundant to
+// be minor" adjustments) into LDS.  Main phase with lanes = g-points (3 waves x
+// 47): the 16 taugbNN routines are one data-driven expression; gas optics are
+// shared by the two radiative-transfer calls (as in the reference, LW:10990-11044,
+// where taumol runs once).  The downward and the upward sweep each evaluate the
+// layer optics (no per-lane profile store); level fluxes are wave reductions.
+#include <hip/hip_runtime.h>
+
+#include "lw_common.h"
+#include "lw_kernel.h"
+
+namespace rrtmg {
+
+namespace {
+
+constexpr int LW_THREADS = 192;
+constexpr int LW_CHUNK = 47;
+
+__constant__ double c_lw_preflog[59];
+__constant__ double c_lw_tref[59];
+__constant__ double c_lw_o3ann[31];
+__constant__ double c_lw_ppwrkh[32];
+// mean pressure / temperature profile for the buffer layers, LW:11802-11821
+__constant__ double c_pprof[60] = {
+    1000.00, 855.47, 731.82, 626.05, 535.57, 458.16, 391.94, 335.29, 286.83, 245.38, 209.91, 179.57,
+    153.62, 131.41, 112.42, 96.17, 82.27, 70.38, 60.21, 51.51, 44.06, 37.69, 32.25, 27.59,
+    23.60, 20.19, 17.27, 14.77, 12.64, 10.81, 9.25, 7.91, 6.77, 5.79, 4.95, 4.24,
+    3.63, 3.10, 2.65, 2.27, 1.94, 1.66, 1.42, 1.22, 1.04, 0.89, 0.76, 0.65,
+    0.56, 0.48, 0.41, 0.35, 0.30, 0.26, 0.22, 0.19, 0.16, 0.14, 0.12, 0.10};
+__constant__ double c_tprof[60] = {
+    286.96, 281.07, 275.16, 268.11, 260.56, 253.02, 245.62, 238.41, 231.57, 225.91, 221.72, 217.79,
+    215.06, 212.74, 210.25, 210.16, 210.69, 212.14, 213.74, 215.37, 216.82, 217.94, 219.03, 220.18,
+    221.37, 222.64, 224.16, 225.88, 227.63, 229.51, 231.50, 233.73, 236.18, 238.78, 241.60, 244.44,
+    247.35, 250.33, 253.32, 256.30, 259.22, 262.12, 264.80, 266.50, 267.59, 268.44, 268.69, 267.76,
+    266.13, 263.96, 261.54, 258.93, 256.15, 253.23, 249.89, 246.67, 243.48, 240.25, 236.66, 233.86};
+// diffusivity-angle coefficients, LW:2958-2969
+__constant__ double c_a0[LW_NBND] = {1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33, 1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
+__constant__ double c_a1[LW_NBND] = {0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40, -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+__constant__ double c_a2[LW_NBND] = {0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062, 0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+
+__device__ __forceinline__ double ldr(const void *p, size_t idx, int real4)
+{
+    return real4 ? (double)reinterpret_cast<const float *>(p)[idx] : reinterpret_cast<const double *>(p)[idx];
+}
+__device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
+{
+    if (real4) reinterpret_cast<float *>(p)[idx] = (float)v;
+    else reinterpret_cast<double *>(p)[idx] = v;
+}
+
+// sums of two values over the wave: lane 0 ends with sum(a), lane 32 with sum(b)
+__device__ __forceinline__ double wave_sum2(double a, double b, int lane)
+{
+    const bool hi = lane & 32;
+    double send = hi ? a : b, keep = hi ? b : a;
+    double v = keep + __shfl_xor(send, 32, 64);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+struct LCol {   // LDS image of the column
+    double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac, *minorfrac, *pavel;
+    double *pz;        // [nl+1]
+    double *mul;       // [LS_COUNT][nl]
+    double *rat;       // [LR_COUNT][2][nl]
+    double *planklay;  // [16][nl]
+    double *planklev;  // [16][nl+1]
+    double *taua;      // [16][nl]
+    double *secdiff, *plankbnd;   // [16]
+    double *wrk;       // [2][nl] scratch for the column sums
+    double *flux;      // [3 waves][4][nl+1]: down clean, down total, up clean, up total
+    int *rb0, *rb1, *inds, *indf, *indm;
+    int nl;
+};
+
+__device__ __forceinline__ LCol carve(double *base, int nl)
+{
+    LCol c;
+    c.nl = nl;
+    double *p = base;
+    c.fac00 = p; p += nl; c.fac01 = p; p += nl; c.fac10 = p; p += nl; c.fac11 = p; p += nl;
+    c.selffac = p; p += nl; c.selffrac = p; p += nl; c.forfac = p; p += nl; c.forfrac = p; p += nl;
+    c.minorfrac = p; p += nl; c.pavel = p; p += nl;
+    c.pz = p; p += nl + 1;
+    c.mul = p; p += LS_COUNT * nl;
+    c.rat = p; p += LR_COUNT * 2 * nl;
+    c.planklay = p; p += LW_NBND * nl;
+    c.planklev = p; p += LW_NBND * (nl + 1);
+    c.taua = p; p += LW_NBND * nl;
+    c.secdiff = p; p += LW_NBND; c.plankbnd = p; p += LW_NBND;
+    c.wrk = p; p += 2 * nl;
+    c.flux = p; p += 3 * 4 * (nl + 1);
+    int *q = reinterpret_cast<int *>(p);
+    c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
+    return c;
+}
+
+// species index / fraction of a binary parameter, e.g. LW:5199-5204
+__device__ __forceinline__ void spec_idx(double cola, double ratio, double colb, double mult, double oneminus,
+                                         double &speccomb, double &specparm, int &j, double &f)
+{
+    speccomb = cola + ratio * colb;
+    specparm = cola / speccomb;
+    specparm = specparm >= oneminus ? oneminus : specparm;
+    double specmult = mult * specparm;
+    j = (int)specmult;
+    f = specmult - (double)j;
+}
+
+struct LaneL {
+    int ng, off_self, off_for;
+};
+
+// gaseous optical depth and Planck fraction of layer k for this lane's g-point
+__device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol &c, const LwRegime &R,
+                                           const LaneL &L, int k, double &taug, double &frac)
+{
+    const uint32_t cf = R.cfg;
+    const int nl = c.nl, ng = L.ng;
+    const int type = (cf >> LC_TYPE_SHIFT) & 3;
+    const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
+    const int nsp = (cf >> LC_NSP_SHIFT) & 15;
+    const bool binary = type == 2, edges = cf & LC_EDGES;
+    const double mult = (cf & LC_MULT4) ? 4. : 8.;
+    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
+    const double fT[2] = {c.fac00[k], c.fac01[k]}, fT1[2] = {c.fac10[k], c.fac11[k]};
+    const int rb[2] = {c.rb0[k], c.rb1[k]};
+    const int ts = (binary ? nsp : 1) * ng;
+    double maj[2], sc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        double speccomb, specparm, fs;
+        int jsi;
+        spec_idx(colA, c.rat[(rs * 2 + m) * nl + k], colB, mult, tb.oneminus, speccomb, specparm, jsi, fs);
+        double wm1 = 0., w0 = 1. - fs, w1 = fs, w2 = 0.;
+        if (edges) {   // LW:5231-5290
+            const bool lo = specparm < 0.125, hi = specparm > 0.875;
+            double p = lo ? fs - 1 : -fs;
+            double p4 = (p * p) * (p * p);
+            double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+            wm1 = hi ? fk2 : 0.;
+            w0 = lo ? fk0 : (hi ? fk1 : w0);
+            w1 = lo ? fk1 : (hi ? fk0 : w1);
+            w2 = lo ? fk2 : 0.;
+        }
+        if (!binary) { wm1 = 0.; w0 = 1.; w1 = 0.; w2 = 0.; jsi = 0; speccomb = colA; }
+        const double *Kp = tb.K + R.off_major + (size_t)(rb[m] * nsp + jsi) * ng;
+        double s = (wm1 * fT[m]) * Kp[-ng] + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * Kp[2 * ng] +
+                   (wm1 * fT1[m]) * Kp[ts - ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] +
+                   (w2 * fT1[m]) * Kp[ts + 2 * ng];
+        maj[m] = s;
+        sc[m] = speccomb;
+    }
+    double tau = 0.;
+    if (type == 2) tau = sc[0] * maj[0] + sc[1] * maj[1];
+    else if (type == 1) tau = colA * (maj[0] + maj[1]);
+    // continua (selffac / forfac already carry colh2o, LW:3806-3807)
+    if (cf & (LC_SELF | LC_FOR)) {
+        const double *Sf = tb.K + L.off_self + (size_t)c.inds[k] * ng;
+        const double *Ff = tb.K + L.off_for + (size_t)c.indf[k] * ng;
+        double s0 = Sf[0], s1 = Sf[ng], f0 = Ff[0], f1 = Ff[ng];
+        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
+        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
+        tau = tau + tauself + taufor;
+    }
+    // minor species, e.g. LW:5297-5301, 5877-5878
+    const double mf = c.minorfrac[k];
+    const int im = c.indm[k];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const LwMinor &M = R.minor[m];
+        if (__any(M.slot != LS_ZERO)) {
+            int jm = 0;
+            double fm = 0.;
+            if (M.nsp > 1) {
+                double scb, spp;
+                spec_idx(colA, M.refrat, colB, mult, tb.oneminus, scb, spp, jm, fm);
+            }
+            const double *Kp = tb.K + M.off + (size_t)(im * M.nsp + jm) * ng;
+            const int tm = M.nsp * ng;
+            double a0 = Kp[0], a1 = Kp[ng], b0 = Kp[tm], b1 = Kp[tm + ng];
+            double m1 = a0 + fm * (a1 - a0);
+            double m2 = b0 + fm * (b1 - b0);
+            double absm = m1 + mf * (m2 - m1);
+            tau = tau + c.mul[M.slot * nl + k] * absm;
+        }
+    }
+    tau = tau + c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
+    // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
+    const int corr = (cf >> LC_CORR_SHIFT) & 3;
+    if (corr) {
+        const double pp = c.pavel[k];
+        double corradj = 1.;
+        if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
+        else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
+        else corradj = 1. - .05 * (pp - 100.) / 900.;
+        tau = corradj * tau;
+    }
+    taug = tau * R.postscale;
+    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    double fr = fmode == 1 ? R.fracconst : 0.;
+    if (fmode == 2) {   // LW:5354-5355
+        double scb, spp, fpl;
+        int jpl;
+        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
+        const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
+        double f0 = Fp[0], f1 = Fp[ng];
+        fr = f0 + fpl * (f1 - f0);
+    }
+    frac = fr;
+}
+
+// absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
+__device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, double secdiff, double plfrac,
+                                          double blay, double dplankup, double dplankdn, double &atrans,
+                                          double &bbd, double &bbu)
+{
+    double odepth = secdiff * tau;
+    odepth = odepth < 0.0 ? 0.0 : odepth;
+    double tblind = odepth / (tb.bpade + odepth);
+    int itr = (int)(10000.0 * tblind + 0.5);
+    itr = itr > LW_NTBL ? LW_NTBL : itr;
+    const bool small = odepth <= 0.06;
+    double transc = tb.exp_tbl[itr], tausfac_t = tb.tfn_tbl[itr];
+    atrans = small ? odepth - 0.5 * odepth * odepth : 1. - transc;
+    double tausfac = small ? 0.166667 * odepth : tausfac_t;
+    // small branch: plfrac*(blay + dplank*odepth_rec); table branch: plfrac*(blay + tausfac*dplank)
+    bbd = small ? plfrac * (blay + dplankdn * tausfac) : plfrac * (blay + tausfac * dplankdn);
+    bbu = small ? plfrac * (blay + dplankup * tausfac) : plfrac * (blay + tausfac * dplankup);
+}
+
+// pressure (mb) of level l (0-based, l = 0 surface), LW:12149-12152, 12207-12212
+__device__ double plev_at(const LwKernelArgs &a, size_t base3, size_t sk, int l, int nk, int nl)
+{
+    if (l <= nk) return ldr(a.p8w, base3 + (size_t)l * sk, a.real4) / 100.;
+    if (l == nl) return 0.00;
+    double p = ldr(a.p8w, base3 + (size_t)nk * sk, a.real4) / 100.;
+    for (int i = nk; i < l; ++i) p = p - 4.;   // deltap = 4 mb
+    return p;
+}
+// temperature of the 60-level mean profile interpolated to pressure p, LW:12219-12241
+__device__ double varint_at(double p)
+{
+    int klev = 60;
+    if (c_pprof[59] < p) {
+        for (int LL = 2; LL <= 60; ++LL)
+            if (c_pprof[LL - 1] < p) { klev = LL - 1; break; }
+    }
+    double vark = c_tprof[klev - 1], vark1 = klev != 60 ? c_tprof[klev] : vark;
+    double wght = klev != 60 ? (p - c_pprof[klev - 1]) / (c_pprof[klev] - c_pprof[klev - 1]) : 0.0;
+    return wght * (vark1 - vark) + vark;
+}
+__device__ double tlev_at(const LwKernelArgs &a, size_t base3, size_t sk, int l, int nk, int nl)
+{
+    if (l <= nk - 1) return ldr(a.t8w, base3 + (size_t)l * sk, a.real4);
+    // tlev(L) = varint(L) + (tlev(kte) - varint(kte)) for L >= kte+1, LW:12244-12247
+    double tk = ldr(a.t8w, base3 + (size_t)(nk - 1) * sk, a.real4);
+    double vk = varint_at(plev_at(a, base3, sk, nk - 1, nk, nl));
+    return varint_at(plev_at(a, base3, sk, l, nk, nl)) + (tk - vk);
+}
+__device__ double o3clim(double plev_b, double plev_t)
+{   // O3DATA, LW:12806-12836
+    double o3 = 0.;
+    for (int jj = 0; jj < 31; ++jj) {
+        double pb1 = (-(plev_b - c_lw_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_lw_ppwrkh[jj];
+        double pb2 = (-(plev_b - c_lw_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_lw_ppwrkh[jj + 1];
+        double pt1 = (-(plev_t - c_lw_ppwrkh[jj]) >= 0.) ? 0. : plev_t - c_lw_ppwrkh[jj];
+        double pt2 = (-(plev_t - c_lw_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_t - c_lw_ppwrkh[jj + 1];
+        o3 = o3 + (pb2 - pb1 - pt2 + pt1) * c_lw_o3ann[jj];
+    }
+    return o3 / (plev_b - plev_t);
+}
+// "too abundant to be minor" column adjustment, e.g. LW:5209-5216
+__device__ __forceinline__ double adjcol(double col, double coldry, double chiref, double thr, double a0, double ex)
+{
+    double chi = col / coldry;
+    double rat = 1.e20 * chi / chiref;
+    double adjfac = a0 + pow(rat - a0, ex);
+    double adj = adjfac * chiref * coldry * 1.e-20;
+    return rat > thr ? adj : col;
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernelArgs a)
+{
+    extern __shared__ double lds[];
+    const LwDeviceTables &tb = a.tab;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nk = a.nk, nl = a.nlayers;
+    LCol c = carve(lds, nl);
+
+    int col;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x;
+        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        col = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int it = col % a.ni_t, jt = col / a.ni_t;
+    const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
+    const size_t i2 = j0 * a.ni_m + i0;
+    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m, sjf = (size_t)a.ni_m * (a.nk_m + 2);
+    const size_t base3 = j0 * sj + k0 * sk + i0, base3f = j0 * sjf + k0 * sk + i0;
+    const int r4 = a.real4;
+    const double tbound = ldr(a.tsk, i2, r4);
+    const double semiss = ldr(a.emiss, i2, r4);   // same emissivity in all 16 bands, LW:12296-12298
+
+    // ======================= prologue: lanes = layers =======================
+    int nlower = 0;
+    for (int k = tid; k < nl; k += LW_THREADS) {
+        const double plev_b = plev_at(a, base3, sk, k, nk, nl), plev_t = plev_at(a, base3, sk, k + 1, nk, nl);
+        const double pavel = k < nk ? ldr(a.p3d, base3 + (size_t)k * sk, r4) / 100. : 0.5 * (plev_b + plev_t);
+        const double tz_t = tlev_at(a, base3, sk, k + 1, nk, nl);
+        double tavel;
+        if (k <= nk - 2) tavel = ldr(a.t3d, base3 + (size_t)k * sk, r4);
+        else tavel = 0.5 * (tz_t + tlev_at(a, base3, sk, k, nk, nl));   // LW:12246 (also overwrites tlay(kte))
+        const int km = k < nk ? k : nk - 1;
+        double qv = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
+        qv = fmax(0., qv);
+        qv = fmax(qv, 1.E-12);
+        const double amdw = 1.607793, amdo = 0.603461;
+        const double h2ovmr = qv * amdw;
+        const double o3mmr = o3clim(plev_b, plev_t);
+        double o3vmr = o3mmr * amdo;
+        if (a.o33d && a.o3input == 2) {   // LW:12268-12280
+            if (k < nk) o3vmr = ldr(a.o33d, base3 + (size_t)k * sk, r4);
+            else {
+                const double pb = plev_at(a, base3, sk, nk - 1, nk, nl), pt = plev_at(a, base3, sk, nk, nk, nl);
+                double v = ldr(a.o33d, base3 + (size_t)(nk - 1) * sk, r4) - o3clim(pb, pt) * amdo + o3mmr * amdo;
+                o3vmr = v <= 0. ? o3mmr * amdo : v;
+            }
+        }
+        // fixed trace gases, LW:11720-11738
+        const double co2 = 379.e-6, ch4 = 1774.e-9, n2o = 319.e-9, cfc11 = 0.251e-9, cfc12 = 0.538e-9,
+                     cfc22 = 0.169e-9, ccl4 = 0.093e-9, o2 = 0.209488;
+        // inatm, LW:11262-11300
+        const double avogad = 6.02214199e+23, grav = 9.8066, amd = 28.9660, amw = 18.0160;
+        const double amm = (1. - h2ovmr) * amd + h2ovmr * amw;
+        const double coldry = (plev_b - plev_t) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + h2ovmr));
+        double summol = 0.0;
+        summol = summol + co2; summol = summol + o3vmr; summol = summol + n2o; summol = summol + 0.0;
+        summol = summol + ch4; summol = summol + o2;
+        const double wbrodl = coldry * (1. - summol);
+        const double wh2o = coldry * h2ovmr, wco2 = coldry * co2, wo3 = coldry * o3vmr, wn2o = coldry * n2o,
+                     wco = coldry * 0.0, wch4 = coldry * ch4, wo2 = coldry * o2;
+        c.wrk[k] = coldry + wh2o;
+        c.wrk[nl + k] = wh2o;
+        c.mul[LS_WX1 * nl + k] = coldry * ccl4 * 1.e-20;
+        c.mul[LS_WX2 * nl + k] = coldry * cfc11 * 1.e-20;
+        c.mul[LS_WX3 * nl + k] = coldry * cfc12 * 1.e-20;
+        c.mul[LS_WX4 * nl + k] = coldry * cfc22 * 1.e-20;
+        // setcoef: Planck functions, LW:3583-3644
+        int indlay = (int)(tavel - 159.);
+        indlay = indlay < 1 ? 1 : (indlay > 180 ? 180 : indlay);
+        const double tlayfrac = tavel - 159. - (double)indlay;
+        int indlev = (int)(tz_t - 159.);
+        indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
+        const double tlevfrac = tz_t - 159. - (double)indlev;
+        for (int ib = 0; ib < LW_NBND; ++ib) {
+            const double *P = tb.totplnk + ib * 181;
+            double dbdtlev = P[indlev] - P[indlev - 1];
+            double dbdtlay = P[indlay] - P[indlay - 1];
+            c.planklay[ib * nl + k] = P[indlay - 1] + tlayfrac * dbdtlay;
+            c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + tlevfrac * dbdtlev;
+        }
+        if (k == 0) {
+            const double tz0 = tlev_at(a, base3, sk, 0, nk, nl);
+            int indbound = (int)(tbound - 159.);
+            indbound = indbound < 1 ? 1 : (indbound > 180 ? 180 : indbound);
+            const double tbndfrac = tbound - 159. - (double)indbound;
+            int indlev0 = (int)(tz0 - 159.);
+            indlev0 = indlev0 < 1 ? 1 : (indlev0 > 180 ? 180 : indlev0);
+            const double t0frac = tz0 - 159. - (double)indlev0;
+            for (int ib = 0; ib < LW_NBND; ++ib) {
+                const double *P = tb.totplnk + ib * 181;
+                double dbdtlev = P[indbound] - P[indbound - 1];
+                c.plankbnd[ib] = semiss * (P[indbound - 1] + tbndfrac * dbdtlev);
+                dbdtlev = P[indlev0] - P[indlev0 - 1];
+                c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + t0frac * dbdtlev;
+            }
+            c.pz[0] = plev_b;
+        }
+        c.pz[k + 1] = plev_t;
+        // setcoef: interpolation factors, LW:3647-3808
+        const double stpfac = 296. / 1013.;
+        const double plog = log(pavel);
+        int jp = (int)(36. - 5 * (plog + 0.04));
+        jp = jp < 1 ? 1 : (jp > 58 ? 58 : jp);
+        const int jp1 = jp + 1;
+        const double fp = 5. * (c_lw_preflog[jp - 1] - plog);
+        const double d0 = (tavel - c_lw_tref[jp - 1]) / 15.;
+        int jtt = (int)(3. + d0);
+        jtt = jtt < 1 ? 1 : (jtt > 4 ? 4 : jtt);
+        const double ft = d0 - (double)(jtt - 3);
+        const double d1 = (tavel - c_lw_tref[jp1 - 1]) / 15.;
+        int jt1 = (int)(3. + d1);
+        jt1 = jt1 < 1 ? 1 : (jt1 > 4 ? 4 : jt1);
+        const double ft1 = d1 - (double)(jt1 - 3);
+        const double water = wh2o / coldry;
+        const double scalefac = pavel * stpfac / tavel;
+        const bool lower = plog > 4.56;
+        nlower += lower ? 1 : 0;
+        double forfac = scalefac / (1. + water), forfrac, selffac = water * forfac, selffrac = 0.;
+        int indfor, indself = 1;
+        if (lower) {
+            double factor = (332.0 - tavel) / 36.0;
+            int ifac = (int)factor;
+            indfor = ifac > 1 ? (ifac < 2 ? ifac : 2) : 1;
+            forfrac = factor - (double)indfor;
+            factor = (tavel - 188.0) / 7.2;
+            int is = (int)factor - 7;
+            indself = is > 1 ? (is < 9 ? is : 9) : 1;
+            selffrac = factor - (double)(indself + 7);
+        } else {
+            double factor = (tavel - 188.0) / 36.0;
+            indfor = 3;
+            forfrac = factor - 1.0;
+        }
+        const double scaleminor = pavel / tavel;
+        const double scaleminorn2 = (pavel / tavel) * (wbrodl / (coldry + wh2o));
+        double factor = (tavel - 180.8) / 7.2;
+        int im = (int)factor;
+        const int indminor = im > 1 ? (im < 18 ? im : 18) : 1;
+        const double minorfrac = factor - (double)indminor;
+        const double *X = tb.chi_mls;   // [7][59]
+#define CHI(m, l) X[((m)-1) * 59 + (l)-1]
+        c.rat[(LR_H2OCO2 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(2, jp);
+        c.rat[(LR_H2OCO2 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(2, jp + 1);
+        c.rat[(LR_H2OO3 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(3, jp);
+        c.rat[(LR_H2OO3 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(3, jp + 1);
+        c.rat[(LR_H2ON2O * 2 + 0) * nl + k] = CHI(1, jp) / CHI(4, jp);
+        c.rat[(LR_H2ON2O * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(4, jp + 1);
+        c.rat[(LR_H2OCH4 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(6, jp);
+        c.rat[(LR_H2OCH4 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(6, jp + 1);
+        c.rat[(LR_N2OCO2 * 2 + 0) * nl + k] = CHI(4, jp) / CHI(2, jp);
+        c.rat[(LR_N2OCO2 * 2 + 1) * nl + k] = CHI(4, jp + 1) / CHI(2, jp + 1);
+        c.rat[(LR_O3CO2 * 2 + 0) * nl + k] = CHI(3, jp) / CHI(2, jp);
+        c.rat[(LR_O3CO2 * 2 + 1) * nl + k] = CHI(3, jp + 1) / CHI(2, jp + 1);
+        c.rat[(LR_ONE * 2 + 0) * nl + k] = 1.;
+        c.rat[(LR_ONE * 2 + 1) * nl + k] = 1.;
+        const double colh2o = 1.e-20 * wh2o;
+        double colco2 = 1.e-20 * wco2, colo3 = 1.e-20 * wo3, coln2o = 1.e-20 * wn2o, colco = 1.e-20 * wco,
+               colch4 = 1.e-20 * wch4;
+        const double colo2 = 1.e-20 * wo2;
+        if (colco2 == 0.) colco2 = 1.e-32 * coldry;
+        if (colo3 == 0.) colo3 = 1.e-32 * coldry;
+        if (coln2o == 0.) coln2o = 1.e-32 * coldry;
+        if (colco == 0.) colco = 1.e-32 * coldry;
+        if (colch4 == 0.) colch4 = 1.e-32 * coldry;
+        const double colbrd = 1.e-20 * wbrodl;
+        c.mul[LS_H2O * nl + k] = colh2o; c.mul[LS_CO2 * nl + k] = colco2; c.mul[LS_O3 * nl + k] = colo3;
+        c.mul[LS_N2O * nl + k] = coln2o; c.mul[LS_CO * nl + k] = colco; c.mul[LS_CH4 * nl + k] = colch4;
+        c.mul[LS_O2 * nl + k] = colo2; c.mul[LS_BRD * nl + k] = colbrd; c.mul[LS_ZERO * nl + k] = 0.;
+        const double chin2o = CHI(4, jp + 1), chico2 = CHI(2, jp + 1);
+        c.mul[LS_ADJ_N2O * nl + k] = adjcol(coln2o, coldry, chin2o, 1.5, 0.5, 0.65);
+        c.mul[LS_ADJ_CO2_6 * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 2.0, 0.77);
+        c.mul[LS_ADJ_CO2_7L * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 3.0, 0.79);
+        c.mul[LS_ADJ_CO2_7U * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 2.0, 0.79);
+        c.mul[LS_ADJ_CO2_8 * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 2.0, 0.65);
+        c.mul[LS_ADJ_CO2_13 * nl + k] = adjcol(colco2, coldry, 3.55e-4, 3.0, 2.0, 0.68);
+        c.mul[LS_SCALEN2A * nl + k] = colbrd * scaleminorn2;
+        c.mul[LS_SCALEN2B * nl + k] = colbrd * scaleminor;
+        c.mul[LS_SCALEO2 * nl + k] = colo2 * scaleminor;
+#undef CHI
+        const double compfp = 1. - fp;
+        c.fac10[k] = compfp * ft;
+        c.fac00[k] = compfp * (1. - ft);
+        c.fac11[k] = fp * ft1;
+        c.fac01[k] = fp * (1. - ft1);
+        c.selffac[k] = colh2o * selffac;
+        c.forfac[k] = colh2o * forfac;
+        c.selffrac[k] = selffrac; c.forfrac[k] = forfrac; c.minorfrac[k] = minorfrac; c.pavel[k] = pavel;
+        c.rb0[k] = lower ? ((jp - 1) * 5 + (jtt - 1)) : ((jp - 13) * 5 + (jtt - 1));
+        c.rb1[k] = lower ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
+        c.inds[k] = indself - 1; c.indf[k] = indfor - 1; c.indm[k] = indminor - 1;
+    }
+    // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers)
+    for (int item = tid; item < LW_NBND * nl; item += LW_THREADS) {
+        const int nb = item / nl, k = item - nb * nl;
+        double tau = 0.;
+        if (a.aer_ra_feedback == 1 && k < nk) {
+            const size_t q = base3 + (size_t)k * sk;
+            if (ldr(a.tauaerlw[0], q, r4) > 1.e-9 && ldr(a.tauaerlw[15], q, r4) > 1.e-9) tau = ldr(a.tauaerlw[nb], q, r4);
+        }
+        c.taua[item] = tau;
+    }
+    // laytrop: layers with ln(p) > 4.56 (LW:3673)
+    __shared__ int s_laytrop;
+    if (tid == 0) s_laytrop = 0;
+    __syncthreads();
+    if (nlower) atomicAdd(&s_laytrop, nlower);
+    __syncthreads();
+    const int ltrop = s_laytrop;
+    if (tid == 0) {
+        // precipitable water -> diffusivity angle per band, LW:11307-11309 and LW:3142-3150
+        double amttl = 0.0, wvttl = 0.0;
+        for (int k = 0; k < nl; ++k) { amttl = amttl + c.wrk[k]; wvttl = wvttl + c.wrk[nl + k]; }
+        const double amd = 28.9660, amw = 18.0160, grav = 9.8066;
+        const double wvsh = (amw * wvttl) / (amd * amttl);
+        const double pwvcm = wvsh * (1.e3 * c.pz[0]) / (1.e2 * grav);
+        for (int ib = 0; ib < LW_NBND; ++ib) {
+            double sd = 1.66;
+            if (!(ib == 0 || ib == 3 || ib >= 9)) {
+                sd = c_a0[ib] + c_a1[ib] * exp(c_a2[ib] * pwvcm);
+                if (sd > 1.80) sd = 1.80;
+                if (sd < 1.50) sd = 1.50;
+            }
+            c.secdiff[ib] = sd;
+        }
+    }
+    if (a.aer_ra_feedback == 1 && tid >= 64 && tid < 64 + LW_NBND) {
+        // negative column aerosol optical depth is fatal, LW:12607-12615
+        const int nb = tid - 64;
+        double slope = 0.;
+        for (int k = 0; k < nk; ++k) slope = slope + c.taua[nb * nl + k];
+        if (slope < 0.) atomicMax(a.status, 1 + col);
+    }
+    __syncthreads();
+
+    // ======================= main phase: lanes = g-points =======================
+    const int gbeg = wave * LW_CHUNK;
+    const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
+    const bool active = lane < gcnt;
+    const int g = gbeg + (active ? lane : gcnt - 1);
+    const LwGDesc *gd = tb.gdesc + g;
+    LaneL L;
+    L.ng = gd->ng; L.off_self = gd->off_self; L.off_for = gd->off_for;
+    const int band = gd->band;
+    const double wgt = active ? 0.5 * gd->delwave : 0.;   // wtdiff * delwave(iband), LW:3366-3371
+    const double secdiff = c.secdiff[band];
+    const bool clean_on = a.clean > 0;
+    const int nlev = nl + 1;
+    double *fl = c.flux + (size_t)wave * 4 * nlev;
+    const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
+
+    // ---- downward sweep (top -> surface), LW:3207-3312 ----
+    double radld_c = 0., radld_t = 0., frac0 = 0.;
+    if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; }
+    auto down_step = [&](const LwRegime &R, int k) {
+        double taug, plfrac;
+        gas_optics(tb, c, R, L, k, taug, plfrac);
+        const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+        double at, bbd, bbu;
+        layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
+        radld_t = radld_t + (bbd - radld_t) * at;
+        if (clean_on) {
+            layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            radld_c = radld_c + (bbd - radld_c) * at;
+        }
+        double s = wave_sum2(wgt * radld_c, wgt * radld_t, lane);
+        if (lane == 0) fl[0 * nlev + k] = s;
+        if (lane == 32) fl[1 * nlev + k] = s;
+        frac0 = plfrac;
+    };
+    {
+        const LwRegime R = gd->up;
+        for (int k = nl - 1; k >= ltrop; --k) down_step(R, k);
+    }
+    {
+        const LwRegime R = gd->lo;
+        for (int k = ltrop - 1; k >= 0; --k) down_step(R, k);
+    }
+    // ---- surface: emission + reflection, LW:3320-3324 ----
+    const double rad0 = frac0 * c.plankbnd[band];
+    const double reflect = 1. - semiss;
+    double radlu_c = rad0 + reflect * radld_c, radlu_t = rad0 + reflect * radld_t;
+    {
+        double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
+        if (lane == 0) fl[2 * nlev] = s;
+        if (lane == 32) fl[3 * nlev] = s;
+    }
+    // ---- upward sweep (surface -> top), LW:3331-3356 ----
+    auto up_step = [&](const LwRegime &R, int k) {
+        double taug, plfrac;
+        gas_optics(tb, c, R, L, k, taug, plfrac);
+        const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+        double at, bbd, bbu;
+        layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+        radlu_t = radlu_t + (bbu - radlu_t) * at;
+        if (clean_on) {
+            layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            radlu_c = radlu_c + (bbu - radlu_c) * at;
+        }
+        double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
+        if (lane == 0) fl[2 * nlev + k + 1] = s;
+        if (lane == 32) fl[3 * nlev + k + 1] = s;
+    };
+    {
+        const LwRegime R = gd->lo;
+        for (int k = 0; k < ltrop; ++k) up_step(R, k);
+    }
+    {
+        const LwRegime R = gd->up;
+        for (int k = ltrop; k < nl; ++k) up_step(R, k);
+    }
+    __syncthreads();
+
+    // ======================= epilogue: lanes = levels =======================
+    const double *f0 = c.flux, *f1 = c.flux + (size_t)4 * nlev, *f2 = c.flux + (size_t)8 * nlev;
+    for (int l = tid; l < nlev; l += LW_THREADS) {
+        auto tot = [&](int q, int lev) { return (f0[q * nlev + lev] + f1[q * nlev + lev] + f2[q * nlev + lev]) * tb.fluxfac; };
+        const double dnc = clean_on ? tot(0, l) : 0., dn = tot(1, l), upc = clean_on ? tot(2, l) : 0., up = tot(3, l);
+        if (a.lwupflx && l <= nk + 1) {   // kts:kte+2, LW:12677-12684
+            const size_t q = base3f + (size_t)l * sk;
+            str(a.lwupflx, q, r4, up); str(a.lwupflxc, q, r4, up); str(a.lwdnflx, q, r4, dn); str(a.lwdnflxc, q, r4, dn);
+            str(a.lwupflxcln, q, r4, upc); str(a.lwdnflxcln, q, r4, dnc);
+        }
+        if (l < nk && a.rthratenlw) {
+            // htr(l) = heatfac*(fnet(l)-fnet(l+1))/(pz(l)-pz(l+1)), LW:3402; then LW:12687-12690
+            const double up1 = tot(3, l + 1), dn1 = tot(1, l + 1);
+            const double fnet0 = up - dn, fnet1 = up1 - dn1;
+            const double htr = tb.heatfac * (fnet0 - fnet1) / (c.pz[l] - c.pz[l + 1]);
+            const double tten = htr / 86400.;
+            str(a.rthratenlw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
+        }
+        if (l == 0) {
+            if (a.glw) str(a.glw, i2, r4, dn);
+            if (a.lwupt) {
+                str(a.lwupb, i2, r4, up); str(a.lwupbc, i2, r4, up); str(a.lwdnb, i2, r4, dn); str(a.lwdnbc, i2, r4, dn);
+                str(a.lwupbcln, i2, r4, upc); str(a.lwdnbcln, i2, r4, dnc);
+            }
+        }
+        if (l == nl) {
+            if (a.olr) str(a.olr, i2, r4, up);
+            if (a.lwcf) str(a.lwcf, i2, r4, up - up);   // cloud-free: uflxc == uflx
+            if (a.lwupt) {
+                str(a.lwupt, i2, r4, up); str(a.lwuptc, i2, r4, up); str(a.lwdnt, i2, r4, dn); str(a.lwdntc, i2, r4, dn);
+                str(a.lwuptcln, i2, r4, upc); str(a.lwdntcln, i2, r4, dnc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+size_t lw_lds_bytes(int nl)
+{
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 3 * LW_NBND + 2) + (nl + 1) + (size_t)LW_NBND * (nl + 1) +
+                2 * LW_NBND + (size_t)3 * 4 * (nl + 1);
+    size_t ni = (size_t)nl * 5;
+    return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
+}
+
+hipError_t lw_upload_constants(const double *preflog, const double *tref)
+{
+    static const double o3sum[31] = {
+        5.297E-8, 5.852E-8, 6.579E-8, 7.505E-8, 8.577E-8, 9.895E-8, 1.175E-7, 1.399E-7, 1.677E-7, 2.003E-7,
+        2.571E-7, 3.325E-7, 4.438E-7, 6.255E-7, 8.168E-7, 1.036E-6, 1.366E-6, 1.855E-6, 2.514E-6, 3.240E-6,
+        4.033E-6, 4.854E-6, 5.517E-6, 6.089E-6, 6.689E-6, 1.106E-5, 1.462E-5, 1.321E-5, 9.856E-6, 5.960E-6,
+        5.960E-6};
+    static const double ppsum[31] = {
+        955.890, 850.532, 754.599, 667.742, 589.841, 519.421, 455.480, 398.085, 347.171, 301.735, 261.310,
+        225.360, 193.419, 165.490, 141.032, 120.125, 102.689, 87.829, 75.123, 64.306, 55.086, 47.209, 40.535,
+        34.795, 29.865, 19.122, 9.277, 4.660, 2.421, 1.294, 0.647};
+    static const double o3win[31] = {
+        4.629E-8, 4.686E-8, 5.017E-8, 5.613E-8, 6.871E-8, 8.751E-8, 1.138E-7, 1.516E-7, 2.161E-7, 3.264E-7,
+        4.968E-7, 7.338E-7, 1.017E-6, 1.308E-6, 1.625E-6, 2.011E-6, 2.516E-6, 3.130E-6, 3.840E-6, 4.703E-6,
+        5.486E-6, 6.289E-6, 6.993E-6, 7.494E-6, 8.197E-6, 9.632E-6, 1.113E-5, 1.146E-5, 9.389E-6, 6.135E-6,
+        6.135E-6};
+    static const double ppwin[31] = {
+        955.747, 841.783, 740.199, 649.538, 568.404, 495.815, 431.069, 373.464, 322.354, 277.190, 237.635,
+        203.433, 174.070, 148.949, 127.408, 108.915, 93.114, 79.551, 67.940, 58.072, 49.593, 42.318, 36.138,
+        30.907, 26.362, 16.423, 7.583, 3.620, 1.807, 0.938, 0.469};
+    double o3ann[31], ppwrkh[32];
+    o3ann[0] = 0.5 * (o3sum[0] + o3win[0]);
+    for (int k = 1; k < 31; ++k)
+        o3ann[k] = o3win[k - 1] + (o3win[k] - o3win[k - 1]) / (ppwin[k] - ppwin[k - 1]) * (ppsum[k] - ppwin[k - 1]);
+    for (int k = 1; k < 31; ++k) o3ann[k] = 0.5 * (o3ann[k] + o3sum[k]);
+    ppwrkh[0] = 1100.;
+    for (int k = 1; k < 31; ++k) ppwrkh[k] = (ppsum[k] + ppsum[k - 1]) / 2.;
+    ppwrkh[31] = 0.;
+    hipError_t e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lw_o3ann), o3ann, sizeof o3ann)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lw_ppwrkh), ppwrkh, sizeof ppwrkh)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lw_preflog), preflog, 59 * sizeof(double))) != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_lw_tref), tref, 59 * sizeof(double));
+}
+
+hipError_t lw_launch(const LwKernelArgs &a, int ncol, hipStream_t stream)
+{
+    const size_t lds = lw_lds_bytes(a.nlayers);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_column_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(lw_column_kernel, dim3(ncol), dim3(LW_THREADS), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace rrtmg
