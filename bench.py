@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: aerosol + clean-sky RRTMG double call on MI355X.
+"""Benchmark of the hot path: aerosol + clean-sky RRTMG SW+LW double call on MI355X.
 
-A "step" is one pass of the HIP path over one batch of synthetic WRF columns
-resident in HBM.  Workload at N=1 (BASELINE.json configs[1]):
-200x200x40 synthetic columns, RRTMG-SW aerosol+clean double call, fp64.
-With --gpus N each rank owns its own 200x200 slab of (i,j) columns (weak
-scaling, no data-path collective); the only exchange is an all-reduce of the
-per-tile flux sums (16 doubles) over RCCL.
+A "step" is one pass of the HIP path (RRTMG_SWRAD + RRTMG_LWRAD, each with its
+aerosol and clean-sky call) over one batch of synthetic WRF columns resident in
+HBM.  Workload at N=1: 200x200x40 synthetic columns, fp64 (BASELINE.json
+configs[2] without the optical-averaging stage: aerosol optics are supplied in
+the WRF-Chem compact form, 12 SW + 16 LW arrays).  `--mode sw` runs configs[1]
+(SW double call only).  With --gpus N each rank owns its own 200x200 slab of
+(i,j) columns (weak scaling, no data-path collective); the only exchange is an
+all-reduce of the per-tile flux sums (32 doubles) over RCCL.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
-import subprocess
 import sys
 import tempfile
 import time
@@ -23,40 +24,50 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
-FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+P_TOP = 5000.0                 # Pa, model top of the synthetic atmosphere
 
 
-def algorithmic_bytes_per_column(nk, real_bytes=8):
-    """Compulsory boundary traffic of the SW double call with the WRF-Chem compact aerosol form
-    (DESIGN.md 'Measurement'): reads p3d,t3d,qv3d,pi3d (4K), p8w,t8w (2(K+1)), 12 aerosol arrays (12K),
-    3 surface scalars; writes rthratensw (K) and 22 two-dimensional fields."""
-    return ((4 + 12 + 1) * nk + 2 * (nk + 1) + 3 + 22) * real_bytes
+def algorithmic_bytes_per_column(nk, mode, real_bytes=8):
+    """Compulsory boundary traffic with the WRF-Chem compact aerosol form (DESIGN.md 'Measurement').
+    SW: reads p3d,t3d,qv3d,pi3d (4K), p8w,t8w (2(K+1)), 12 aerosol arrays (12K), 3 surface scalars;
+        writes rthratensw (K) and 22 two-dimensional fields.
+    LW: reads the same 6 state arrays again (second launch), 16 aerosol arrays (16K), 2 scalars;
+        writes rthratenlw (K) and 15 two-dimensional fields."""
+    sw = (4 + 12 + 1) * nk + 2 * (nk + 1) + 3 + 22
+    lw = (4 + 16 + 1) * nk + 2 * (nk + 1) + 2 + 15
+    return (sw + (lw if mode == "swlw" else 0)) * real_bytes, sw * real_bytes, lw * real_bytes
 
 
-def cpu_baseline(tab, st, ncol_sample):
-    """Reference Fortran (oracle/_ref/ref_sw, built from /root/reference by oracle/build_ref.sh) timed on
-    one host core over a bounded sample of the same workload; falls back to the C port if the binary is absent."""
+def cpu_baseline(tab_sw, tab_lw, st, ncol_sample, mode):
+    """Reference Fortran (oracle/_ref, built from /root/reference by oracle/build_ref.sh) timed on one host
+    core over a bounded sample of the same workload; falls back to the C port if the binaries are absent."""
     from tools.make_golden import sw_columns_from_state, run_ref_sw
-    cols = sw_columns_from_state(st)
-    cols = {k: v[:ncol_sample] for k, v in cols.items()}
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_sw")
-    if os.path.exists(exe):
-        t0 = time.perf_counter()
-        _, stdout = run_ref_sw(tab, cols, clean=1)
-        wall = time.perf_counter() - t0
-        secs = float(stdout.split("seconds=")[1].split()[0])   # solver loop only, excludes table init and file I/O
+    from tools.make_golden_lw import lw_columns_from_state, run_ref_lw
+    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_sw")) and \
+        os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_lw"))
+    cols = {k: v[:ncol_sample] for k, v in sw_columns_from_state(st).items()}
+    if have_ref:
+        _, so = run_ref_sw(tab_sw, cols, clean=1)
+        secs_sw = float(so.split("seconds=")[1].split()[0])
+        secs_lw = 0.0
+        if mode == "swlw":
+            lcols = {k: v[:ncol_sample] for k, v in lw_columns_from_state(st).items()}
+            _, lo = run_ref_lw(tab_lw, lcols, clean=1)
+            secs_lw = float(lo.split("seconds=")[1].split()[0])
+        secs = secs_sw + secs_lw
         return {"value": ncol_sample / secs, "unit": "columns/s", "cores": 1, "kind": "reference",
-                "sample": f"{ncol_sample} columns of the bench workload through rrtmg_sw (flang -O2, fp64), "
-                          f"{secs:.2f} s solver time ({wall:.2f} s incl. I/O)"}
+                "sample": f"{ncol_sample} columns of the bench workload through the reference rrtmg_sw"
+                          f"{' + rrtmg_lw' if mode == 'swlw' else ''} (flang -O2, fp64, 1 core): "
+                          f"SW {secs_sw:.2f} s, LW {secs_lw:.2f} s solver time"}
     from oracle import oracle as orc
-    o = orc.SwOracle(tab)
-    n = min(ncol_sample, 512)
+    o = orc.SwOracle(tab_sw)
+    n = min(ncol_sample, 256)
     t0 = time.perf_counter()
     o.rrtmg_sw({k: v[:n] for k, v in cols.items()}, clean=1)
     secs = time.perf_counter() - t0
     return {"value": n / secs, "unit": "columns/s", "cores": 1, "kind": "port",
-            "sample": f"{n} columns through the C restatement (gcc -O2), {secs:.2f} s"}
+            "sample": f"{n} columns through the C restatement of rrtmg_sw only (gcc -O2), {secs:.2f} s"}
 
 
 def main():
@@ -67,6 +78,7 @@ def main():
     ap.add_argument("--ni", type=int, default=200)
     ap.add_argument("--nj", type=int, default=200)
     ap.add_argument("--nk", type=int, default=40)
+    ap.add_argument("--mode", choices=["swlw", "sw"], default="swlw")
     ap.add_argument("--night", type=float, default=0.0, help="fraction of night columns (0 for kernel timing)")
     ap.add_argument("--cpu-sample", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -76,6 +88,7 @@ def main():
     import torch.distributed as dist
     import wrfchem_arc_amd as wa
     from tests.helpers import AER, IN2, IN3, OUT2, dims_of
+    from tests import helpers_lw as hl
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,74 +104,105 @@ def main():
     import __graft_entry__ as ge
     if not os.path.exists(wa.engine.LIB_PATH):
         ge.build_product()
-    eng = wa.engine
+    eng, engl = wa.engine, wa.engine_lw
     tmp = tempfile.mkdtemp(prefix="rrtmg_bench_")
     tab = os.path.join(tmp, "RRTMG_SW_DATA")
+    tabl = os.path.join(tmp, "RRTMG_LW_DATA")
     wa.synth.write_sw_data(tab, seed=20260001, real_bytes=8)
+    wa.synth.write_lw_data(tabl, seed=20260003, real_bytes=8)
     eng.rrtmg_swinit(tab, 8, device=local_rank)
+    do_lw = args.mode == "swlw"
+    if do_lw:
+        engl.rrtmg_lwinit(P_TOP, tabl, kme=args.nk + 1, device=local_rank)
 
-    # each rank: its own (i,j) slab of the domain, seed = 20260000 + config# + rank
+    # each rank: its own (i,j) slab of the domain
     st = wa.synth.make_wrf_state(args.ni, args.nj, args.nk, seed=20260002 + 1000 * rank, night_fraction=args.night)
     ncol = st.ncol
     d = dims_of(st)
-    dev_in = {n: torch.from_numpy(np.ascontiguousarray(st.a2[n])).cuda() for n in IN2}
-    dev_in.update({n: torch.from_numpy(np.ascontiguousarray(st.a3[n])).cuda() for n in IN3 + AER})
-    dev_out = {"rthratensw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
-    dev_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in OUT2})
-    sums = torch.zeros(16, dtype=torch.float64, device="cuda")
-    flux12 = ["swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
-              "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln"]
 
-    def step():
-        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **dev_in, **dev_out)
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    sw_in = {n: dev(st.a2[n]) for n in IN2}
+    sw_in.update({n: dev(st.a3[n]) for n in IN3 + AER})
+    sw_out = {"rthratensw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
+    sw_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in OUT2})
+    lw_in = {n: dev(st.a2[n]) for n in hl.IN2}
+    lw_in.update({n: sw_in[n] for n in hl.IN3})            # the same state arrays, not copies
+    lw_in.update({n: dev(st.a3[n]) for n in hl.AER})
+    lw_out = {"rthratenlw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
+    lw_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in hl.OUT2})
+    sums = torch.zeros(32, dtype=torch.float64, device="cuda")
+    sw12 = ["swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
+            "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln"]
+    lw12 = ["lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
+            "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
+
+    def sw_call():
+        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **sw_in, **sw_out)
+
+    def lw_call():
+        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **lw_in, **lw_out)
+
+    def gather_sums():
+        # the only exchange on the path: per-tile flux / forcing sums for the domain means
+        for i, n in enumerate(sw12):
+            sums[i] = sw_out[n].sum()
+        if do_lw:
+            for i, n in enumerate(lw12):
+                sums[12 + i] = lw_out[n].sum()
+        sums[24] = sums[2] - sums[0]      # SWUPTCLN - SWUPT
+        sums[25] = sums[14] - sums[12]    # LWUPTCLN - LWUPT
+        sums[26] = float(ncol)
+        dist.all_reduce(sums)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        sw_call()
+        if ev:
+            ev[1].record()
+        if do_lw:
+            lw_call()
+        if ev:
+            ev[2].record()
         if world > 1:
-            # the only exchange on the path: per-tile flux / forcing sums for the domain means
-            for i, n in enumerate(flux12):
-                sums[i] = dev_out[n].sum()
-            sums[12] = sums[2] - sums[0]
-            sums[13] = float(ncol)
-            dist.all_reduce(sums)
+            gather_sums()
 
     for _ in range(args.warmup):
         step()
     eng.sw_status()
+    if do_lw:
+        engl.lw_status()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    kernel_ms = []
+    events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ev0.record()
-        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **dev_in, **dev_out)
-        ev1.record()
-        if world > 1:
-            for i, n in enumerate(flux12):
-                sums[i] = dev_out[n].sum()
-            sums[12] = sums[2] - sums[0]
-            sums[13] = float(ncol)
-            dist.all_reduce(sums)
-        kernel_ms.append((ev0, ev1))
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        step(ev)
+        events.append(ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     eng.sw_status()
+    if do_lw:
+        engl.lw_status()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    kms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))   # HIP events on the launch stream
+    sw_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))   # HIP events on the launch stream
+    lw_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if do_lw else 0.0
 
     if rank == 0:
         value = world * ncol * args.steps / elapsed
-        bpc = algorithmic_bytes_per_column(args.nk)
-        achieved = ncol * bpc / (kms * 1e-3) / 1e9
+        bpc, bpc_sw, bpc_lw = algorithmic_bytes_per_column(args.nk, args.mode)
+        achieved = ncol * bpc_sw / (sw_ms * 1e-3) / 1e9          # dominant kernel: sw_column_kernel
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tf):
@@ -166,25 +210,31 @@ def main():
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        what = "SW+LW" if do_lw else "RRTMG-SW"
         line = {
             "metric": "columns/sec, aerosol+clean RRTMG SW+LW double-call; flux RMSE vs reference",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, RRTMG-SW "
-                                   "aerosol+clean double-call only, fp64 (BASELINE configs[1]); LW not yet on the path",
+            "config": {"workload": f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, {what} "
+                                   "aerosol+clean double-call, fp64, cloud-free; aerosol optics supplied in the "
+                                   "WRF-Chem compact form (BASELINE configs[2] without the optical-averaging stage)"
+                                   if do_lw else
+                                   f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, RRTMG-SW "
+                                   "aerosol+clean double-call only, fp64 (BASELINE configs[1])",
                        "columns_per_gpu": ncol, "layers": args.nk, "night_fraction": args.night,
-                       "aerosol_form": "WRF-Chem compact (tauaer/waer/gaer at 300/400/600/999 nm)",
-                       "parallelism": f"(i,j) slabs over {world} GPU(s), RCCL all-reduce of 16 flux sums"},
+                       "parallelism": f"(i,j) slabs over {world} GPU(s), RCCL all-reduce of 32 flux sums"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sw_column_kernel", "kernel_ms": kms, "algorithmic_bytes_per_column": bpc,
-                         "note": "fp64-VALU-bound path (SURVEY 8d): arithmetic intensity ~1e3 flop/B, "
-                                 "see DESIGN.md for the fp64 ceiling"},
+                         "kernel": "sw_column_kernel", "kernel_ms": sw_ms,
+                         "algorithmic_bytes_per_column": bpc_sw,
+                         "lw_kernel_ms": lw_ms, "lw_algorithmic_bytes_per_column": bpc_lw if do_lw else 0,
+                         "step_algorithmic_GBs": ncol * bpc / ((sw_ms + lw_ms) * 1e-3) / 1e9,
+                         "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
         }
         if world == 1 and not args.no_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(tab, st, min(args.cpu_sample, ncol))
+                line["cpu_baseline"] = cpu_baseline(tab, tabl, st, min(args.cpu_sample, ncol), args.mode)
             except Exception as e:   # never let the baseline leg kill the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "reference",
                                         "sample": f"failed: {e!r}"}

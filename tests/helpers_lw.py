@@ -1,7 +1,10 @@
 """Longwave test plumbing: RRTMG_LWRAD through the HIP C-ABI and through the oracle."""
 import numpy as np
 
-from helpers import SENTINEL, dims_of
+try:
+    from helpers import SENTINEL, dims_of
+except ImportError:  # imported as tests.helpers_lw (bench.py)
+    from tests.helpers import SENTINEL, dims_of
 
 OUT2 = ["glw", "olr", "lwcf", "lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
         "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
