@@ -146,15 +146,10 @@ def main():
 
     def gather_sums():
         # the only exchange on the path: per-tile flux / forcing sums for the domain means
-        for i, n in enumerate(sw12):
-            sums[i] = sw_out[n].sum()
+        wa.tiles.tile_sums_device(sw_out, sw12, d, sums[:16])          # native deterministic reduction
         if do_lw:
-            for i, n in enumerate(lw12):
-                sums[12 + i] = lw_out[n].sum()
-        sums[24] = sums[2] - sums[0]      # SWUPTCLN - SWUPT
-        sums[25] = sums[14] - sums[12]    # LWUPTCLN - LWUPT
-        sums[26] = float(ncol)
-        dist.all_reduce(sums)
+            wa.tiles.tile_sums_device(lw_out, lw12, d, sums[16:])
+        wa.tiles.allreduce_sums(sums)
 
     def step(ev=None):
         if ev:

@@ -107,6 +107,11 @@ long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *args);
  * swupb,swupbc,swupbcln,swdnb,swdnbc,swdnbcln, (swuptcln-swupt), ncol_day,
  * ncol, 0. */
 int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *args, double *out16, char *err);
+/* same for any 12 two-dimensional device arrays (order *upt,*uptc,*uptcln,*dnt,
+ * *dntc,*dntcln,*upb,*upbc,*upbcln,*dnb,*dnbc,*dnbcln); out16 is device memory;
+ * enqueued on `stream`, deterministic summation order. */
+int rrtmg_hip_tile_sums(const void *const *fields12, int real_bytes, int ims, int ime, int jms, int jme,
+                        int its, int ite, int jts, int jte, double *out16_dev, void *stream, char *err);
 
 /* ------------------------------- longwave -------------------------------- */
 
@@ -142,6 +147,7 @@ typedef struct rrtmg_hip_lwrad_args {
 int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *args, char *err);
 int rrtmg_hip_lw_status(char *err);
 int rrtmg_hip_lw_finalize(void);
+int rrtmg_hip_lw_tile_sums(const rrtmg_hip_lwrad_args *args, double *out16, char *err);
 /* host-only helpers for the CPU tests of the init path */
 int rrtmg_hip_lw_reduce_tables(const char *data_path, int data_real_bytes, double cpdair, double *k_out,
                                long long k_cap, long long *k_len, double *exp_out, double *tfn_out, char *err);

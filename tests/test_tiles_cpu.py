@@ -1,0 +1,76 @@
+"""CPU: the N>1 path -- j-slab sharding and the one collective -- with world_size-2 gloo.
+Each rank runs the ORACLE on its own slab (the oracle is allowed in tests), reduces its 12 TOA/surface
+fields to the 16-vector, all-reduces it over gloo, and the result must equal the single-process
+sums over the whole domain; every column must be computed by exactly one rank."""
+import os
+
+import numpy as np
+import pytest
+
+
+def test_slab_bounds_cover_and_balance(wa):
+    t = wa.tiles
+    for n, world in ((200, 8), (7, 3), (5, 8), (1, 2), (500, 4)):
+        seen = []
+        for r in range(world):
+            js, je = t.slab_bounds(1, n, world, r)
+            seen.extend(range(js, je + 1))
+            assert je - js + 1 in (n // world, n // world + 1)
+        assert seen == list(range(1, n + 1))
+    # weighted: balance by daylit columns; slabs stay contiguous, ordered, covering
+    w = np.array([0, 0, 0, 10, 10, 10, 10, 0, 0, 10, 10, 10])
+    cuts = [t.slab_bounds(1, 12, 3, r, weights=w) for r in range(3)]
+    cover = [j for js, je in cuts for j in range(js, je + 1)]
+    assert cover == list(range(1, 13))
+    loads = [w[js - 1:je].sum() for js, je in cuts]
+    assert max(loads) - min(loads) <= 10
+    with pytest.raises(ValueError):
+        t.slab_bounds(1, 12, 3, 0, weights=w[:-1])
+
+
+def _worker(rank, world, port, tab, q):
+    import torch
+    import torch.distributed as dist
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import wrfchem_arc_amd as wa
+    from oracle import oracle as orc
+    from helpers import run_oracle_swrad
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = wa.synth.make_wrf_state(5, 6, 30, seed=20260300, night_fraction=0.3)
+    day_rows = (st.a2["xcoszen"] > 0).sum(axis=1)
+    js, je = wa.tiles.slab_bounds(1, st.nj, world, rank, weights=day_rows)
+    out = run_oracle_swrad(orc.SwOracle(tab), st, tile=dict(jts=js, jte=je), profiles=False)
+    v = torch.from_numpy(wa.tiles.tile_sums_host(out, wa.tiles.SW12, 1, st.ni, js, je))
+    wa.tiles.allreduce_sums(v)
+    q.put((rank, js, je, v.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sums_equal_single_process(wa, sw_table_file, sw_oracle):
+    import torch.multiprocessing as mp
+    from helpers import run_oracle_swrad
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sw_table_file, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, js0, je0, v0), (r1, js1, je1, v1) = res
+    st = wa.synth.make_wrf_state(5, 6, 30, seed=20260300, night_fraction=0.3)
+    assert js0 == 1 and je1 == st.nj and js1 == je0 + 1          # disjoint, ordered, covering
+    np.testing.assert_array_equal(v0, v1)                        # both ranks hold the reduced vector
+    full = run_oracle_swrad(sw_oracle, st, profiles=False)
+    ref = wa.tiles.tile_sums_host(full, wa.tiles.SW12, 1, st.ni, 1, st.nj)
+    np.testing.assert_allclose(v0[:13], ref[:13], rtol=1e-13, atol=1e-9)
+    assert v0[13] == st.ni * st.nj
+    means = wa.tiles.domain_means(v0)
+    np.testing.assert_allclose(means[0], full["swupt"].mean(), rtol=1e-12)

@@ -1,6 +1,6 @@
 """MI355X-native column-radiation engine for WRF-Chem's aerosol + clean-sky
 RRTMG double call (drop-in for RRTMG_SWRAD / RRTMG_LWRAD of the
 douglowe/WRFChem-ARC-Interactions patch set)."""
-from . import engine, engine_lw, synth  # noqa: F401
+from . import engine, engine_lw, synth, tiles  # noqa: F401
 
-__all__ = ["synth", "engine", "engine_lw"]
+__all__ = ["synth", "engine", "engine_lw", "tiles"]

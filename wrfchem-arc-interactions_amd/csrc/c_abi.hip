@@ -293,10 +293,6 @@ extern "C" int rrtmg_hip_sw_status(char *err)
     return 0;
 }
 
-extern "C" int rrtmg_hip_sw_tile_sums(const rrtmg_hip_swrad_args *, double *, char *err)
-{
-    return fail(err, "rrtmg_hip_sw_tile_sums: not implemented yet");
-}
 
 extern "C" int rrtmg_hip_finalize(void)
 {
