@@ -57,6 +57,47 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
     else reinterpret_cast<double *>(p)[idx] = v;
 }
 
+// reciprocal / quotient without the compiler's IEEE special-case scaffolding (see sw_kernel.hip)
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double r = frcp(b);
+    double q = a * r;
+    double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+// exp(-x) for 0 <= x <~ 700 in fp64: n = rint(-x/ln2), two-term Cody-Waite reduction, degree-13 Taylor
+// on |r| <= ln2/2 (truncation 6e-18 relative), v_ldexp_f64.  Within ~2 ulp of a correctly rounded exp.
+__device__ __forceinline__ double exp_neg(double x)
+{
+    const double t = -x;
+    const double n = rint(t * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, t);
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;               // 1/13!
+    p = __builtin_fma(p, r, 2.0876756987868098979e-09); // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441718775e-08); // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985890653e-07); // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06); // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05); // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04); // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03); // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03); // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02); // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01); // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // sums of two values over the wave: lane 0 ends with sum(a), lane 32 with sum(b)
 __device__ __forceinline__ double wave_sum2(double a, double b, int lane)
 {
@@ -110,7 +151,7 @@ __device__ __forceinline__ void spec_idx(double cola, double ratio, double colb,
                                          double &speccomb, double &specparm, int &j, double &f)
 {
     speccomb = cola + ratio * colb;
-    specparm = cola / speccomb;
+    specparm = fdiv(cola, speccomb);
     specparm = specparm >= oneminus ? oneminus : specparm;
     double specmult = mult * specparm;
     j = (int)specmult;
@@ -155,9 +196,14 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         }
         if (!binary) { wm1 = 0.; w0 = 1.; w1 = 0.; w2 = 0.; jsi = 0; speccomb = colA; }
         const double *Kp = tb.K + R.off_major + (size_t)(rb[m] * nsp + jsi) * ng;
-        double s = (wm1 * fT[m]) * Kp[-ng] + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * Kp[2 * ng] +
-                   (wm1 * fT1[m]) * Kp[ts - ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] +
-                   (w2 * fT1[m]) * Kp[ts + 2 * ng];
+        double s;
+        if (__any(wm1 != 0. || w2 != 0.)) {   // some lane of the wave sits on a 3-point edge stencil
+            s = (wm1 * fT[m]) * Kp[-ng] + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * Kp[2 * ng] +
+                (wm1 * fT1[m]) * Kp[ts - ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] +
+                (w2 * fT1[m]) * Kp[ts + 2 * ng];
+        } else {                              // same value: the skipped terms are exact zeros
+            s = (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng];
+        }
         maj[m] = s;
         sc[m] = speccomb;
     }
@@ -227,11 +273,20 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, 
 {
     double odepth = secdiff * tau;
     odepth = odepth < 0.0 ? 0.0 : odepth;
-    double tblind = odepth / (tb.bpade + odepth);
+    double tblind = fdiv(odepth, tb.bpade + odepth);
     int itr = (int)(10000.0 * tblind + 0.5);
-    itr = itr > LW_NTBL ? LW_NTBL : itr;
+    const bool last = itr >= LW_NTBL;
+    itr = last ? LW_NTBL - 1 : itr;
     const bool small = odepth <= 0.06;
-    double transc = tb.exp_tbl[itr], tausfac_t = tb.tfn_tbl[itr];
+    // The reference reads exp_tbl(itr) and tfn_tbl(itr) (10 001-entry tables, LW:7940-7957).  A 64-lane
+    // gather of random entries costs more texture-addresser time than recomputing the entry, so the
+    // quantised table value is re-evaluated from its index: same itr, same formulas as rrtmg_lw_ini.
+    const double tfn = fdiv((double)itr, 10000.0);
+    const double tau_t = fdiv(tb.bpade * tfn, 1. - tfn);
+    double transc = fmax(exp_neg(tau_t), 1.e-20);
+    double tausfac_t = tau_t < 0.06 ? fdiv(tau_t, 6.) : 1. - 2. * (frcp(tau_t) - fdiv(transc, 1. - transc));
+    transc = last ? 1.e-20 : transc;
+    tausfac_t = last ? 1.0 : tausfac_t;
     atrans = small ? odepth - 0.5 * odepth * odepth : 1. - transc;
     double tausfac = small ? 0.166667 * odepth : tausfac_t;
     // small branch: plfrac*(blay + dplank*odepth_rec); table branch: plfrac*(blay + tausfac*dplank)

@@ -80,10 +80,41 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// sums of two values over the wave in one butterfly: lane 0 ends with sum(a), lane 32 with sum(b)
+__device__ __forceinline__ double wave_sum2(double a, double b, int lane)
+{
+    const bool hi = lane & 32;
+    double send = hi ? a : b, keep = hi ? b : a;
+    double v = keep + __shfl_xor(send, 32, 64);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Reciprocal / quotient without the IEEE special-case scaffolding of the compiler's fp64 division
+// (v_div_scale x2, v_div_fmas, v_div_fixup): v_rcp_f64 seed, two Newton steps, one residual
+// correction.  Operands on this path are normal-range and non-zero (the reference guards its own
+// denominators with max(.,1e-30)); the result agrees with IEEE division to <= 1 ulp.
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double r = frcp(b);
+    double q = a * r;
+    double rem = __builtin_fma(-b, q, a);
+    return __builtin_fma(rem, r, q);
+}
+
 // transmittance by lookup table or small-argument expansion (SW:8459-8466, 2575-2581)
 __device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze1)
 {
-    double tblind = ze1 / (tb.bpade + ze1);
+    double tblind = fdiv(ze1, tb.bpade + ze1);
     int itind = (int)(10000.0 * tblind + 0.5);
     itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
     double tv = tb.exp_tbl[itind];
@@ -161,6 +192,69 @@ __device__ __forceinline__ void reftra(const SwDeviceTables &tb, double zto1, do
     }
 }
 
+// reftra_sw (SW:2526-2699) with the divisions folded: the reference forms zep1 = 1/zem1 and
+// zep2 = 1/zem2 and divides by zdenr = zr4*zep1 + zr5*zem1 (= zdent); multiplying numerators and
+// denominator by zem1 gives the same ratios over D = zr4 + zr5*zem1^2 with one reciprocal, and
+// zdend = 1/((1 - zbeta*zemm)*zrkg) = 1/(zrkg - (zgamma1 - zrk)*zemm) without forming zbeta.
+// zem2 is the caller's direct-beam transmittance exp(-tau/mu0): the reference looks it up twice
+// (SW:2663-2665 with the 500 cap, SW:8568-8575 without; beyond the cap both are the 1e-20 floor).
+__device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto1, double zw, double zg,
+                                            double prmuz, double zem2, RT &o)
+{
+    const double eps = 1.e-08, zwcrit = 0.9999995;
+    double zg3 = 3. * zg;
+    double zgamma1 = (8. - zw * (5. + zg3)) * 0.25;
+    double zgamma2 = 3. * (zw * (1. - zg)) * 0.25;
+    double zgamma3 = (2. - zg3 * prmuz) * 0.25;
+    double zgamma4 = 1. - zgamma3;
+    double zq = fdiv(zg, 1. - zg);
+    double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
+    if (zw >= zwcrit * denom) {   // zwo = zw/denom >= zwcrit, SW:2557-2560
+        // conservative scattering, SW:2560-2600
+        double za = zgamma1 * prmuz;
+        double za1 = za - zgamma3;
+        double zgt = zgamma1 * zto1;
+        double rg = frcp(1. + zgt);
+        double r = (zgt - za1 * (1. - zem2)) * rg;
+        double rd = zgt * rg;
+        bool one = (zem2 == 1.0);
+        o.ref = one ? 0.0 : r;
+        o.tra = one ? 1.0 : 1. - r;
+        o.refd = one ? 0.0 : rd;
+        o.trad = one ? 1.0 : 1. - rd;
+    } else {
+        double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
+        double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
+        double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        double zrp = zrk * prmuz;
+        double zrp1 = 1. + zrp;
+        double zrm1 = 1. - zrp;
+        double zrk2 = 2. * zrk;
+        double zrpp = 1. - zrp * zrp;
+        double zrkg = zrk + zgamma1;
+        double zr1 = zrm1 * (za2 + zrk * zgamma3);
+        double zr2 = zrp1 * (za2 - zrk * zgamma3);
+        double zr3 = zrk2 * (zgamma3 - za2 * prmuz);
+        double zr4 = zrpp * zrkg;
+        double zr5 = zrpp * (zrk - zgamma1);
+        double zt1 = zrp1 * (za1 + zrk * zgamma4);
+        double zt2 = zrm1 * (za1 - zrk * zgamma4);
+        double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
+        double zem1 = exp_lookup(tb, fmin(zrk * zto1, 500.));
+        double zemm = zem1 * zem1;
+        double D = zr4 + zr5 * zemm;                 // zdenr * zem1
+        double rD = frcp(D);
+        bool small = fabs(D) <= eps * zem1;          // |zdenr| <= eps, SW:2679
+        double r = zw * (zr1 - zr2 * zemm - zr3 * (zem2 * zem1)) * rD;
+        double t = zem2 - zw * (zem2 * (zt1 - zt2 * zemm) - zt3 * zem1) * rD;
+        o.ref = small ? eps : r;
+        o.tra = small ? zem2 : t;
+        double zdend = frcp(zrkg - (zgamma1 - zrk) * zemm);
+        o.refd = zgamma2 * (1. - zemm) * zdend;
+        o.trad = zrk2 * zem1 * zdend;
+    }
+}
+
 // LDS image of one column (all arrays indexed by 0-based layer, bottom -> top)
 struct ColView {
     double *fac00, *fac01, *fac10, *fac11;
@@ -215,7 +309,7 @@ __device__ __forceinline__ void gas_optics(const SwDeviceTables &tb, const ColVi
     if (cf & CFG_BINARY) {
         // SW:3321-3326
         speccomb = colA + R.strrat * colB;
-        double specparm = colA / speccomb;
+        double specparm = fdiv(colA, speccomb);
         specparm = specparm >= tb.oneminus ? tb.oneminus : specparm;
         double specmult = ((cf & CFG_MULT4) ? 4. : 8.) * specparm;
         jsi = (int)specmult;
@@ -266,18 +360,19 @@ __device__ __forceinline__ void layer_rt(const SwDeviceTables &tb, const ColView
     const int ia = L.band * c.nlp + k;
     const double ta = aer_on ? c.taer[ia] : 0.0;   // clean call: ztauacln = 0 (SW:9346), omega/g unchanged
     const double wa = c.waer[ia], ga = c.gaer[ia];
+    const double rprmu0 = 1.0 / prmu0;   // loop-invariant: hoisted by the compiler
     double ztauc = taur + taug + ta;
     double zomcc = taur * 1.0 + ta * wa;
-    double zgcc = ga * wa * ta / zomcc;
-    zomcc = zomcc / ztauc;
-    if (NODEL) dbt_nodel = exp_lookup(tb, ztauc / prmu0);
+    double zgcc = fdiv(ga * wa * ta, zomcc);
+    zomcc = fdiv(zomcc, ztauc);
+    if (NODEL) dbt_nodel = exp_lookup(tb, ztauc * rprmu0);
     double zf = zgcc * zgcc;
     double zwf = zomcc * zf;
     ztauc = (1.0 - zwf) * ztauc;
-    zomcc = (zomcc - zwf) / fmax((1.0 - zwf), 1.0E-30);
-    zgcc = (zgcc - zf) / fmax((1.0 - zf), 1.0E-30);
-    reftra(tb, ztauc, zomcc, zgcc, prmu0, o);
-    o.dbt = exp_lookup(tb, ztauc / prmu0);
+    zomcc = fdiv(zomcc - zwf, fmax((1.0 - zwf), 1.0E-30));
+    zgcc = fdiv(zgcc - zf, fmax((1.0 - zf), 1.0E-30));
+    o.dbt = exp_lookup(tb, ztauc * rprmu0);
+    reftra_fast(tb, ztauc, zomcc, zgcc, prmu0, o.dbt, o);
 }
 
 }  // namespace
@@ -556,7 +651,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             double dummy;
             layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy);
             // vrtqdr_sw, SW:7997-8015
-            double zreflect = 1. / (1. - rupd * rt.refd);
+            double zreflect = frcp(1. -rupd * rt.refd);
             double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
             double nrupd = rt.refd + rt.trad * rt.trad * rupd * zreflect;
             rup = nrup; rupd = nrupd;
@@ -578,7 +673,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
                 } else {
                     rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
                 }
-                double zreflect = 1. / (1. - rud[j] * rt[j].refd);
+                double zreflect = frcp(1. -rud[j] * rt[j].refd);
                 ru[j + 1] = rt[j].ref + (rt[j].trad * ((rt[j].tra - rt[j].dbt) * rud[j] + rt[j].dbt * ru[j])) * zreflect;
                 rud[j + 1] = rt[j].refd + rt[j].trad * rt[j].trad * rud[j] * zreflect;
             }
@@ -587,14 +682,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
                 const int l = b * BLK + j + 1;   // level at the top of layer k = b*BLK + j
                 if (l <= nlay) {
                     // fluxes at level l, SW:8038-8044
-                    double zreflect = 1. / (1. - rdnd * rud[j + 1]);
+                    double zreflect = frcp(1. -rdnd * rud[j + 1]);
                     double fu = (tdbt * ru[j + 1] + (tdn - tdbt) * rud[j + 1]) * zreflect;
                     double fd = tdbt + (tdn - tdbt + tdbt * ru[j + 1] * rdnd) * zreflect;
-                    double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
-                    if (lane == 0) { flux[2 * l] = su; flux[2 * l + 1] = sd; }
+                    double s2 = wave_sum2(zincflx * fu, zincflx * fd, lane);
+                    if (lane == 0) flux[2 * l] = s2;
+                    if (lane == 32) flux[2 * l + 1] = s2;
                 }
                 // through layer k, SW:8026-8034 and SW:8578
-                double zreflect = 1. / (1. - rt[j].refd * rdnd);
+                double zreflect = frcp(1. -rt[j].refd * rdnd);
                 double ntdn = tdbt * rt[j].tra + (rt[j].trad * ((tdn - tdbt) + tdbt * rt[j].ref * rdnd)) * zreflect;
                 double nrdnd = rt[j].refd + rt[j].trad * rt[j].trad * rdnd * zreflect;
                 tdn = ntdn; rdnd = nrdnd;
@@ -603,7 +699,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             }
         }
         {   // surface level
-            double zreflect = 1. / (1. - rdnd * alb);
+            double zreflect = frcp(1. -rdnd * alb);
             double fu = (tdbt * alb + (tdn - tdbt) * alb) * zreflect;
             double fd = tdbt + (tdn - tdbt + tdbt * alb * rdnd) * zreflect;
             double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
