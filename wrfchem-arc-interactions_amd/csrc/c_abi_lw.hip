@@ -179,7 +179,8 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         return failw(err, "rrtmg_hip_lwrad: inconsistent tile / memory dimensions");
     const int nl = st.nlayers;
     if (nl < nk + 1 || nl > 200) return failw(err, "rrtmg_hip_lwrad: NLAYERS from rrtmg_hip_lw_init does not fit this tile");
-    if (lw_lds_bytes(nl) > 160 * 1024 - 64) return failw(err, "rrtmg_hip_lwrad: column does not fit LDS");
+    if (lw_gas_lds_bytes(nl) > 160 * 1024 - 64 || lw_rt_lds_bytes(nl) > 160 * 1024 - 64)
+        return failw(err, "rrtmg_hip_lwrad: column does not fit LDS");
     if (a->aer_ra_feedback == 1)
         for (int b = 0; b < 16; ++b)
             if (!a->tauaerlw[b]) return failw(err, "Warning: missing fields required for aerosol radiation");   // LW:11823-11845
@@ -240,7 +241,32 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     if (a->lwupflx && !(a->lwupflxc && a->lwupflxcln && a->lwdnflx && a->lwdnflxc && a->lwdnflxcln))
         return failw(err, "rrtmg_hip_lwrad: the six flux profile arrays must be passed together");
 
-    HIPCHK(lw_launch(k, ni_t * nj_t, stream));
+    // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB (default 8192) holds
+    const int ncol = ni_t * nj_t;
+    double *scratch = nullptr;
+    int cap_cols = 0;
+    {
+        size_t mb = 8192;
+        if (const char *e = std::getenv("RRTMG_HIP_LW_SCRATCH_MB")) {
+            const long v = std::atol(e);
+            if (v > 0) mb = (size_t)v;
+        }
+        const size_t percol = lw_scratch_doubles(nl);
+        size_t cols = (mb << 20) / (percol * sizeof(double));
+        if (cols < 8) cols = 8;
+        cap_cols = (size_t)ncol < cols ? ncol : (int)cols;
+        std::lock_guard<std::mutex> lock(st.scratch_mutex);
+        LwState::Scratch &w = st.scratch[stream];
+        if (w.doubles < percol * (size_t)cap_cols) {
+            if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
+            void *p = nullptr;
+            HIPCHK(hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double)));
+            w.p = static_cast<double *>(p);
+            w.doubles = percol * (size_t)cap_cols;
+        }
+        scratch = w.p;
+    }
+    HIPCHK(lw_launch(k, ncol, scratch, cap_cols, stream));
 
     if (a->mem != 1) {
         for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
@@ -280,6 +306,11 @@ extern "C" int rrtmg_hip_lw_finalize(void)
     LwState &st = lw_state();
     void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus};
     for (void **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    {
+        std::lock_guard<std::mutex> lock(st.scratch_mutex);
+        for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+        st.scratch.clear();
+    }
     st.ready = false;
     return 0;
 }

@@ -20,11 +20,24 @@ struct LwKernelArgs {
     void *lwupb, *lwupbc, *lwupbcln, *lwdnb, *lwdnbc, *lwdnbcln;
     void *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;
     int *status;
+    // scratch between the gas-optics kernel and the transfer kernel, per column slot of the batch:
+    // taug / frac [slot][layer][140]; rec [slot][lw_rec_doubles(nlayers)]
+    double *taug, *frac, *rec;
+    int col0;                           // first tile column of this batch
     LwDeviceTables tab;
 };
 
-size_t lw_lds_bytes(int nlayers);
+// per-column record handed from lw_gas_kernel to lw_rt_kernel:
+// planklay[16][nl] planklev[16][nl+1] taua[16][nl] secdiff[16] plankbnd[16] pz[nl+1]
+__host__ __device__ inline size_t lw_rec_doubles(int nl) { return (size_t)49 * nl + 49; }
+// scratch doubles one column needs (taug + frac + record)
+inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_rec_doubles(nl); }
+
+size_t lw_gas_lds_bytes(int nlayers);
+size_t lw_rt_lds_bytes(int nlayers);
 hipError_t lw_upload_constants(const double *preflog, const double *tref);
-hipError_t lw_launch(const LwKernelArgs &a, int ncol, hipStream_t stream);
+// runs ncol columns in batches of at most cap_cols through the two kernels; `scratch` holds
+// cap_cols * lw_scratch_doubles(nlayers) doubles
+hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream);
 
 }  // namespace rrtmg

@@ -124,7 +124,9 @@ struct LCol {   // LDS image of the column
     int nl;
 };
 
-__device__ __forceinline__ LCol carve(double *base, int nl)
+// gas kernel: the layer state lives in LDS; the per-band Planck / aerosol arrays are written straight
+// into the column's global record (lw_rec_doubles), which lw_rt_kernel stages into its own LDS
+__device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
 {
     LCol c;
     c.nl = nl;
@@ -135,14 +137,29 @@ __device__ __forceinline__ LCol carve(double *base, int nl)
     c.pz = p; p += nl + 1;
     c.mul = p; p += LS_COUNT * nl;
     c.rat = p; p += LR_COUNT * 2 * nl;
+    c.wrk = p; p += 2 * nl;
+    int *q = reinterpret_cast<int *>(p);
+    c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
+    double *r = rec;
+    c.planklay = r; r += LW_NBND * nl;
+    c.planklev = r; r += LW_NBND * (nl + 1);
+    c.taua = r; r += LW_NBND * nl;
+    c.secdiff = r; r += LW_NBND; c.plankbnd = r; r += LW_NBND;
+    c.flux = nullptr;
+    return c;
+}
+// transfer kernel: LDS image of the record (same order) followed by the flux slots
+__device__ __forceinline__ LCol carve_rt(double *base, int nl)
+{
+    LCol c{};
+    c.nl = nl;
+    double *p = base;
     c.planklay = p; p += LW_NBND * nl;
     c.planklev = p; p += LW_NBND * (nl + 1);
     c.taua = p; p += LW_NBND * nl;
     c.secdiff = p; p += LW_NBND; c.plankbnd = p; p += LW_NBND;
-    c.wrk = p; p += 2 * nl;
+    c.pz = p; p += nl + 1;
     c.flux = p; p += 3 * 4 * (nl + 1);
-    int *q = reinterpret_cast<int *>(p);
-    c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
     return c;
 }
 
@@ -347,20 +364,27 @@ __device__ __forceinline__ double adjcol(double col, double coldry, double chire
 
 }  // namespace
 
-__global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernelArgs a)
+// column slot of this workgroup within the batch: consecutive slots stay on one XCD (its own L2)
+__device__ __forceinline__ int batch_slot()
+{
+    const int b = blockIdx.x, nwg = gridDim.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
+// fractions of every (layer, g-point) (taumol, lanes = g-points) -> scratch.
+__global__ void __launch_bounds__(LW_THREADS) lw_gas_kernel(const LwKernelArgs a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
-    LCol c = carve(lds, nl);
+    const int slot = batch_slot();
+    const int col = a.col0 + slot;
+    double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
+    LCol c = carve_gas(lds, rec, nl);
 
-    int col;
-    {
-        const int b = blockIdx.x, nwg = gridDim.x;
-        const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        col = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
     const size_t i2 = j0 * a.ni_m + i0;
@@ -582,7 +606,10 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
     }
     __syncthreads();
 
-    // ======================= main phase: lanes = g-points =======================
+    // pressure levels complete the record (heating-rate denominators of the transfer kernel)
+    for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_doubles(nl) - (nl + 1) + l] = c.pz[l];
+
+    // ======================= gas optics: lanes = g-points, loop over layers =======================
     const int gbeg = wave * LW_CHUNK;
     const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
     const bool active = lane < gcnt;
@@ -590,20 +617,71 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
     const LwGDesc *gd = tb.gdesc + g;
     LaneL L;
     L.ng = gd->ng; L.off_self = gd->off_self; L.off_for = gd->off_for;
+    double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    {
+        const LwRegime R = gd->lo;
+        for (int k = 0; k < ltrop; ++k) {
+            double taug, plfrac;
+            gas_optics(tb, c, R, L, k, taug, plfrac);
+            if (active) { tg[(size_t)k * LW_NGPT] = taug; fr[(size_t)k * LW_NGPT] = plfrac; }
+        }
+    }
+    {
+        const LwRegime R = gd->up;
+        for (int k = ltrop; k < nl; ++k) {
+            double taug, plfrac;
+            gas_optics(tb, c, R, L, k, taug, plfrac);
+            if (active) { tg[(size_t)k * LW_NGPT] = taug; fr[(size_t)k * LW_NGPT] = plfrac; }
+        }
+    }
+}
+
+// Kernel 2 of 2: radiative transfer (rtrnmc) for the clean and the aerosol optical depths, lanes = g-points;
+// flux profiles, heating rate and the WRF output fields.
+__global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
+{
+    extern __shared__ double lds[];
+    const LwDeviceTables &tb = a.tab;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nk = a.nk, nl = a.nlayers;
+    const int slot = batch_slot();
+    const int col = a.col0 + slot;
+    LCol c = carve_rt(lds, nl);
+    {
+        const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
+        const int n = (int)lw_rec_doubles(nl);
+        for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
+    }
+    const int it = col % a.ni_t, jt = col / a.ni_t;
+    const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
+    const size_t i2 = j0 * a.ni_m + i0;
+    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m, sjf = (size_t)a.ni_m * (a.nk_m + 2);
+    const size_t base3 = j0 * sj + k0 * sk + i0, base3f = j0 * sjf + k0 * sk + i0;
+    const int r4 = a.real4;
+    const double semiss = ldr(a.emiss, i2, r4);   // same emissivity in all 16 bands, LW:12296-12298
+
+    const int gbeg = wave * LW_CHUNK;
+    const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
+    const bool active = lane < gcnt;
+    const int g = gbeg + (active ? lane : gcnt - 1);
+    const LwGDesc *gd = tb.gdesc + g;
     const int band = gd->band;
     const double wgt = active ? 0.5 * gd->delwave : 0.;   // wtdiff * delwave(iband), LW:3366-3371
-    const double secdiff = c.secdiff[band];
     const bool clean_on = a.clean > 0;
     const int nlev = nl + 1;
+    const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    __syncthreads();
+    const double secdiff = c.secdiff[band];
     double *fl = c.flux + (size_t)wave * 4 * nlev;
     const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
 
     // ---- downward sweep (top -> surface), LW:3207-3312 ----
     double radld_c = 0., radld_t = 0., frac0 = 0.;
     if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; }
-    auto down_step = [&](const LwRegime &R, int k) {
-        double taug, plfrac;
-        gas_optics(tb, c, R, L, k, taug, plfrac);
+    double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
+    for (int k = nl - 1; k >= 0; --k) {
+        const double taug = tnext, plfrac = fnext;
+        if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         double at, bbd, bbu;
         layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
@@ -616,14 +694,6 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
         if (lane == 0) fl[0 * nlev + k] = s;
         if (lane == 32) fl[1 * nlev + k] = s;
         frac0 = plfrac;
-    };
-    {
-        const LwRegime R = gd->up;
-        for (int k = nl - 1; k >= ltrop; --k) down_step(R, k);
-    }
-    {
-        const LwRegime R = gd->lo;
-        for (int k = ltrop - 1; k >= 0; --k) down_step(R, k);
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
     const double rad0 = frac0 * c.plankbnd[band];
@@ -635,9 +705,9 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
         if (lane == 32) fl[3 * nlev] = s;
     }
     // ---- upward sweep (surface -> top), LW:3331-3356 ----
-    auto up_step = [&](const LwRegime &R, int k) {
-        double taug, plfrac;
-        gas_optics(tb, c, R, L, k, taug, plfrac);
+    for (int k = 0; k < nl; ++k) {   // tnext / fnext hold layer 0 after the downward sweep
+        const double taug = tnext, plfrac = fnext;
+        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         double at, bbd, bbu;
         layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
@@ -649,14 +719,6 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
         double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
         if (lane == 0) fl[2 * nlev + k + 1] = s;
         if (lane == 32) fl[3 * nlev + k + 1] = s;
-    };
-    {
-        const LwRegime R = gd->lo;
-        for (int k = 0; k < ltrop; ++k) up_step(R, k);
-    }
-    {
-        const LwRegime R = gd->up;
-        for (int k = ltrop; k < nl; ++k) up_step(R, k);
     }
     __syncthreads();
 
@@ -697,12 +759,15 @@ __global__ void __launch_bounds__(LW_THREADS, 2) lw_column_kernel(const LwKernel
 }
 
 // ---------------------------------------------------------------------------
-size_t lw_lds_bytes(int nl)
+size_t lw_gas_lds_bytes(int nl)
 {
-    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 3 * LW_NBND + 2) + (nl + 1) + (size_t)LW_NBND * (nl + 1) +
-                2 * LW_NBND + (size_t)3 * 4 * (nl + 1);
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2) + (nl + 1);
     size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
+}
+size_t lw_rt_lds_bytes(int nl)
+{
+    return (lw_rec_doubles(nl) + (size_t)3 * 4 * (nl + 1)) * sizeof(double);
 }
 
 hipError_t lw_upload_constants(const double *preflog, const double *tref)
@@ -740,17 +805,33 @@ hipError_t lw_upload_constants(const double *preflog, const double *tref)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_lw_tref), tref, 59 * sizeof(double));
 }
 
-hipError_t lw_launch(const LwKernelArgs &a, int ncol, hipStream_t stream)
+hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream)
 {
-    const size_t lds = lw_lds_bytes(a.nlayers);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_column_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nl = a.nlayers;
+    const size_t lds_gas = lw_gas_lds_bytes(nl), lds_rt = lw_rt_lds_bytes(nl);
+    static size_t attr_gas = 0, attr_rt = 0;
+    if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_gas_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gas);
         if (e != hipSuccess) return e;
-        attr_bytes = lds;
+        attr_gas = lds_gas;
     }
-    hipLaunchKernelGGL(lw_column_kernel, dim3(ncol), dim3(LW_THREADS), lds, stream, a);
+    if (lds_rt > attr_rt && lds_rt > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
+        if (e != hipSuccess) return e;
+        attr_rt = lds_rt;
+    }
+    if (!scratch || cap_cols <= 0) return hipErrorInvalidValue;
+    a.taug = scratch;
+    a.frac = a.taug + (size_t)cap_cols * nl * LW_NGPT;
+    a.rec = a.frac + (size_t)cap_cols * nl * LW_NGPT;
+    for (int c0 = 0; c0 < ncol; c0 += cap_cols) {
+        const int n = ncol - c0 < cap_cols ? ncol - c0 : cap_cols;
+        a.col0 = c0;
+        hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
+        hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -1,5 +1,7 @@
 // Host-side state of the longwave engine.
 #pragma once
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,12 @@ struct LwState {
     LwDeviceTables dev{};
     void *dK = nullptr, *dExp = nullptr, *dTfn = nullptr, *dPlk = nullptr, *dChi = nullptr, *dG = nullptr,
          *dStatus = nullptr;
+    // Scratch between the two kernels (taug, frac, column record), one grow-only buffer per stream: calls
+    // on one stream run in order and may share it, calls on different streams (the OpenMP tile loop of
+    // DRV:975-982) must not.
+    struct Scratch { double *p = nullptr; size_t doubles = 0; };
+    std::map<void *, Scratch> scratch;
+    std::mutex scratch_mutex;
 };
 
 LwState &lw_state();
