@@ -297,11 +297,14 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, 
     const bool small = odepth <= 0.06;
     // The reference reads exp_tbl(itr) and tfn_tbl(itr) (10 001-entry tables, LW:7940-7957).  A 64-lane
     // gather of random entries costs more texture-addresser time than recomputing the entry, so the
-    // quantised table value is re-evaluated from its index: same itr, same formulas as rrtmg_lw_ini.
-    const double tfn = fdiv((double)itr, 10000.0);
-    const double tau_t = fdiv(tb.bpade * tfn, 1. - tfn);
+    // quantised table value is re-evaluated from its index: same itr, the formulas of rrtmg_lw_ini with
+    // tfn = itr/10000 substituted (tau = bpade*itr/(10000-itr)) and the two quotients of tfn_tbl,
+    // 1/tau - trans/(1-trans), taken over one common denominator.
+    const double fi = (double)itr;
+    const double tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
     double transc = fmax(exp_neg(tau_t), 1.e-20);
-    double tausfac_t = tau_t < 0.06 ? fdiv(tau_t, 6.) : 1. - 2. * (frcp(tau_t) - fdiv(transc, 1. - transc));
+    const double omt = 1. - transc;
+    double tausfac_t = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp(tau_t * omt));
     transc = last ? 1.e-20 : transc;
     tausfac_t = last ? 1.0 : tausfac_t;
     atrans = small ? odepth - 0.5 * odepth * odepth : 1. - transc;
@@ -374,7 +377,7 @@ __device__ __forceinline__ int batch_slot()
 
 // Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
 // fractions of every (layer, g-point) (taumol, lanes = g-points) -> scratch.
-__global__ void __launch_bounds__(LW_THREADS) lw_gas_kernel(const LwKernelArgs a)
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) lw_gas_kernel(const LwKernelArgs a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
@@ -687,7 +690,8 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
         layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
         radld_t = radld_t + (bbd - radld_t) * at;
         if (clean_on) {
-            layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
+            if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
             radld_c = radld_c + (bbd - radld_c) * at;
         }
         double s = wave_sum2(wgt * radld_c, wgt * radld_t, lane);
@@ -713,7 +717,8 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
         layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
         radlu_t = radlu_t + (bbu - radlu_t) * at;
         if (clean_on) {
-            layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
+            if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
             radlu_c = radlu_c + (bbu - radlu_c) * at;
         }
         double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
