@@ -154,6 +154,58 @@ int rrtmg_hip_lw_reduce_tables(const char *data_path, int data_real_bytes, doubl
 int rrtmg_hip_lw_table_info(const char *data_path, int data_real_bytes, int g, int *fields24, double *dfields8,
                             char *err);
 
+/* ------------------------- aerosol optical averaging ------------------------ */
+/*
+ * Produces the arrays the radiation path consumes (S2 / L2): tauaer1..4, waer1..4, gaer1..4 at 300/400/600/999 nm
+ * (registry.chem:1367-1378, handed over at module_first_rk_step_part1.F:374-385, consumed at
+ * module_ra_rrtmg_sw.F:10993-11023) and tauaerlw1..16 per RRTMG-LW band (registry.chem:1349-1364, consumed at
+ * module_ra_rrtmg_lw.F:12582-12604) from MOSAIC sectional aerosol (registry.chem:2325-2447, packages
+ * registry.chem:3823-3826).  Upstream WRF-Chem does this in chem/module_optical_averaging.F, which is NOT part of
+ * the reference repository: there is no reference arithmetic to match, the physics is specified in DESIGN.md
+ * (volume-mixed or Maxwell-Garnett refractive index per bin, homogeneous-sphere Mie theory evaluated per grid
+ * cell, bin and wavelength) and parity is "unpinned".
+ *
+ * chem is WRF-Chem's 4-D tracer array chem(ims:ime, kms:kme, jms:jme, num_chem), i fastest; idx[b][s] is the
+ * 1-based index (as in module_state_description's p_so4_a01 ...) of species s of bin b, 0 = not carried.
+ */
+enum {
+    RRTMG_HIP_AER_SO4 = 0, RRTMG_HIP_AER_NO3, RRTMG_HIP_AER_CL, RRTMG_HIP_AER_NH4, RRTMG_HIP_AER_NA,
+    RRTMG_HIP_AER_OIN, RRTMG_HIP_AER_OC, RRTMG_HIP_AER_BC, RRTMG_HIP_AER_WATER, RRTMG_HIP_AER_NUM,
+    RRTMG_HIP_AER_NSPEC
+};
+#define RRTMG_HIP_MAXBIN 8
+
+/* nbin sections between dlo_um and dhi_um (MOSAIC: 0.0390625 and 10.0 um), equal in log diameter.
+ * refindex: NULL = built-in table, else [9 mass species][20 wavelengths][2] (real, imaginary >= 0) for the 4 SW
+ * wavelengths followed by the 16 LW band centres; density: NULL = built-in, else [9] in g cm-3. */
+int rrtmg_hip_optics_init(int nbin, double dlo_um, double dhi_um, const double *refindex, const double *density,
+                          int device, char *err);
+
+typedef struct rrtmg_hip_optics_args {
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    int real_bytes;
+    int mem;
+    void *stream;
+    int aer_op_opt;           /* registry.chem:4014-4018: 1/3 volume mixing, 2/4 Maxwell-Garnett (BC inclusions);
+                                 every option evaluates Mie theory per cell; 5 (shell_exact) is refused */
+    int num_chem;
+    int idx[RRTMG_HIP_MAXBIN][RRTMG_HIP_AER_NSPEC];
+    const void *chem;         /* (ims:ime, kms:kme, jms:jme, num_chem), ug/kg-dryair, number #/kg-dryair */
+    const void *alt;          /* inverse dry-air density, m3 kg-1, 3-D */
+    const void *dz8w;         /* layer thickness, m, 3-D */
+    /* outputs, 3-D; each group may be NULL as a whole */
+    void *tauaer[4], *waer[4], *gaer[4];        /* layer optical depth, single-scattering albedo, asymmetry */
+    void *extaer[4], *bscoef[4];                /* extinction 1/km, backscatter 1/(km sr) */
+    void *tauaerlw[16];                         /* layer absorption optical depth per LW band */
+    void *extaerlw[16];                         /* absorption coefficient 1/km */
+} rrtmg_hip_optics_args;
+
+int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *args, char *err);
+int rrtmg_hip_optics_finalize(void);
+/* host-only: wavelengths (um) of the 20 spectral points and the table the engine would use */
+int rrtmg_hip_optics_table_info(double *wavelength_um20, double *refindex_9x20x2, double *density9);
+
 /* Device for this process: RRTMG_HIP_DEVICE, else the MPI/SLURM local rank
  * (OMPI_COMM_WORLD_LOCAL_RANK, MV2_COMM_WORLD_LOCAL_RANK, MPI_LOCALRANKID,
  * SLURM_LOCALID, LOCAL_RANK) modulo the visible device count, else 0. */

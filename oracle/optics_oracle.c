@@ -1,0 +1,186 @@
+/*
+ * oracle/optics_oracle.c -- CPU restatement of the aerosol optical-averaging stage.  TEST INFRASTRUCTURE ONLY:
+ * imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path.
+ *
+ * PARITY UNPINNED.  The arithmetic of this stage (upstream WRF-Chem chem/module_optical_averaging.F) is not part
+ * of /root/reference; only its interface is (tracers: Registry/registry.chem:2325-2447, 3823-3826; outputs:
+ * registry.chem:1332-1387; consumers: phys/module_ra_rrtmg_sw.F:10993-11023, module_ra_rrtmg_lw.F:12582-12604).
+ * This file restates the engine's own specification (DESIGN.md "Optical averaging") in plain C99 with
+ * <complex.h>, and its Mie core is pinned against published known answers instead (tests/test_optics_oracle.py):
+ * Bohren & Huffman (1983) appendix A test case, Wiscombe (1979) / Du (2004) efficiency tables, the Rayleigh and
+ * geometric-optics limits, and an independent formulation with scipy's spherical Bessel functions.
+ */
+#include <complex.h>
+#include <math.h>
+#include <stddef.h>
+
+#define NSPEC 9
+#define NSLOT 10
+#define NWAVE 20
+#define NSW 4
+#define NMIE 256
+#define XMAX 225.0
+#define S_BC 7
+#define S_WATER 8
+#define S_NUM 9
+
+/* Homogeneous sphere after Bohren & Huffman (1983), appendix A (BHMIE): D_n by downward recurrence, Riccati-
+ * Bessel psi/chi by upward recurrence, nstop = x + 4 x^(1/3) + 2.  BHMIE starts the D_n recurrence at
+ * max(xstop,|mx|)+15, which leaves errors up to 1e-4 .. 1 in D_n for |mx| > 10 (the start value decays only
+ * where n exceeds |mx| by several |mx|^(1/3)); the start is therefore raised by 8 |mx|^(1/3), after which D_n
+ * equals the converged value to the last bit in a 20 000-case sweep. */
+void optics_oracle_mie(double x, double mre, double mim, double *out4)
+{
+    static _Thread_local double complex D[4096];
+    const double complex m = mre + I * mim;
+    const double complex y = x * m;
+    const double xstop = x + 4. * cbrt(x) + 2.;
+    const int nstop = (int)xstop;
+    const double base = fmax(xstop, cabs(y));
+    int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 15;
+    if (nmx > 4095) nmx = 4095;
+    D[nmx] = 0.;
+    for (int n = nmx; n >= 2; --n) {
+        const double complex ny = (double)n / y;
+        D[n - 1] = ny - 1. / (D[n] + ny);
+    }
+    double psi0 = cos(x), psi1 = sin(x), chi0 = -sin(x), chi1 = cos(x);
+    double complex an1 = 0., bn1 = 0., xb = 0.;
+    double qs = 0., qe = 0., gs = 0., sgn = -1.;
+    for (int n = 1; n <= nstop; ++n) {
+        const double en = (double)n;
+        const double psi = (2. * en - 1.) * psi1 / x - psi0;
+        const double chi = (2. * en - 1.) * chi1 / x - chi0;
+        const double complex xi = psi - I * chi, xi1 = psi1 - I * chi1;
+        const double complex ta = D[n] / m + en / x, tb = m * D[n] + en / x;
+        const double complex an = (ta * psi - psi1) / (ta * xi - xi1);
+        const double complex bn = (tb * psi - psi1) / (tb * xi - xi1);
+        qs += (2. * en + 1.) * (creal(an) * creal(an) + cimag(an) * cimag(an) + creal(bn) * creal(bn) + cimag(bn) * cimag(bn));
+        qe += (2. * en + 1.) * (creal(an) + creal(bn));
+        gs += ((2. * en + 1.) / (en * (en + 1.))) * (creal(an) * creal(bn) + cimag(an) * cimag(bn));
+        if (n > 1)
+            gs += ((en - 1.) * (en + 1.) / en) *
+                  (creal(an1) * creal(an) + cimag(an1) * cimag(an) + creal(bn1) * creal(bn) + cimag(bn1) * cimag(bn));
+        xb += sgn * (2. * en + 1.) * (an - bn);
+        sgn = -sgn;
+        psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
+        an1 = an; bn1 = bn;
+    }
+    out4[0] = 2. * qe / (x * x);                           /* Qext */
+    out4[1] = 2. * qs / (x * x);                           /* Qsca */
+    out4[2] = qs > 0. ? 2. * gs / qs : 0.;                 /* asymmetry parameter */
+    out4[3] = (creal(xb) * creal(xb) + cimag(xb) * cimag(xb)) / (x * x);   /* Qback */
+}
+
+typedef struct optics_oracle_tables {
+    double refr[NSPEC][NWAVE], refi[NSPEC][NWAVE];
+    double dens[NSPEC];
+    double wavelength_um[NWAVE];
+    double dlo_um[8], dhi_um[8];
+    int nbin;
+} optics_oracle_tables;
+
+/* one grid cell: mass[b][s] ug/kg (s = so4 no3 cl nh4 na oin oc bc water), num[b] #/kg, alt m3/kg, dz m.
+ * out_sw[w][5] = tau, omega, g, ext (1/km), backscatter (1/(km sr)); out_lw[b][2] = absorption tau, coefficient (1/km) */
+void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *mass /*[nbin][9]*/,
+                        const double *numb /*[nbin]*/, double alt, double dz, double *out_sw, double *out_lw)
+{
+    const double pi = 3.14159265358979323846;
+    for (int w = 0; w < NWAVE; ++w) {
+        double ext = 0., sca = 0., gsca = 0., bsc = 0.;
+        for (int b = 0; b < t->nbin; ++b) {
+            double vol[NSPEC], vdry = 0.;
+            for (int s = 0; s < NSPEC; ++s) {
+                vol[s] = fmax(mass[b * NSPEC + s], 0.) / t->dens[s];
+                if (s != S_WATER) vdry += vol[s];
+            }
+            double num = fmax(numb[b], 0.);
+            if (!(vdry > 1.e-25)) continue;
+            const double vwet = vdry + vol[S_WATER];
+            const double vpart = vdry * 1.e-6 / fmax(num, 1.e-30);
+            double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+            if (ddry < t->dlo_um[b] || ddry > t->dhi_um[b]) {
+                ddry = ddry < t->dlo_um[b] ? t->dlo_um[b] : t->dhi_um[b];
+                const double dcm = ddry * 1.e-4;
+                num = vdry * 1.e-6 / ((pi / 6.) * dcm * dcm * dcm);
+            }
+            const double dwet = ddry * cbrt(vwet / vdry);
+            double complex m;
+            double sr = 0., si = 0.;
+            for (int s = 0; s < NSPEC; ++s) {
+                if (mix == 1 && s == S_BC) continue;
+                sr += vol[s] * t->refr[s][w];
+                si += vol[s] * t->refi[s][w];
+            }
+            if (mix == 0) {
+                m = (sr + I * si) / vwet;
+            } else {
+                const double vbc = vol[S_BC], vmat = vwet - vbc;
+                const double complex mbc = t->refr[S_BC][w] + I * t->refi[S_BC][w];
+                if (!(vmat > 1.e-30 * vwet)) m = mbc;
+                else {
+                    const double complex mm = (sr + I * si) / vmat;
+                    if (!(vbc > 0.)) m = mm;
+                    else {
+                        const double f = vbc / vwet;
+                        const double complex em = mm * mm, ei = mbc * mbc;
+                        m = csqrt(em * (ei + 2. * em + 2. * f * (ei - em)) / (ei + 2. * em - f * (ei - em)));
+                    }
+                }
+            }
+            double x = pi * dwet / t->wavelength_um[w];
+            if (x > XMAX) x = XMAX;
+            double q[4];
+            optics_oracle_mie(x, creal(m), cimag(m), q);
+            const double dcm = dwet * 1.e-4;
+            const double cross = (num / alt * 1.e-6) * (0.25 * pi * dcm * dcm);
+            ext += cross * q[0];
+            sca += cross * q[1];
+            gsca += cross * q[1] * q[2];
+            bsc += cross * q[3] * (0.25 / pi);
+        }
+        if (w < NSW) {
+            double *o = out_sw + w * 5;
+            o[0] = ext * 100. * dz;
+            o[1] = ext > 0. ? sca / ext : 0.;
+            o[2] = sca > 0. ? gsca / sca : 0.;
+            o[3] = ext * 1.e5;
+            o[4] = bsc * 1.e5;
+        } else {
+            double *o = out_lw + (w - NSW) * 2;
+            const double ab = fmax(ext - sca, 0.);
+            o[0] = ab * 100. * dz;
+            o[1] = ab * 1.e5;
+        }
+    }
+}
+
+/* a WRF tile: chem(ni_m,nk_m,nj_m,num_chem) i fastest, idx[b][10] 0-based (-1 absent); outputs are 3-D arrays
+ * of the memory shape, [field][ni_m*nk_m*nj_m]: sw5 = 4 wavelengths x (tau,omega,g,ext,bsc), lw2 = 16 x (tau,ext) */
+void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0, int j0,
+                        int ni_t, int nk_t, int nj_t, int num_chem, const int *idx /*[8][10]*/, const double *chem,
+                        const double *alt, const double *dz8w, double *sw5, double *lw2)
+{
+    const size_t n3 = (size_t)ni_m * nk_m * nj_m;
+    (void)num_chem;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int jt = 0; jt < nj_t; ++jt)
+        for (int k = 0; k < nk_t; ++k)
+            for (int it = 0; it < ni_t; ++it) {
+                const size_t q = ((size_t)(j0 + jt) * nk_m + (k0 + k)) * ni_m + (i0 + it);
+                double mass[8 * NSPEC], num[8], osw[NSW * 5], olw[16 * 2];
+                for (int b = 0; b < t->nbin; ++b) {
+                    for (int s = 0; s < NSPEC; ++s) {
+                        const int id = idx[b * NSLOT + s];
+                        mass[b * NSPEC + s] = id >= 0 ? chem[(size_t)id * n3 + q] : 0.;
+                    }
+                    const int id = idx[b * NSLOT + S_NUM];
+                    num[b] = id >= 0 ? chem[(size_t)id * n3 + q] : 0.;
+                }
+                optics_oracle_cell(t, mix, mass, num, alt[q], dz8w[q], osw, olw);
+                for (int w = 0; w < NSW; ++w)
+                    for (int f = 0; f < 5; ++f) sw5[((size_t)w * 5 + f) * n3 + q] = osw[w * 5 + f];
+                for (int b = 0; b < 16; ++b)
+                    for (int f = 0; f < 2; ++f) lw2[((size_t)b * 2 + f) * n3 + q] = olw[b * 2 + f];
+            }
+}

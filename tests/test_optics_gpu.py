@@ -1,0 +1,113 @@
+"""GPU parity tests: the optical-averaging stage through the HIP C-ABI against the CPU oracle (parity unpinned:
+the oracle restates the engine's own specification, see oracle/optics_oracle.c).
+
+Tolerance: |hip - oracle| <= 1e-8*|oracle| + 1e-30 in fp64.  The Mie series is evaluated in the same order on both
+sides; differences come from FMA contraction, reciprocal-based division and the device's sin/cos/cbrt, amplified
+by the cancellation in psi_n for very small size parameters (longwave bands, x ~ 2e-3)."""
+import numpy as np
+import pytest
+
+from helpers import SENTINEL
+from helpers_optics import LW_NAMES, SW_NAMES, run_hip_optics, run_oracle_optics, tile_mask
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+
+
+def _init(wa, nbin):
+    import torch
+    assert torch.cuda.is_available()
+    wa.engine_optics.optics_init(nbin, device=0)
+
+
+def _compare(got, ref, mask, rtol, atol=1e-30):
+    worst = 0.0
+    for n, g in got.items():
+        r = ref[n]
+        assert np.isfinite(g[mask]).all(), n
+        err = np.abs(g[mask] - r[mask]) - (rtol * np.abs(r[mask]) + atol)
+        assert (err <= 0).all(), (n, float(np.max(np.abs(g[mask] - r[mask]) / (np.abs(r[mask]) + 1e-300))))
+        worst = max(worst, float(np.max(np.abs(g[mask] - r[mask]) / (np.abs(r[mask]) + 1e-300))))
+        assert (g[~mask] == SENTINEL).all(), f"{n}: wrote outside the tile"
+    return worst
+
+
+@pytest.mark.parametrize("nbin,ni,nj,nk,opt", [(4, 9, 5, 40, 1), (8, 6, 4, 30, 1), (4, 5, 3, 20, 2), (8, 4, 3, 12, 4)])
+def test_optics_matches_oracle(hip_lib, wa, nbin, ni, nj, nk, opt):
+    _init(wa, nbin)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260300 + nbin + nk)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=nbin, seed=20260310 + nk)
+    got = run_hip_optics(wa, st, ms, aer_op_opt=opt)
+    ref = run_oracle_optics(wa, st, ms, mix=1 if opt in (2, 4) else 0)
+    mask = tile_mask(st, ms.alt.shape)
+    _compare(got, ref, mask, RTOL)
+    t2 = got["tauaer2"][mask]
+    assert (t2 >= 0).all() and t2.max() > 1e-4
+    w2 = got["waer2"][mask][t2 > 0]
+    assert (w2 > 0.2).all() and (w2 <= 1.0).all()
+
+
+def test_optics_tile_subset_and_host_mode(hip_lib, wa):
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(8, 6, 16, seed=20260320)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260321)
+    tile = dict(its=3, ite=7, jts=2, jte=5, kts=2, kte=15)
+    a = run_hip_optics(wa, st, ms, device=True, tile=tile)
+    b = run_hip_optics(wa, st, ms, device=False, tile=tile)
+    ref = run_oracle_optics(wa, st, ms, tile=tile)
+    mask = tile_mask(st, ms.alt.shape, tile)
+    _compare(a, ref, mask, RTOL)
+    for n in a:
+        np.testing.assert_array_equal(a[n], b[n], err_msg=n)
+
+
+def test_optics_real4_state(hip_lib, wa):
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(6, 4, 24, seed=20260330)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260331)
+    got = run_hip_optics(wa, st, ms, real_bytes=4)
+    # oracle on the same rounded inputs
+    ms32 = type(ms)(nbin=ms.nbin, chem=ms.chem.astype(np.float32).astype(np.float64),
+                    alt=ms.alt.astype(np.float32).astype(np.float64),
+                    dz8w=ms.dz8w.astype(np.float32).astype(np.float64), idx=ms.idx, names=ms.names)
+    ref = run_oracle_optics(wa, st, ms32)
+    mask = tile_mask(st, ms.alt.shape)
+    _compare(got, ref, mask, 3e-7, atol=1e-37)
+
+
+def test_optics_groups_and_refusals(hip_lib, wa):
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(3, 2, 8, seed=20260340)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260341)
+    only_lw = run_hip_optics(wa, st, ms, names=[f"tauaerlw{b}" for b in range(1, 17)])
+    full = run_hip_optics(wa, st, ms)
+    for n in only_lw:
+        np.testing.assert_array_equal(only_lw[n], full[n])
+    with pytest.raises(wa.engine.WrfFatal, match="complete or not at all"):
+        run_hip_optics(wa, st, ms, names=["tauaer1", "waer1", "gaer1"])
+    with pytest.raises(wa.engine.WrfFatal, match="shell_exact"):
+        run_hip_optics(wa, st, ms, aer_op_opt=5)
+
+
+def test_optics_feed_the_radiation(hip_lib, wa, sw_table_file, sw_oracle):
+    """End to end: MOSAIC tracers -> (tau, omega, g) -> RRTMG_SWRAD double call, HIP against oracle."""
+    from helpers import compare_sw, run_hip_swrad, run_oracle_swrad
+    _init(wa, 4)
+    wa.engine.rrtmg_swinit(sw_table_file, device=0)
+    st = wa.synth.make_wrf_state(6, 4, 40, seed=20260350)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260351)
+    got = run_hip_optics(wa, st, ms)
+    ref = run_oracle_optics(wa, st, ms)
+    for src, dst in (("1", "300"), ("2", "400"), ("3", "600"), ("4", "999")):
+        for stem in ("tauaer", "waer", "gaer"):
+            a = got[stem + src].copy()
+            a[a == SENTINEL] = 0.0
+            st.a3[stem + dst] = a
+    hip = run_hip_swrad(wa.engine, st)
+    for src, dst in (("1", "300"), ("2", "400"), ("3", "600"), ("4", "999")):
+        for stem in ("tauaer", "waer", "gaer"):
+            st.a3[stem + dst] = ref[stem + src]
+    orc = run_oracle_swrad(sw_oracle, st)
+    assert compare_sw(hip, orc, 1e-8, 1e-8) < 1e-7
+    forcing = hip["swuptcln"] - hip["swupt"]
+    assert np.abs(forcing).max() > 0.1

@@ -1,0 +1,141 @@
+"""CPU tests of the optical-averaging oracle.  The reference repository holds no arithmetic for this stage
+(parity unpinned), so the oracle's Mie core is pinned on published known answers and on an
+independent formulation instead."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def oo(oracle_mod):
+    from oracle import oracle_optics
+    return oracle_optics
+
+
+# (m, x, Qext) -- Wiscombe (1979) NCAR/TN-140 test cases as tabulated by Du (2004, Appl. Opt. 43, table 1);
+# our convention m = n + ik
+WISCOMBE = [
+    (0.75, 0.099, 7.417859e-06), (0.75, 0.101, 8.033538e-06), (0.75, 10.0, 2.232265), (0.75, 1000.0, 1.997908),
+    (1.33 + 1e-5j, 1.0, 9.395198e-02), (1.33 + 1e-5j, 100.0, 2.101321),
+    (1.5 + 1j, 0.055, 0.101491), (1.5 + 1j, 0.056, 0.103347), (1.5 + 1j, 1.0, 2.336321), (1.5 + 1j, 100.0, 2.097502),
+    (10 + 10j, 1.0, 2.532993), (10 + 10j, 100.0, 2.071124),
+]
+
+
+def test_mie_bohren_huffman_appendix_case(oo):
+    # Bohren & Huffman (1983) appendix A sample run: radius 0.525 um, wavelength 0.6328 um, m = 1.55
+    qext, qsca, g, qback = oo.mie(2.0 * np.pi * 0.525 / 0.6328, 1.55)
+    assert qext == pytest.approx(3.10543, abs=5e-6)
+    assert qsca == pytest.approx(3.10543, abs=5e-6)
+    assert qback == pytest.approx(2.92534, abs=5e-6)
+
+
+@pytest.mark.parametrize("m,x,qext_ref", WISCOMBE)
+def test_mie_wiscombe_cases(oo, m, x, qext_ref):
+    qext = oo.mie(x, m)[0]
+    assert qext == pytest.approx(qext_ref, rel=5e-6)   # tabulated to 6-7 significant digits
+
+
+def _mie_scipy(x, m, nmax):
+    """a_n, b_n straight from spherical Bessel functions (no recurrences of our own)."""
+    from scipy.special import spherical_jn, spherical_yn
+    n = np.arange(1, nmax + 1)
+    z = m * x
+    jx, djx = spherical_jn(n, x), spherical_jn(n, x, derivative=True)
+    yx, dyx = spherical_yn(n, x), spherical_yn(n, x, derivative=True)
+    jz, djz = spherical_jn(n, z), spherical_jn(n, z, derivative=True)
+    psi_x, dpsi_x = x * jx, jx + x * djx
+    xi_x, dxi_x = x * (jx + 1j * yx), (jx + 1j * yx) + x * (djx + 1j * dyx)
+    psi_z, dpsi_z = z * jz, jz + z * djz
+    a = (m * psi_z * dpsi_x - psi_x * dpsi_z) / (m * psi_z * dxi_x - xi_x * dpsi_z)
+    b = (psi_z * dpsi_x - m * psi_x * dpsi_z) / (psi_z * dxi_x - m * xi_x * dpsi_z)
+    qext = 2.0 / x**2 * np.sum((2 * n + 1) * (a + b).real)
+    qsca = 2.0 / x**2 * np.sum((2 * n + 1) * (abs(a) ** 2 + abs(b) ** 2))
+    gs = np.sum(n[:-1] * (n[:-1] + 2) / (n[:-1] + 1) * (a[:-1] * a[1:].conj() + b[:-1] * b[1:].conj()).real)
+    gs += np.sum((2 * n + 1) / (n * (n + 1)) * (a * b.conj()).real)
+    return qext, qsca, 4.0 / x**2 * gs / qsca
+
+
+@pytest.mark.parametrize("m,x", [(1.33 + 1e-5j, 100.0), (1.33 + 1e-5j, 10.0), (1.52 + 1e-9j, 3.3), (1.85 + 0.71j, 7.0),
+                                 (1.45 + 0.05j, 25.0), (1.7 + 0.55j, 0.02), (2.9 + 0.86j, 0.4), (1.33, 0.005)])
+def test_mie_against_scipy_formulation(oo, m, x):
+    nmax = int(x + 4.0 * x ** (1.0 / 3.0) + 2.0)
+    qext, qsca, g = _mie_scipy(x, complex(m), nmax)
+    o = oo.mie(x, m)
+    assert o[0] == pytest.approx(qext, rel=1e-9)
+    assert o[1] == pytest.approx(qsca, rel=1e-9)
+    assert o[2] == pytest.approx(g, rel=1e-7, abs=1e-9)   # g ~ x^2 for tiny x: both forms cancel
+
+
+def test_mie_limits(oo):
+    # Rayleigh limit: Qsca -> 8/3 x^4 |(m^2-1)/(m^2+2)|^2, Qabs -> 4x Im((m^2-1)/(m^2+2)), g -> 0
+    m, x = 1.5 + 0.1j, 1e-3
+    al = (m * m - 1) / (m * m + 2)
+    qext, qsca, g, _ = oo.mie(x, m)
+    assert qsca == pytest.approx(8.0 / 3.0 * x**4 * abs(al) ** 2, rel=1e-5)
+    assert qext - qsca == pytest.approx(4.0 * x * al.imag, rel=1e-5)
+    assert abs(g) < 1e-5
+    # extinction paradox: Qext -> 2 for large absorbing spheres; non-absorbing sphere: Qext == Qsca
+    assert oo.mie(220.0, 1.5 + 0.3j)[0] == pytest.approx(2.0, abs=0.08)
+    qe, qs, _, _ = oo.mie(12.0, 1.45)
+    assert qe == pytest.approx(qs, rel=1e-12)
+    for x in (0.05, 0.7, 4.0, 31.0, 180.0):
+        qe, qs, g, qb = oo.mie(x, 1.6 + 0.2j)
+        assert 0.0 < qs < qe and -1.0 < g < 1.0 and qb >= 0.0
+
+
+def _tables(oo, wa, nbin):
+    wl, ref, den = wa.engine_optics.table_info()
+    return oo.make_tables(nbin, 0.0390625, 10.0, wl, ref, den)
+
+
+def test_cell_properties(oo, wa):
+    tb = _tables(oo, wa, 4)
+    rng = np.random.default_rng(7)
+    mass = rng.uniform(0.0, 3.0, size=(4, 9))
+    num = np.array([4e9, 6e8, 2e7, 1e5])
+    sw, lw = oo.cell(tb, mass, num, alt=0.85, dz=120.0)
+    assert np.all(sw[:, 0] > 0) and np.all((sw[:, 1] > 0) & (sw[:, 1] <= 1)) and np.all(np.abs(sw[:, 2]) < 1)
+    assert np.all(lw[:, 0] >= 0)
+    # tau is extensive: doubling mass and number doubles tau and leaves omega, g unchanged
+    sw2, lw2 = oo.cell(tb, 2 * mass, 2 * num, alt=0.85, dz=120.0)
+    np.testing.assert_allclose(sw2[:, 0], 2 * sw[:, 0], rtol=1e-12)
+    np.testing.assert_allclose(sw2[:, 1:3], sw[:, 1:3], rtol=1e-12)
+    np.testing.assert_allclose(lw2[:, 0], 2 * lw[:, 0], rtol=1e-12)
+    # tau = ext * dz
+    np.testing.assert_allclose(sw[:, 0], sw[:, 3] * 1e-3 * 120.0, rtol=1e-13)
+    # no aerosol -> zeros
+    sw0, lw0 = oo.cell(tb, np.zeros((4, 9)), np.zeros(4), alt=0.85, dz=120.0)
+    assert not sw0.any() and not lw0.any()
+    # black carbon lowers the single-scattering albedo; Maxwell-Garnett differs from volume mixing only with BC
+    m_bc = mass.copy(); m_bc[:, 7] += 2.0
+    assert np.all(oo.cell(tb, m_bc, num, 0.85, 120.0)[0][:, 1] < sw[:, 1])
+    m_nobc = mass.copy(); m_nobc[:, 7] = 0.0
+    a, _ = oo.cell(tb, m_nobc, num, 0.85, 120.0, mix=0)
+    b, _ = oo.cell(tb, m_nobc, num, 0.85, 120.0, mix=1)
+    np.testing.assert_allclose(a, b, rtol=1e-12)
+    c, _ = oo.cell(tb, mass, num, 0.85, 120.0, mix=1)
+    assert np.max(np.abs(c[:, 1] - sw[:, 1])) > 1e-5
+    # number far outside the section is clipped: result depends on volume only
+    hi, _ = oo.cell(tb, mass, num * 1e6, 0.85, 120.0)
+    hi2, _ = oo.cell(tb, mass, num * 1e7, 0.85, 120.0)
+    np.testing.assert_allclose(hi, hi2, rtol=1e-12)
+
+
+def test_optics_abi_exports_and_refusal(wa):
+    import ctypes as C
+    lib = wa.engine.load_library()
+    for name in wa.engine_optics.EXPORTS_OPTICS:
+        assert hasattr(lib, name), name
+    wl, ref, den = wa.engine_optics.table_info()
+    assert wl[0] == 0.3 and wl[3] == 0.999 and wl[4] == pytest.approx(1e4 / 180.0)
+    assert ref.shape == (9, 20, 2) and np.all(ref[..., 0] > 1.0) and np.all(ref[..., 1] >= 0) and np.all(den > 0)
+    import torch
+    if not torch.cuda.is_available():
+        st = wa.synth.make_wrf_state(2, 2, 5, seed=3)
+        ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4)
+        dims = dict(ims=1, ime=2, jms=1, jme=2, kms=1, kme=6, its=1, ite=2, jts=1, jte=2, kts=1, kte=5)
+        out = {f"tauaerlw{b}": np.zeros_like(ms.alt) for b in range(1, 17)}
+        with pytest.raises(wa.engine.WrfFatal, match="rrtmg_hip_optics_init has not been called"):
+            wa.engine_optics.optical_averaging(chem=ms.chem, alt=ms.alt, dz8w=ms.dz8w, idx=ms.idx, **dims, **out)
+        with pytest.raises(wa.engine.WrfFatal, match="no HIP device"):
+            wa.engine_optics.optics_init(4)

@@ -1,0 +1,198 @@
+// C ABI of the aerosol optical-averaging stage (include/rrtmg_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmg_hip.h"
+#include "optics_common.h"
+#include "optics_kernel.h"
+
+namespace rrtmg {
+namespace {
+
+struct OpticsState {
+    bool ready = false;
+    int device = 0;
+    OpticsTables tab{};
+};
+OpticsState g_opt;
+std::mutex g_opt_mutex;
+
+int failo(char *err, const std::string &msg)
+{
+    if (err) {
+        std::strncpy(err, msg.c_str(), RRTMG_HIP_ERRLEN - 1);
+        err[RRTMG_HIP_ERRLEN - 1] = 0;
+    }
+    return 1;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return failo(err, std::string("rrtmg_hip: ") + #expr + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int fill_tables(OpticsTables &t, int nbin, double dlo_um, double dhi_um, const double *refindex, const double *density,
+                std::string &msg)
+{
+    if (nbin < 1 || nbin > OPT_MAXBIN) { msg = "rrtmg_hip_optics_init: nbin must be 1..8"; return 1; }
+    if (!(dlo_um > 0. && dhi_um > dlo_um)) { msg = "rrtmg_hip_optics_init: need 0 < dlo_um < dhi_um"; return 1; }
+    optics_default_tables(t, nbin, dlo_um, dhi_um);
+    if (refindex)
+        for (int s = 0; s < OPT_NSPEC; ++s)
+            for (int w = 0; w < OPT_NWAVE; ++w) {
+                const double re = refindex[(s * OPT_NWAVE + w) * 2], im = refindex[(s * OPT_NWAVE + w) * 2 + 1];
+                if (!(re > 0.) || im < 0.) { msg = "rrtmg_hip_optics_init: refractive index needs real > 0, imaginary >= 0"; return 1; }
+                t.refr[s][w] = re; t.refi[s][w] = im;
+            }
+    if (density)
+        for (int s = 0; s < OPT_NSPEC; ++s) {
+            if (!(density[s] > 0.)) { msg = "rrtmg_hip_optics_init: density must be positive"; return 1; }
+            t.dens[s] = density[s];
+        }
+    return 0;
+}
+
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
+    hipError_t put(const void *host, size_t bytes, hipStream_t s, void **dev)
+    {
+        *dev = nullptr;
+        if (!host) return hipSuccess;
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, bytes);
+        if (e != hipSuccess) return e;
+        bufs.push_back(d);
+        *dev = d;
+        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
+    }
+};
+
+}  // namespace
+}  // namespace rrtmg
+
+using namespace rrtmg;
+
+extern "C" int rrtmg_hip_optics_init(int nbin, double dlo_um, double dhi_um, const double *refindex,
+                                     const double *density, int device, char *err)
+{
+    std::lock_guard<std::mutex> lock(g_opt_mutex);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return failo(err, "rrtmg_hip_optics_init: no HIP device visible (the engine has no CPU path)");
+    std::string msg;
+    OpticsTables t{};
+    if (fill_tables(t, nbin, dlo_um, dhi_um, refindex, density, msg)) return failo(err, msg);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(optics_upload_tables(t));
+    g_opt.tab = t;
+    g_opt.device = device;
+    g_opt.ready = true;
+    return 0;
+}
+
+extern "C" int rrtmg_hip_optics_table_info(double *wavelength_um20, double *refindex_9x20x2, double *density9)
+{
+    OpticsTables t{};
+    if (g_opt.ready) t = g_opt.tab;
+    else optics_default_tables(t, 4, 0.0390625, 10.0);
+    if (wavelength_um20) std::memcpy(wavelength_um20, t.wavelength_um, sizeof t.wavelength_um);
+    if (refindex_9x20x2)
+        for (int s = 0; s < OPT_NSPEC; ++s)
+            for (int w = 0; w < OPT_NWAVE; ++w) {
+                refindex_9x20x2[(s * OPT_NWAVE + w) * 2] = t.refr[s][w];
+                refindex_9x20x2[(s * OPT_NWAVE + w) * 2 + 1] = t.refi[s][w];
+            }
+    if (density9) std::memcpy(density9, t.dens, sizeof t.dens);
+    return 0;
+}
+
+extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char *err)
+{
+    if (!g_opt.ready) return failo(err, "rrtmg_hip_optical_averaging: rrtmg_hip_optics_init has not been called");
+    if (a->real_bytes != 4 && a->real_bytes != 8) return failo(err, "rrtmg_hip_optical_averaging: real_bytes must be 4 or 8");
+    if (a->aer_op_opt < 1 || a->aer_op_opt > 4)
+        return failo(err, "rrtmg_hip_optical_averaging: aer_op_opt must be 1..4 (5 = shell_exact is not implemented)");
+    const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
+    const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk_t = a->kte - a->kts + 1;
+    if (ni_t <= 0 || nj_t <= 0 || nk_t <= 0 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
+        a->jte > a->jme || a->kts < a->kms || a->kte > a->kme)
+        return failo(err, "rrtmg_hip_optical_averaging: inconsistent tile / memory dimensions");
+    if (a->num_chem < 1) return failo(err, "rrtmg_hip_optical_averaging: num_chem must be positive");
+    if (!a->chem || !a->alt || !a->dz8w) return failo(err, "rrtmg_hip_optical_averaging: a required input array is NULL");
+    const int nbin = g_opt.tab.nbin;
+    OpticsKernelArgs k{};
+    for (int b = 0; b < OPT_MAXBIN; ++b)
+        for (int s = 0; s < OPT_NSLOT; ++s) {
+            const int id = b < nbin ? a->idx[b][s] : 0;
+            if (id < 0 || id > a->num_chem) return failo(err, "rrtmg_hip_optical_averaging: species index outside 1..num_chem");
+            k.idx[b][s] = id - 1;
+        }
+    auto group = [](void *const *p, int n) {
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) cnt += p[i] != nullptr;
+        return cnt == 0 ? 0 : (cnt == n ? 1 : -1);
+    };
+    void *const sw3[12] = {a->tauaer[0], a->tauaer[1], a->tauaer[2], a->tauaer[3], a->waer[0], a->waer[1],
+                           a->waer[2], a->waer[3], a->gaer[0], a->gaer[1], a->gaer[2], a->gaer[3]};
+    if (group(sw3, 12) < 0 || group(a->extaer, 4) < 0 || group(a->bscoef, 4) < 0 || group(a->tauaerlw, 16) < 0 ||
+        group(a->extaerlw, 16) < 0)
+        return failo(err, "rrtmg_hip_optical_averaging: an output group (tauaer/waer/gaer, extaer, bscoef, tauaerlw, "
+                          "extaerlw) must be passed complete or not at all");
+    HIPCHK(hipSetDevice(g_opt.device));
+    hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
+    k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
+    k.i0 = a->its - a->ims; k.k0 = a->kts - a->kms; k.j0 = a->jts - a->jms;
+    k.ni_t = ni_t; k.nk_t = nk_t; k.nj_t = nj_t;
+    k.real4 = a->real_bytes == 4;
+    k.mix = (a->aer_op_opt == 2 || a->aer_op_opt == 4) ? 1 : 0;
+    k.nbin = nbin;
+    const size_t n3 = (size_t)ni_m * nk_m * nj_m * a->real_bytes;
+    Staging stg;
+    struct OutCopy { void *host; void *dev; };
+    std::vector<OutCopy> outs;
+    if (a->mem == 1) {
+        k.chem = a->chem; k.alt = a->alt; k.dz8w = a->dz8w;
+        for (int w = 0; w < OPT_NSW; ++w) {
+            k.tauaer[w] = a->tauaer[w]; k.waer[w] = a->waer[w]; k.gaer[w] = a->gaer[w];
+            k.extaer[w] = a->extaer[w]; k.bscoef[w] = a->bscoef[w];
+        }
+        for (int b = 0; b < OPT_NLW; ++b) { k.tauaerlw[b] = a->tauaerlw[b]; k.extaerlw[b] = a->extaerlw[b]; }
+    } else {
+        void *d = nullptr;
+        HIPCHK(stg.put(a->chem, n3 * (size_t)a->num_chem, stream, &d)); k.chem = d;
+        HIPCHK(stg.put(a->alt, n3, stream, &d)); k.alt = d;
+        HIPCHK(stg.put(a->dz8w, n3, stream, &d)); k.dz8w = d;
+        auto out = [&](void *host, void **dev) -> hipError_t {
+            hipError_t e = stg.put(host, n3, stream, dev);   // upload first: only the tile is rewritten
+            if (e == hipSuccess && host) outs.push_back({host, *dev});
+            return e;
+        };
+        for (int w = 0; w < OPT_NSW; ++w) {
+            HIPCHK(out(a->tauaer[w], &k.tauaer[w])); HIPCHK(out(a->waer[w], &k.waer[w])); HIPCHK(out(a->gaer[w], &k.gaer[w]));
+            HIPCHK(out(a->extaer[w], &k.extaer[w])); HIPCHK(out(a->bscoef[w], &k.bscoef[w]));
+        }
+        for (int b = 0; b < OPT_NLW; ++b) {
+            HIPCHK(out(a->tauaerlw[b], &k.tauaerlw[b])); HIPCHK(out(a->extaerlw[b], &k.extaerlw[b]));
+        }
+    }
+    HIPCHK(optics_launch(k, stream));
+    if (a->mem != 1) {
+        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, n3, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+    }
+    return 0;
+}
+
+extern "C" int rrtmg_hip_optics_finalize(void)
+{
+    std::lock_guard<std::mutex> lock(g_opt_mutex);
+    g_opt.ready = false;
+    return 0;
+}

@@ -1,0 +1,12 @@
+// Launch interface of the aerosol optical-averaging kernel (optics_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "optics_common.h"
+
+namespace rrtmg {
+
+hipError_t optics_upload_tables(const OpticsTables &t);
+hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream);
+
+}  // namespace rrtmg

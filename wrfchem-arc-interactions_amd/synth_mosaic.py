@@ -1,0 +1,105 @@
+"""Synthetic MOSAIC sectional aerosol for the optical-averaging stage (BASELINE configs[2], [3]: 4 and 8 bins).
+
+Species per bin follow the reference's registry (Registry/registry.chem:2325-2447, package lists :3823-3826):
+so4, no3, cl, nh4, na, oin, oc, bc, hysw, water (ug/kg-dryair) and num (#/kg-dryair).  The tracer array is laid
+out like WRF-Chem's ``chem(ims:ime, kms:kme, jms:jme, num_chem)``: numpy shape (num_chem, nj, nk_mem, ni).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .engine_optics import MOSAIC_DHI_UM, MOSAIC_DLO_UM, SPECIES
+
+REGISTRY_ORDER = ["so4", "no3", "cl", "nh4", "na", "oin", "oc", "bc", "hysw", "water", "num"]
+DENSITY = dict(so4=1.8, no3=1.8, cl=2.2, nh4=1.8, na=2.2, oin=2.6, oc=1.0, bc=1.7)
+N_GAS = 5   # a few leading gas-phase tracers so that aerosol indices do not start at 1
+
+
+@dataclass
+class MosaicState:
+    nbin: int
+    chem: np.ndarray      # (num_chem, nj, nk_mem, ni) float64
+    alt: np.ndarray       # (nj, nk_mem, ni) inverse dry-air density, m3/kg
+    dz8w: np.ndarray      # (nj, nk_mem, ni) m
+    idx: np.ndarray       # [nbin][10] 1-based species numbers in engine_optics.SPECIES order
+    names: list
+
+
+def section_bounds(nbin, dlo=MOSAIC_DLO_UM, dhi=MOSAIC_DHI_UM):
+    edges = dlo * (dhi / dlo) ** (np.arange(nbin + 1) / nbin)
+    edges[-1] = dhi
+    return edges[:-1], edges[1:]
+
+
+def make_mosaic_state(st, nbin=4, seed=20260005, empty_fraction=0.02) -> MosaicState:
+    """st: synth.WrfState (uses rho3d, dz8w).  Mass loading decays with height (scale 2 km); a fine and a coarse
+    log-normal mode are split over the sections; number follows from the section's mass and a mean diameter that
+    sometimes lies outside the section (to exercise the clipping rule); water from a per-cell growth factor."""
+    rng = np.random.default_rng(seed)
+    nj, kme, ni = st.a3["rho3d"].shape
+    nk = st.nk
+    rho = st.a3["rho3d"][:, :nk, :]
+    dz = st.a3["dz8w"][:, :nk, :]
+    z = np.cumsum(dz, axis=1) - 0.5 * dz
+    shp2, shp3 = (nj, ni), (nj, nk, ni)
+    lo, hi = section_bounds(nbin)
+    dmid = np.sqrt(lo * hi)
+    # column loadings (ug/m3 at the surface) of a fine and a coarse mode
+    fine0 = 10.0 ** rng.uniform(np.log10(2.0), np.log10(60.0), size=shp2)
+    coarse0 = 10.0 ** rng.uniform(np.log10(1.0), np.log10(40.0), size=shp2)
+    prof = np.exp(-z / 2000.0)
+
+    def mode_split(dg_um, sg):
+        # fraction of a log-normal volume distribution falling into each section
+        from math import erf, log, sqrt
+        cdf = lambda d: 0.5 * (1.0 + erf(log(d / dg_um) / (sqrt(2.0) * log(sg))))
+        f = np.array([cdf(h) - cdf(l) for l, h in zip(lo, hi)])
+        return f / f.sum()
+
+    f_fine, f_coarse = mode_split(0.30, 1.8), mode_split(3.0, 2.0)
+    names = [f"gas{i + 1}" for i in range(N_GAS)]
+    for b in range(nbin):
+        names += [f"{s}_a{b + 1:02d}" for s in REGISTRY_ORDER]
+    num_chem = len(names)
+    chem = np.zeros((num_chem, nj, kme, ni))
+    chem[:N_GAS, :, :nk, :] = rng.uniform(0.0, 1.0, size=(N_GAS,) + shp3)
+    alt = np.zeros((nj, kme, ni))
+    alt[:, :nk, :] = 1.0 / rho
+    alt[:, nk:, :] = 1.0
+    # composition of the two modes per column (mass fractions of the dry species)
+    comp_f = rng.dirichlet([4.0, 2.0, 0.3, 2.0, 0.3, 0.8, 3.0, 0.6], size=shp2)    # so4 no3 cl nh4 na oin oc bc
+    comp_c = rng.dirichlet([0.5, 0.5, 2.0, 0.2, 2.0, 6.0, 0.5, 0.05], size=shp2)
+    growth = rng.uniform(0.0, 2.5, size=shp3)          # water mass / soluble dry mass
+    idx = np.zeros((nbin, len(SPECIES)), dtype=np.int64)
+    for b in range(nbin):
+        base = N_GAS + b * len(REGISTRY_ORDER)
+        for s, sp in enumerate(SPECIES):
+            idx[b, s] = base + REGISTRY_ORDER.index(sp) + 1
+        m_f = fine0[:, None, :] * prof * f_fine[b]       # ug/m3
+        m_c = coarse0[:, None, :] * prof * f_coarse[b]
+        dry = np.zeros(shp3)
+        vol = np.zeros(shp3)                             # 1e-6 cm3 per m3 of air
+        soluble = np.zeros(shp3)
+        for s, sp in enumerate(["so4", "no3", "cl", "nh4", "na", "oin", "oc", "bc"]):
+            m = m_f * comp_f[:, None, :, s] + m_c * comp_c[:, None, :, s]
+            chem[base + REGISTRY_ORDER.index(sp), :, :nk, :] = m / rho     # ug/kg
+            dry += m
+            vol += m / DENSITY[sp]
+            if sp in ("so4", "no3", "cl", "nh4", "na"):
+                soluble += m
+        water = growth * soluble
+        chem[base + REGISTRY_ORDER.index("water"), :, :nk, :] = water / rho
+        chem[base + REGISTRY_ORDER.index("hysw"), :, :nk, :] = 0.3 * water / rho   # carried, not used by the optics
+        # number from the section's dry volume and a mean diameter around the section centre
+        d_um = dmid[b] * rng.uniform(0.45, 2.2, size=shp3)
+        vpart = np.pi / 6.0 * (d_um * 1.0e-4) ** 3      # cm3
+        number = vol * 1.0e-6 / vpart                    # per m3
+        chem[base + REGISTRY_ORDER.index("num"), :, :nk, :] = number / rho
+        # some empty sections / cells
+        empty = rng.uniform(size=shp3) < empty_fraction
+        for sp in REGISTRY_ORDER:
+            c = chem[base + REGISTRY_ORDER.index(sp), :, :nk, :]
+            c[empty] = 0.0
+    return MosaicState(nbin=nbin, chem=chem, alt=alt, dz8w=st.a3["dz8w"].copy(), idx=idx, names=names)
