@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: aerosol + clean-sky RRTMG SW+LW double call on MI355X.
 
-A "step" is one pass of the HIP path (RRTMG_SWRAD + RRTMG_LWRAD, each with its
-aerosol and clean-sky call) over one batch of synthetic WRF columns resident in
-HBM.  Workload at N=1: 200x200x40 synthetic columns, fp64 (BASELINE.json
-configs[2] without the optical-averaging stage: aerosol optics are supplied in
-the WRF-Chem compact form, 12 SW + 16 LW arrays).  `--mode sw` runs configs[1]
-(SW double call only).  With --gpus N each rank owns its own 200x200 slab of
+A "step" is one pass of the HIP path -- MOSAIC 4-bin optical averaging, then
+RRTMG_SWRAD + RRTMG_LWRAD, each with its aerosol and clean-sky call -- over one
+batch of synthetic WRF columns resident in HBM.  Workload at N=1: 200x200x40
+synthetic columns, fp64 = BASELINE.json configs[2] (`--mode full`, default).
+`--mode swlw` skips the optics stage (aerosol optics supplied in the WRF-Chem
+compact form, 12 SW + 16 LW arrays); `--mode sw` runs configs[1] (SW double
+call only).  With --gpus N each rank owns its own 200x200 slab of
 (i,j) columns (weak scaling, no data-path collective); the only exchange is an
 all-reduce of the per-tile flux sums (32 doubles) over RCCL.
 
@@ -36,7 +37,27 @@ def algorithmic_bytes_per_column(nk, mode, real_bytes=8):
         writes rthratenlw (K) and 15 two-dimensional fields."""
     sw = (4 + 12 + 1) * nk + 2 * (nk + 1) + 3 + 22
     lw = (4 + 16 + 1) * nk + 2 * (nk + 1) + 2 + 15
-    return (sw + (lw if mode == "swlw" else 0)) * real_bytes, sw * real_bytes, lw * real_bytes
+    return (sw + (lw if mode != "sw" else 0)) * real_bytes, sw * real_bytes, lw * real_bytes
+
+
+def optics_bytes_per_column(nk, nbin, real_bytes=8):
+    """Optical averaging: reads 10 tracers per section + alt + dz8w per cell, writes tau/omega/g at 4 wavelengths
+    and 16 longwave optical depths per cell."""
+    return (10 * nbin + 2 + 12 + 16) * nk * real_bytes
+
+
+def cpu_optics_seconds_per_column(wa, st, ms, ncol_sample):
+    """The optical-averaging stage has no reference arithmetic: timed from the C port, one thread."""
+    from oracle import oracle_optics as oo
+    from tests.helpers_optics import oracle_tables
+    lib = oo._lib()
+    lib.omp_set_num_threads(1)
+    nj = max(1, min(st.nj, ncol_sample // st.ni))
+    d = dict(ims=1, ime=st.ni, jms=1, jme=st.nj, kms=1, kme=st.nk + 1, its=1, ite=st.ni, jts=1, jte=nj, kts=1, kte=st.nk)
+    t0 = time.perf_counter()
+    oo.tile(oracle_tables(wa, ms.nbin), ms.chem, ms.alt, ms.dz8w, ms.idx, d)
+    secs = time.perf_counter() - t0
+    return secs / (nj * st.ni), nj * st.ni
 
 
 def cpu_baseline(tab_sw, tab_lw, st, ncol_sample, mode):
@@ -51,15 +72,16 @@ def cpu_baseline(tab_sw, tab_lw, st, ncol_sample, mode):
         _, so = run_ref_sw(tab_sw, cols, clean=1)
         secs_sw = float(so.split("seconds=")[1].split()[0])
         secs_lw = 0.0
-        if mode == "swlw":
+        if mode != "sw":
             lcols = {k: v[:ncol_sample] for k, v in lw_columns_from_state(st).items()}
             _, lo = run_ref_lw(tab_lw, lcols, clean=1)
             secs_lw = float(lo.split("seconds=")[1].split()[0])
         secs = secs_sw + secs_lw
         return {"value": ncol_sample / secs, "unit": "columns/s", "cores": 1, "kind": "reference",
                 "sample": f"{ncol_sample} columns of the bench workload through the reference rrtmg_sw"
-                          f"{' + rrtmg_lw' if mode == 'swlw' else ''} (flang -O2, fp64, 1 core): "
-                          f"SW {secs_sw:.2f} s, LW {secs_lw:.2f} s solver time"}
+                          f"{' + rrtmg_lw' if mode != 'sw' else ''} (flang -O2, fp64, 1 core): "
+                          f"SW {secs_sw:.2f} s, LW {secs_lw:.2f} s solver time",
+                "seconds_per_column": secs / ncol_sample}
     from oracle import oracle as orc
     o = orc.SwOracle(tab_sw)
     n = min(ncol_sample, 256)
@@ -78,7 +100,9 @@ def main():
     ap.add_argument("--ni", type=int, default=200)
     ap.add_argument("--nj", type=int, default=200)
     ap.add_argument("--nk", type=int, default=40)
-    ap.add_argument("--mode", choices=["swlw", "sw"], default="swlw")
+    ap.add_argument("--mode", choices=["full", "swlw", "sw"], default="full")
+    ap.add_argument("--nbin", type=int, default=4, help="MOSAIC sections of the optics stage (4 or 8)")
+    ap.add_argument("--cpu-optics-sample", type=int, default=400)
     ap.add_argument("--night", type=float, default=0.0, help="fraction of night columns (0 for kernel timing)")
     ap.add_argument("--cpu-sample", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -111,7 +135,10 @@ def main():
     wa.synth.write_sw_data(tab, seed=20260001, real_bytes=8)
     wa.synth.write_lw_data(tabl, seed=20260003, real_bytes=8)
     eng.rrtmg_swinit(tab, 8, device=local_rank)
-    do_lw = args.mode == "swlw"
+    do_lw = args.mode != "sw"
+    do_opt = args.mode == "full"
+    if do_opt:
+        wa.engine_optics.optics_init(args.nbin, device=local_rank)
     if do_lw:
         engl.rrtmg_lwinit(P_TOP, tabl, kme=args.nk + 1, device=local_rank)
 
@@ -132,6 +159,19 @@ def main():
     lw_in.update({n: dev(st.a3[n]) for n in hl.AER})
     lw_out = {"rthratenlw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
     lw_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in hl.OUT2})
+    ms = None
+    if do_opt:
+        # MOSAIC tracers -> the aerosol inputs of the two radiation calls (written in place every step)
+        ms = wa.synth_mosaic.make_mosaic_state(st, nbin=args.nbin, seed=20260005 + 1000 * rank)
+        opt_in = dict(chem=dev(ms.chem), alt=dev(ms.alt), dz8w=dev(ms.dz8w))
+        opt_out = {}
+        for w, nm in enumerate(("300", "400", "600", "999"), start=1):
+            for stem in ("tauaer", "waer", "gaer"):
+                opt_out[f"{stem}{w}"] = sw_in[stem + nm]
+        for b in range(1, 17):
+            opt_out[f"tauaerlw{b}"] = lw_in[f"tauaerlw{b}"]
+        for t in opt_out.values():
+            t.zero_()
     sums = torch.zeros(32, dtype=torch.float64, device="cuda")
     sw12 = ["swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
             "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln"]
@@ -151,7 +191,14 @@ def main():
             wa.tiles.tile_sums_device(lw_out, lw12, d, sums[16:])
         wa.tiles.allreduce_sums(sums)
 
+    def opt_call():
+        wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **opt_out)
+
     def step(ev=None):
+        if ev:
+            ev[3].record()
+        if do_opt:
+            opt_call()
         if ev:
             ev[0].record()
         sw_call()
@@ -176,7 +223,7 @@ def main():
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         step(ev)
         events.append(ev)
     torch.cuda.synchronize()
@@ -193,6 +240,7 @@ def main():
     elapsed = float(tmax.item())
     sw_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))   # HIP events on the launch stream
     lw_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if do_lw else 0.0
+    opt_ms = float(np.mean([e[3].elapsed_time(e[0]) for e in events])) if do_opt else 0.0
 
     if rank == 0:
         value = world * ncol * args.steps / elapsed
@@ -206,17 +254,22 @@ def main():
             except Exception:
                 traffic = None
         what = "SW+LW" if do_lw else "RRTMG-SW"
+        if do_opt:
+            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic columns per GPU, MOSAIC {args.nbin}-bin optical "
+                        "averaging + SW+LW aerosol+clean double-call, fp64, cloud-free (BASELINE configs[2])")
+        elif do_lw:
+            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, SW+LW aerosol+clean "
+                        "double-call, fp64, cloud-free; aerosol optics supplied in the WRF-Chem compact form "
+                        "(BASELINE configs[2] without the optical-averaging stage)")
+        else:
+            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, RRTMG-SW aerosol+clean "
+                        "double-call only, fp64 (BASELINE configs[1])")
         line = {
             "metric": "columns/sec, aerosol+clean RRTMG SW+LW double-call; flux RMSE vs reference",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, {what} "
-                                   "aerosol+clean double-call, fp64, cloud-free; aerosol optics supplied in the "
-                                   "WRF-Chem compact form (BASELINE configs[2] without the optical-averaging stage)"
-                                   if do_lw else
-                                   f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, RRTMG-SW "
-                                   "aerosol+clean double-call only, fp64 (BASELINE configs[1])",
+            "config": {"workload": workload,
                        "columns_per_gpu": ncol, "layers": args.nk, "night_fraction": args.night,
                        "parallelism": f"(i,j) slabs over {world} GPU(s), RCCL all-reduce of 32 flux sums"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,12 +277,25 @@ def main():
                          "kernel": "sw_column_kernel", "kernel_ms": sw_ms,
                          "algorithmic_bytes_per_column": bpc_sw,
                          "lw_kernel_ms": lw_ms, "lw_algorithmic_bytes_per_column": bpc_lw if do_lw else 0,
-                         "step_algorithmic_GBs": ncol * bpc / ((sw_ms + lw_ms) * 1e-3) / 1e9,
+                         "optics_kernel_ms": opt_ms,
+                         "optics_algorithmic_bytes_per_column": optics_bytes_per_column(args.nk, args.nbin) if do_opt else 0,
+                         "step_algorithmic_GBs": ncol * (bpc + (optics_bytes_per_column(args.nk, args.nbin) if do_opt else 0))
+                         / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
                          "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
         }
         if world == 1 and not args.no_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(tab, tabl, st, min(args.cpu_sample, ncol), args.mode)
+                if do_opt:   # the CPU leg runs the radiation on the optics the device produced
+                    for n, t in list(sw_in.items()) + list(lw_in.items()):
+                        if n.startswith(("tauaer", "waer", "gaer")):
+                            st.a3[n] = t.cpu().numpy()
+                cb = cpu_baseline(tab, tabl, st, min(args.cpu_sample, ncol), args.mode)
+                if do_opt and cb.get("seconds_per_column"):
+                    spc_opt, n_opt = cpu_optics_seconds_per_column(wa, st, ms, min(args.cpu_optics_sample, ncol))
+                    cb["value"] = 1.0 / (cb["seconds_per_column"] + spc_opt)
+                    cb["sample"] += (f"; optical averaging: {n_opt} columns through the C port of the engine's own "
+                                     f"specification (no reference arithmetic exists), {spc_opt * n_opt:.2f} s, 1 thread")
+                line["cpu_baseline"] = cb
             except Exception as e:   # never let the baseline leg kill the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "reference",
                                         "sample": f"failed: {e!r}"}

@@ -37,7 +37,7 @@ void optics_oracle_mie(double x, double mre, double mim, double *out4)
     const double xstop = x + 4. * cbrt(x) + 2.;
     const int nstop = (int)xstop;
     const double base = fmax(xstop, cabs(y));
-    int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 15;
+    int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
     if (nmx > 4095) nmx = 4095;
     D[nmx] = 0.;
     for (int n = nmx; n >= 2; --n) {

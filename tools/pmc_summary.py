@@ -34,7 +34,7 @@ def main():
                 k = r["Kernel_Name"]
                 if "rrtmg::" not in k:
                     continue
-                k = k.split("(")[0]
+                k = k.replace("(anonymous namespace)::", "").split("(")[0]
                 sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnts[k][r["Counter_Name"]] += 1
                 meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],

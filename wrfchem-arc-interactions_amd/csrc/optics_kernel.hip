@@ -68,69 +68,107 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
 }
 
 // Mie efficiencies of a homogeneous sphere, size parameter x, refractive index m = n + ik (k >= 0).
-__device__ void mie_sphere(double x, cplx m, double &qext, double &qsca, double &gasy, double &qback)
+//
+// The a_n, b_n series runs upward in n, the logarithmic derivative D_n(mx) is only stable downward.  A per-lane
+// array of D_n (4 KB) lives in scratch memory and made the first version of this kernel HBM-bound (85 GB of
+// scratch traffic per 1.6 M cells).  Here the downward pass keeps only every OPT_MB-th D_n in LDS
+// (ck[j][thread]); the upward pass rebuilds each block of OPT_MB values from its checkpoint in registers
+// (statically indexed) and consumes them.  D_n is recomputed once; nothing goes to scratch.
+constexpr int OPT_MB = 16;
+constexpr int OPT_NCK = (OPT_NMIE + OPT_MB - 1) / OPT_MB;   // 16 checkpoints cover nstop <= 256
+
+struct MieAcc {
+    double psi0, psi1, chi0, chi1, qs, qe, gs, sgn;
+    cplx an1, bn1, xb;
+};
+
+__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
 {
-    double dre[OPT_NMIE], dim[OPT_NMIE];   // logarithmic derivative D_n(mx), n = 1..nstop
+    const double en = (double)n;
+    const double psi = (2. * en - 1.) * xinv * A.psi1 - A.psi0;
+    const double chi = (2. * en - 1.) * xinv * A.chi1 - A.chi0;
+    const cplx xi = {psi, -chi}, xi1 = {A.psi1, -A.chi1};
+    cplx t = cmul(D, minv);
+    t.re += en * xinv;
+    const cplx an = cdiv(cplx{t.re * psi - A.psi1, t.im * psi}, csub(cmul(t, xi), xi1));
+    t = cmul(m, D);
+    t.re += en * xinv;
+    const cplx bn = cdiv(cplx{t.re * psi - A.psi1, t.im * psi}, csub(cmul(t, xi), xi1));
+    const double w2 = 2. * en + 1.;
+    A.qs += w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
+    A.qe += w2 * (an.re + bn.re);
+    A.gs += (w2 * frcp(en * (en + 1.))) * (an.re * bn.re + an.im * bn.im);
+    if (n > 1)
+        A.gs += ((en - 1.) * (en + 1.) * frcp(en)) *
+                (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+    A.xb.re += A.sgn * w2 * (an.re - bn.re);
+    A.xb.im += A.sgn * w2 * (an.im - bn.im);
+    A.sgn = -A.sgn;
+    A.psi0 = A.psi1; A.psi1 = psi; A.chi0 = A.chi1; A.chi1 = chi;
+    A.an1 = an; A.bn1 = bn;
+}
+
+__device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS [OPT_NCK][OPT_THREADS], this thread's column */,
+                           double &qext, double &qsca, double &gasy, double &qback)
+{
     const cplx y = {x * m.re, x * m.im};
     const double ymod = sqrt(y.re * y.re + y.im * y.im);
     const double xstop = x + 4. * cbrt(x) + 2.;
     const int nstop = (int)xstop;
+    const int nck = (nstop + OPT_MB - 1) / OPT_MB;   // checkpoints D_{MB j}, j = 1..nck (MB*nck <= nstop + 15 < nmx)
     // BHMIE starts at max(xstop,|mx|)+15; that leaves D_n wrong by 1e-4..1 once |mx| > 10, because the start
     // value only decays where n exceeds |mx| by several |mx|^(1/3).  With the extra 8|mx|^(1/3) terms D_n is
     // converged to the last bit.
     const double base = fmax(xstop, ymod);
-    const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 15;
+    const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
     const cplx yinv = crecip(y);
     cplx d = {0., 0.};
+    const int ntop = nck * OPT_MB;
     for (int n = nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y)
         const cplx ny = {(double)n * yinv.re, (double)n * yinv.im};
         d = csub(ny, crecip(cadd(d, ny)));
-        if (n - 1 <= nstop) { dre[n - 1] = d.re; dim[n - 1] = d.im; }
+        const int n1 = n - 1;
+        if (n1 <= ntop && (n1 & (OPT_MB - 1)) == 0) ck[(size_t)(n1 / OPT_MB - 1) * OPT_THREADS] = make_double2(d.re, d.im);
+        if (n1 <= OPT_MB) break;       // the lowest block is rebuilt from its checkpoint below
     }
-    double psi0 = cos(x), psi1 = sin(x);
-    double chi0 = -psi1, chi1 = psi0;
+    MieAcc A;
+    sincos(x, &A.psi1, &A.psi0);
+    A.chi0 = -A.psi1; A.chi1 = A.psi0;
+    A.qs = 0.; A.qe = 0.; A.gs = 0.; A.sgn = -1.;
+    A.an1 = {0., 0.}; A.bn1 = {0., 0.}; A.xb = {0., 0.};
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
-    cplx an1 = {0., 0.}, bn1 = {0., 0.}, xb = {0., 0.};
-    double qs = 0., qe = 0., gs = 0., sgn = -1.;
-    for (int n = 1; n <= nstop; ++n) {
-        const double en = (double)n;
-        const double psi = (2. * en - 1.) * xinv * psi1 - psi0;
-        const double chi = (2. * en - 1.) * xinv * chi1 - chi0;
-        const cplx xi = {psi, -chi}, xi1 = {psi1, -chi1};
-        const cplx D = {dre[n], dim[n]};
-        cplx t = cmul(D, minv);
-        t.re += en * xinv;
-        const cplx an = cdiv(cplx{t.re * psi - psi1, t.im * psi}, csub(cmul(t, xi), xi1));
-        t = cmul(m, D);
-        t.re += en * xinv;
-        const cplx bn = cdiv(cplx{t.re * psi - psi1, t.im * psi}, csub(cmul(t, xi), xi1));
-        const double w2 = 2. * en + 1.;
-        qs += w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
-        qe += w2 * (an.re + bn.re);
-        gs += (w2 * frcp(en * (en + 1.))) * (an.re * bn.re + an.im * bn.im);
-        if (n > 1)
-            gs += ((en - 1.) * (en + 1.) * frcp(en)) *
-                  (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
-        xb.re += sgn * w2 * (an.re - bn.re);
-        xb.im += sgn * w2 * (an.im - bn.im);
-        sgn = -sgn;
-        psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
-        an1 = an; bn1 = bn;
+    for (int j = 0; j < nck; ++j) {
+        cplx dd[OPT_MB];
+        const double2 c = ck[(size_t)j * OPT_THREADS];
+        dd[OPT_MB - 1] = {c.x, c.y};                 // D_{MB (j+1)}
+#pragma unroll
+        for (int i = OPT_MB - 1; i >= 1; --i) {      // dd[i] = D_n with n = MB j + i + 1
+            const double en = (double)(j * OPT_MB + i + 1);
+            const cplx ny = {en * yinv.re, en * yinv.im};
+            dd[i - 1] = csub(ny, crecip(cadd(dd[i], ny)));
+        }
+#pragma unroll
+        for (int i = 0; i < OPT_MB; ++i) {
+            const int n = j * OPT_MB + i + 1;
+            if (n <= nstop) mie_term(A, n, dd[i], m, minv, xinv);
+        }
     }
     const double x2inv = xinv * xinv;
-    qsca = 2. * x2inv * qs;
-    qext = 2. * x2inv * qe;
-    gasy = qs > 0. ? 2. * gs * frcp(qs) : 0.;
-    qback = x2inv * (xb.re * xb.re + xb.im * xb.im);
+    qsca = 2. * x2inv * A.qs;
+    qext = 2. * x2inv * A.qe;
+    gasy = A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
+    qback = x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im);
 }
 
-__global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelArgs a)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) optics_kernel(const OpticsKernelArgs a)
 {
     // the OPT_NWAVE blocks of one cell group run back-to-back on one XCD (blockIdx & 7)
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
     const int gl = s / OPT_NWAVE, w = s - gl * OPT_NWAVE;
+    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
+    double2 *ck = s_ck + threadIdx.x;
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
@@ -207,7 +245,7 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelA
         double x = pi * dwet * frcp(lam);
         x = x > OPT_XMAX ? OPT_XMAX : x;
         double qe, qs, g, qb;
-        mie_sphere(x, m, qe, qs, g, qb);
+        mie_sphere(x, m, ck, qe, qs, g, qb);
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
         ext += cross * qe;
