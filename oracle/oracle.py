@@ -42,7 +42,10 @@ class SwColumnIn(C.Structure):
                 ("h2ovmr", dp), ("o3vmr", dp), ("co2vmr", dp), ("ch4vmr", dp), ("n2ovmr", dp), ("o2vmr", dp),
                 ("asdir", C.c_double), ("asdif", C.c_double), ("aldir", C.c_double), ("aldif", C.c_double),
                 ("coszen", C.c_double), ("adjes", C.c_double), ("scon", C.c_double), ("dyofyr", C.c_int),
-                ("tauaer", dp), ("ssaaer", dp), ("asmaer", dp), ("clean_atm_diag", C.c_int)]
+                ("tauaer", dp), ("ssaaer", dp), ("asmaer", dp), ("clean_atm_diag", C.c_int),
+                ("cldfrac", dp), ("clwp", dp), ("ciwp", dp), ("cswp", dp), ("rel", dp), ("rei", dp), ("res", dp),
+                ("inflgsw", C.c_int), ("iceflgsw", C.c_int), ("liqflgsw", C.c_int), ("seed_real4", C.c_int),
+                ("cldfmc_out", dp)]
 
 
 SW_COL_OUT = ["swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc", "swuflxcln", "swdflxcln",
@@ -87,6 +90,19 @@ class SwOracle:
                             _p(keep["ch4vmr"]), _p(keep["n2ovmr"]), _p(keep["o2vmr"]),
                             s[0], s[1], s[2], s[3], s[4], s[5], s[6], 0,
                             _p(keep["tauaer"]), _p(keep["ssaaer"]), _p(keep["asmaer"]), clean)
+            if "cldfrac" in cols:   # in-cloud state for the McICA path (see rrtmg_oracle.h)
+                ck = {k: np.ascontiguousarray(cols[k][ic], dtype=np.float64)
+                      for k in ("cldfrac", "clwp", "ciwp", "cswp", "rel", "rei", "res")}
+                keep.update(ck)
+                for k in ck:
+                    setattr(ci, k, _p(ck[k]))
+                fl = cols["cldflags"][ic] if np.ndim(cols["cldflags"]) > 1 else cols["cldflags"]
+                ci.inflgsw, ci.iceflgsw, ci.liqflgsw = int(fl[0]), int(fl[1]), int(fl[2])
+                ci.seed_real4 = int(cols.get("seed_real4", 0))
+                mask = np.zeros((112, nlay))
+                keep["mask"] = mask
+                ci.cldfmc_out = _p(mask)
+                out.setdefault("cldfmc", np.zeros((ncol, 112, nlay)))
             rows = [np.zeros(out[n].shape[1]) for n in SW_COL_OUT]
             co = SwColumnOut(*[_p(r) for r in rows])
             rc = lib().sw_oracle_rrtmg_sw(self.h, C.byref(ci), C.byref(co))
@@ -94,6 +110,8 @@ class SwOracle:
                 raise RuntimeError(f"sw_oracle_rrtmg_sw rc={rc}")
             for n, r in zip(SW_COL_OUT, rows):
                 out[n][ic] = r
+            if "cldfrac" in cols:
+                out["cldfmc"][ic] = keep["mask"]
         return out
 
     def close(self):

@@ -8,7 +8,12 @@
 ! RRTMG_SW_DATA-layout file (same READ field order as sw_kgbNN, SW:11379-12366),
 ! calls rrtmg_sw_ini and rrtmg_sw, and dumps the results.
 !
-! usage: ref_sw <tables> <columns.bin> <out.bin> [dump_tables.bin]
+! usage: ref_sw <tables> <columns.bin> <out.bin> [dump_tables.bin|-] [clouds]
+!
+! With the fifth argument "clouds" every column record is followed by the in-cloud state the WRF wrapper hands to
+! the McICA generator (cldfrac, clwp, ciwp, cswp, rel, rei, res per layer and inflgsw/iceflgsw/liqflgsw); the
+! harness then calls the reference's mcica_subcol_sw (icld = 2, permuteseed = 1, irng = 0 as at SW:10950-10957)
+! before rrtmg_sw, and also dumps the sub-column cloud mask.
 !
 ! The only external the reference objects need from their host is the error
 ! hook wrf_error_fatal (cloud-optics range checks, SW:2168-2262); it is
@@ -25,8 +30,13 @@ program ref_sw
   use parrrsw, only : nbndsw, ngptsw, naerec
   use rrtmg_sw_init, only : rrtmg_sw_ini
   use rrtmg_sw_rad, only : rrtmg_sw
+  use mcica_subcol_gen_sw, only : mcica_subcol_sw
   implicit none
-  character(len=512) :: ftab, fcol, fout, fdump
+  character(len=512) :: ftab, fcol, fout, fdump, fmode
+  logical :: clouds
+  integer(kind=im) :: irng, permuteseed, iflags(3)
+  real(kind=rb), allocatable :: cldfrac(:,:), clwp(:,:), ciwp(:,:), cswp(:,:), rel(:,:), rei(:,:), res(:,:)
+  real(kind=rb), allocatable :: taucld(:,:,:), ssacld(:,:,:), asmcld(:,:,:), fsfcld(:,:,:)
   integer :: ncol, nlay, iclean, nrep, ic, irep, nargs
   integer(kind=im) :: icld, inflgsw, iceflgsw, liqflgsw, dyofyr
   real(kind=rb) :: cpdair, adjes, scon
@@ -53,6 +63,12 @@ program ref_sw
   call get_command_argument(3, fout)
   fdump = ''
   if (nargs >= 4) call get_command_argument(4, fdump)
+  if (trim(fdump) == '-') fdump = ''
+  clouds = .false.
+  if (nargs >= 5) then
+     call get_command_argument(5, fmode)
+     clouds = trim(fmode) == 'clouds'
+  end if
 
   call read_tables(trim(ftab))
   cpdair = 7.0_rb * 287.0_rb / 2.0_rb       ! WRF module_model_constants: cp = 7.*r_d/2.
@@ -75,6 +91,8 @@ program ref_sw
   allocate(sibvisdir(1,nlay+1), sibvisdif(1,nlay+1), sibnirdir(1,nlay+1), sibnirdif(1,nlay+1))
   allocate(swdkdir(1,nlay+1), swdkdif(1,nlay+1))
   allocate(buf(nlay*nbndsw))
+  allocate(cldfrac(1,nlay), clwp(1,nlay), ciwp(1,nlay), cswp(1,nlay), rel(1,nlay), rei(1,nlay), res(1,nlay))
+  allocate(taucld(nbndsw,1,nlay), ssacld(nbndsw,1,nlay), asmcld(nbndsw,1,nlay), fsfcld(nbndsw,1,nlay))
 
   ! cloud-free McICA inputs (what mcica_subcol_sw yields for cldfrac = 0)
   cldfmcl = 0._rb; taucmcl = 0._rb; ssacmcl = 1._rb; asmcmcl = 0._rb; fsfcmcl = 0._rb
@@ -93,6 +111,17 @@ program ref_sw
      read(21) buf; tauaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
      read(21) buf; ssaaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
      read(21) buf; asmaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
+     if (clouds) then
+        read(21) cldfrac(1,:), clwp(1,:), ciwp(1,:), cswp(1,:), rel(1,:), rei(1,:), res(1,:)
+        read(21) iflags
+        inflgsw = iflags(1); iceflgsw = iflags(2); liqflgsw = iflags(3)
+        taucld = 0._rb; ssacld = 1._rb; asmcld = 0._rb; fsfcld = 0._rb      ! SW:10925-10932
+        icld = 2; irng = 0; permuteseed = 1                                  ! SW:10950-10952
+        call mcica_subcol_sw(1, 1, nlay, icld, permuteseed, irng, play, &
+             cldfrac, ciwp, clwp, cswp, rei, rel, res, taucld, ssacld, asmcld, fsfcld, &
+             cldfmcl, ciwpmcl, clwpmcl, cswpmcl, reicmcl, relqmcl, resnmcl, &
+             taucmcl, ssacmcl, asmcmcl, fsfcmcl)
+     end if
      do irep = 1, max(1, nrep)
         icld = 2
         call rrtmg_sw(1, nlay, icld, play, plev, tlay, tlev, tsfc, &
@@ -107,6 +136,7 @@ program ref_sw
      write(22) swuflx(1,:), swdflx(1,:), swhr(1,:), swuflxc(1,:), swdflxc(1,:), swhrc(1,:)
      write(22) swuflxcln(1,:), swdflxcln(1,:)
      write(22) sibvisdir(1,:), sibvisdif(1,:), sibnirdir(1,:), sibnirdif(1,:), swdkdir(1,:), swdkdif(1,:)
+     if (clouds) write(22) cldfmcl(:,1,:)
   end do
   call system_clock(t1)
   secs = real(t1 - t0, 8) / real(trate, 8)

@@ -63,7 +63,20 @@ typedef struct {
     int dyofyr;
     const double *tauaer, *ssaaer, *asmaer;
     int clean_atm_diag;
+    /* clouds: cldfrac == NULL -> cloud-free column.  Otherwise the in-cloud state RRTMG_SWRAD hands to
+     * mcica_subcol_sw (SW:10707-10957): per layer cloud fraction, in-cloud liquid / ice / snow water path (g m-2),
+     * effective sizes (um), and inflgsw / iceflgsw / liqflgsw.  icld = 2, permuteseed = 1, irng = 0.
+     * seed_real4: derive the KISS seeds in single precision (stock REAL*4 WRF build). */
+    const double *cldfrac, *clwp, *ciwp, *cswp, *rel, *rei, *res;
+    int inflgsw, iceflgsw, liqflgsw, seed_real4;
+    double *cldfmc_out;      /* optional [SW_NGPT][nlay] dump of the sub-column mask */
 } SwColumnIn;
+
+/* McICA generator and cloud optics (rrtmg_sw_cloud_oracle.c) */
+int sw_oracle_mcica(int nlay, const double *play, const double *cldfrac, int change_seed, int real4, double *cldfmc);
+int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *ciwp,
+                      const double *clwp, const double *cswp, const double *rei, const double *rel, const double *res,
+                      double *taucmc, double *ssacmc, double *asmcmc, double *taormc, char *err, int errlen);
 
 typedef struct {
     double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;

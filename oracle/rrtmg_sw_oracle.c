@@ -971,6 +971,119 @@ static void spcvmc_sw(const SwTables *t, const SwCol *c, const double *palbd, co
     }
 }
 
+/* spcvmc_sw, SW:8083-8658, general McICA form: cld arrays [SW_NGPT][nlay] 0-based layers bottom->top
+ * (cldfmc 0/1, taucmc/ssacmc/asmcmc delta-scaled, taormc unscaled), icpr = 1 (clouds present). */
+typedef struct { const double *cldfmc, *taucmc, *ssacmc, *asmcmc, *taormc; } SwCloudMc;
+
+static void spcvmc_sw_cloudy(const SwTables *t, const SwCol *c, const double *palbd, const double *palbp,
+                             const double (*ptaua)[MAXLAY], const double (*pasya)[MAXLAY],
+                             const double (*pomga)[MAXLAY], const SwCloudMc *cld, double prmu0, const double *adjflux,
+                             SwFlux *f)
+{
+    const int klev = c->nlayers;
+    const double repclc = 1.e-12;
+    int lrtchkclr[MAXLAY + 2], lrtchkcld[MAXLAY + 2];
+    double zdbtc[MAXLAY + 2], ztdbtc[MAXLAY + 2], zdbtc_nodel[MAXLAY + 2], ztdbtc_nodel[MAXLAY + 2];
+    double zdbt[MAXLAY + 2], ztdbt[MAXLAY + 2], zdbt_nodel[MAXLAY + 2], ztdbt_nodel[MAXLAY + 2];
+    double zgcc[MAXLAY + 2], zomcc[MAXLAY + 2], ztauc[MAXLAY + 2], zgco[MAXLAY + 2], zomco[MAXLAY + 2], ztauo[MAXLAY + 2];
+    double zrefc[MAXLAY + 2], zrefdc[MAXLAY + 2], ztrac[MAXLAY + 2], ztradc[MAXLAY + 2];
+    double zrefo[MAXLAY + 2], zrefdo[MAXLAY + 2], ztrao[MAXLAY + 2], ztrado[MAXLAY + 2];
+    double zref[MAXLAY + 2], zrefd[MAXLAY + 2], ztra[MAXLAY + 2], ztrad[MAXLAY + 2];
+    double zrdndc[MAXLAY + 2], zrupc[MAXLAY + 2], zrupdc[MAXLAY + 2], zrdnd[MAXLAY + 2], zrup[MAXLAY + 2], zrupd[MAXLAY + 2];
+    double zcd[MAXLAY + 2], zcu[MAXLAY + 2], zfd[MAXLAY + 2], zfu[MAXLAY + 2];
+    memset(f, 0, sizeof(*f));
+
+    int iw = 0;
+    for (int jb = SW_JPB1; jb <= SW_JPB1 + SW_NBND - 1; ++jb) {
+        int ibm = jb - 15;
+        int igt = ngc[ibm - 1];
+        for (int jg = 1; jg <= igt; ++jg) {
+            iw = iw + 1;
+            const double *cf = cld->cldfmc + (size_t)(iw - 1) * klev, *tc = cld->taucmc + (size_t)(iw - 1) * klev;
+            const double *oc = cld->ssacmc + (size_t)(iw - 1) * klev, *gc = cld->asmcmc + (size_t)(iw - 1) * klev;
+            const double *to = cld->taormc + (size_t)(iw - 1) * klev;
+            double zincflx = adjflux[ibm - 1] * c->sfluxzen[iw - 1] * prmu0;
+            ztdbtc[1] = 1.0; ztdbtc_nodel[1] = 1.0;
+            zdbtc[klev + 1] = 0.0; ztrac[klev + 1] = 0.0; ztradc[klev + 1] = 0.0;
+            zrefc[klev + 1] = palbp[ibm - 1]; zrefdc[klev + 1] = palbd[ibm - 1];
+            zrupc[klev + 1] = palbp[ibm - 1]; zrupdc[klev + 1] = palbd[ibm - 1];
+            ztdbt[1] = 1.0; ztdbt_nodel[1] = 1.0;
+            zdbt[klev + 1] = 0.0; ztra[klev + 1] = 0.0; ztrad[klev + 1] = 0.0;
+            zref[klev + 1] = palbp[ibm - 1]; zrefd[klev + 1] = palbd[ibm - 1];
+            zrup[klev + 1] = palbp[ibm - 1]; zrupd[klev + 1] = palbd[ibm - 1];
+            for (int jk = 1; jk <= klev; ++jk) {
+                int ikl = klev + 1 - jk;
+                const double pcldfmc = cf[ikl - 1], ptaucmc = tc[ikl - 1], pomgcmc = oc[ikl - 1], pasycmc = gc[ikl - 1];
+                const double ptaormc = to[ikl - 1];
+                lrtchkclr[jk] = 1;
+                lrtchkcld[jk] = pcldfmc > repclc;
+                ztauc[jk] = c->taur[iw - 1][ikl] + c->taug[iw - 1][ikl] + ptaua[ibm - 1][ikl];
+                zomcc[jk] = c->taur[iw - 1][ikl] * 1.0 + ptaua[ibm - 1][ikl] * pomga[ibm - 1][ikl];
+                zgcc[jk] = pasya[ibm - 1][ikl] * pomga[ibm - 1][ikl] * ptaua[ibm - 1][ikl] / zomcc[jk];
+                zomcc[jk] = zomcc[jk] / ztauc[jk];
+                double zclear = 1.0 - pcldfmc, zcloud = pcldfmc;
+                double zdbtmc = exp_lookup(t, ztauc[jk] / prmu0);
+                zdbtc_nodel[jk] = zdbtmc;
+                ztdbtc_nodel[jk + 1] = zdbtc_nodel[jk] * ztdbtc_nodel[jk];
+                double tauorig = ztauc[jk] + ptaormc;
+                double zdbtmo = exp_lookup(t, tauorig / prmu0);
+                zdbt_nodel[jk] = zclear * zdbtmc + zcloud * zdbtmo;
+                ztdbt_nodel[jk + 1] = zdbt_nodel[jk] * ztdbt_nodel[jk];
+                double zf = zgcc[jk] * zgcc[jk];
+                double zwf = zomcc[jk] * zf;
+                ztauc[jk] = (1.0 - zwf) * ztauc[jk];
+                double denom = fmax((1.0 - zwf), 1.0E-30);
+                zomcc[jk] = (zomcc[jk] - zwf) / denom;
+                denom = fmax((1.0 - zf), 1.0E-30);
+                zgcc[jk] = (zgcc[jk] - zf) / denom;
+                /* total sky: cloud properties are already delta-scaled, SW:8505-8510 (icpr >= 1) */
+                ztauo[jk] = ztauc[jk] + ptaucmc;
+                zomco[jk] = ztauc[jk] * zomcc[jk] + ptaucmc * pomgcmc;
+                zgco[jk] = (ptaucmc * pomgcmc * pasycmc + ztauc[jk] * zomcc[jk] * zgcc[jk]) / zomco[jk];
+                zomco[jk] = zomco[jk] / ztauo[jk];
+            }
+            reftra_sw(t, klev, lrtchkclr, zgcc, prmu0, ztauc, zomcc, zrefc, zrefdc, ztrac, ztradc);
+            reftra_sw(t, klev, lrtchkcld, zgco, prmu0, ztauo, zomco, zrefo, zrefdo, ztrao, ztrado);
+            for (int jk = 1; jk <= klev; ++jk) {
+                int ikl = klev + 1 - jk;
+                double zclear = 1.0 - cf[ikl - 1], zcloud = cf[ikl - 1];
+                zref[jk] = zclear * zrefc[jk] + zcloud * zrefo[jk];
+                zrefd[jk] = zclear * zrefdc[jk] + zcloud * zrefdo[jk];
+                ztra[jk] = zclear * ztrac[jk] + zcloud * ztrao[jk];
+                ztrad[jk] = zclear * ztradc[jk] + zcloud * ztrado[jk];
+                double zdbtmc = exp_lookup(t, ztauc[jk] / prmu0);
+                zdbtc[jk] = zdbtmc;
+                ztdbtc[jk + 1] = zdbtc[jk] * ztdbtc[jk];
+                double zdbtmo = exp_lookup(t, ztauo[jk] / prmu0);
+                zdbt[jk] = zclear * zdbtmc + zcloud * zdbtmo;
+                ztdbt[jk + 1] = zdbt[jk] * ztdbt[jk];
+            }
+            vrtqdr_sw(klev, zrefc, zrefdc, ztrac, ztradc, zdbtc, zrdndc, zrupc, zrupdc, ztdbtc, zcd, zcu);
+            vrtqdr_sw(klev, zref, zrefd, ztra, ztrad, zdbt, zrdnd, zrup, zrupd, ztdbt, zfd, zfu);
+            for (int jk = 1; jk <= klev + 1; ++jk) {
+                int ikl = klev + 2 - jk;
+                f->bbfu[ikl] = f->bbfu[ikl] + zincflx * zfu[jk];
+                f->bbfd[ikl] = f->bbfd[ikl] + zincflx * zfd[jk];
+                f->bbcu[ikl] = f->bbcu[ikl] + zincflx * zcu[jk];
+                f->bbcd[ikl] = f->bbcd[ikl] + zincflx * zcd[jk];
+                f->bbfddir[ikl] = f->bbfddir[ikl] + zincflx * ztdbt_nodel[jk];
+                f->bbcddir[ikl] = f->bbcddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                if (ibm >= 10 && ibm <= 13) {
+                    f->uvcd[ikl] = f->uvcd[ikl] + zincflx * zcd[jk];
+                    f->uvfd[ikl] = f->uvfd[ikl] + zincflx * zfd[jk];
+                    f->uvcddir[ikl] = f->uvcddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                    f->uvfddir[ikl] = f->uvfddir[ikl] + zincflx * ztdbt_nodel[jk];
+                } else if (ibm == 14 || ibm <= 9) {
+                    f->nicd[ikl] = f->nicd[ikl] + zincflx * zcd[jk];
+                    f->nifd[ikl] = f->nifd[ikl] + zincflx * zfd[jk];
+                    f->nicddir[ikl] = f->nicddir[ikl] + zincflx * ztdbtc_nodel[jk];
+                    f->nifddir[ikl] = f->nifddir[ikl] + zincflx * ztdbt_nodel[jk];
+                }
+            }
+        }
+    }
+}
+
 /* rrtmg_sw, SW:8740-9490 (+ inatm_sw, SW:9520-9873) for one column */
 int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out)
 {
@@ -1034,6 +1147,22 @@ int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out
         }
 
     SwFlux *f = (SwFlux *)malloc(sizeof(SwFlux));
+    /* clouds: mcica_subcol_sw (called by RRTMG_SWRAD, SW:10950-10957) + cldprmc_sw (SW:9260-9264) */
+    double *cbuf = NULL;
+    SwCloudMc cld = {0};
+    if (in->cldfrac) {
+        const size_t n = (size_t)SW_NGPT * nlayers;
+        cbuf = (double *)malloc(5 * n * sizeof(double));
+        double *cldfmc = cbuf, *taucmc = cbuf + n, *ssacmc = cbuf + 2 * n, *asmcmc = cbuf + 3 * n, *taormc = cbuf + 4 * n;
+        int rc = sw_oracle_mcica(nlayers, in->play, in->cldfrac, 1, in->seed_real4, cldfmc);
+        if (!rc) rc = sw_oracle_cldprmc(nlayers, in->inflgsw, in->iceflgsw, in->liqflgsw, cldfmc, in->ciwp, in->clwp,
+                                        in->cswp, in->rei, in->rel, in->res, taucmc, ssacmc, asmcmc, taormc, NULL, 0);
+        if (rc) { free(cbuf); free(f); free(pt); free(c); return 10 + rc; }
+        if (in->cldfmc_out) memcpy(in->cldfmc_out, cldfmc, n * sizeof(double));
+        cld.cldfmc = cldfmc; cld.taucmc = taucmc; cld.ssacmc = ssacmc; cld.asmcmc = asmcmc; cld.taormc = taormc;
+        spcvmc_sw_cloudy(t, c, albdif, albdir, (const double(*)[MAXLAY])ta, (const double(*)[MAXLAY])as,
+                         (const double(*)[MAXLAY])om, &cld, cossza, adjflux, f);
+    } else
     spcvmc_sw(t, c, albdif, albdir, (const double(*)[MAXLAY])ta, (const double(*)[MAXLAY])as,
               (const double(*)[MAXLAY])om, cossza, adjflux, f);
     double swnflx[MAXLAY + 2], swnflxc[MAXLAY + 2];
@@ -1067,6 +1196,10 @@ int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out
 
     if (in->clean_atm_diag > 0) {
         /* second call with aerosol optical depth removed, SW:9436-9472 */
+        if (in->cldfrac)
+            spcvmc_sw_cloudy(t, c, albdif, albdir, (const double(*)[MAXLAY])cl, (const double(*)[MAXLAY])as,
+                             (const double(*)[MAXLAY])om, &cld, cossza, adjflux, f);
+        else
         spcvmc_sw(t, c, albdif, albdir, (const double(*)[MAXLAY])cl, (const double(*)[MAXLAY])as,
                   (const double(*)[MAXLAY])om, cossza, adjflux, f);
         for (int i = 1; i <= nlayers + 1; ++i) {
@@ -1076,7 +1209,7 @@ int sw_oracle_rrtmg_sw(const SwTables *t, const SwColumnIn *in, SwColumnOut *out
     } else {
         for (int i = 1; i <= nlayers + 1; ++i) { out->swuflxcln[i - 1] = 0.0; out->swdflxcln[i - 1] = 0.0; }
     }
-    free(f); free(pt); free(c);
+    free(cbuf); free(f); free(pt); free(c);
     return 0;
 }
 
