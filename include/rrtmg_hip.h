@@ -82,6 +82,17 @@ typedef struct rrtmg_hip_swrad_args {
     void *swddir, *swddni, *swddif;
     /* optional flux profiles (ims:ime, kms:kme+2, jms:jme) */
     void *swupflx, *swupflxc, *swupflxcln, *swdnflx, *swdnflxc, *swdnflxcln;
+    /* clouds, used when icloud != 0 (RRTMG_SWRAD arguments of the same names, SW:9901-9945; McICA with
+     * maximum-random overlap, KISS seeded from the fractional Pa of the four lowest layers, SW:1696-1699).
+     * A hydrometeor array is NULL when the argument is not PRESENT or its F_Q* flag is false. */
+    const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d;      /* 3-D */
+    const void *re_cloud, *re_ice, *re_snow;               /* 3-D, metres; used with has_reqc / has_reqi / has_reqs */
+    const void *qndrop3d;                                  /* 3-D, used with progn = 1 (F_QNDROP) */
+    const void *xland, *xice, *snow;                       /* 2-D */
+    int has_reqc, has_reqi, has_reqs;
+    int warm_rain, progn;
+    int is_cammgmp_used, f_ice_phy, mp_physics;            /* CAM-MG radii and the Ferrier/HWRF splits are refused */
+    double g;                                              /* gravity the driver passes (G), m s-2 */
 } rrtmg_hip_swrad_args;
 
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);

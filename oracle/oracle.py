@@ -120,6 +120,10 @@ class SwOracle:
             self.h = None
 
 
+CLOUD3 = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d", "re_cloud", "re_ice", "re_snow", "qndrop3d"]
+CLOUD2 = ["xland", "xice", "snow"]
+
+
 class SwTileIn(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("ims", "ime", "jms", "jme", "kms", "kme",
                                          "its", "ite", "jts", "jte", "kts", "kte")]
@@ -127,7 +131,11 @@ class SwTileIn(C.Structure):
                                      "tauaer300", "tauaer400", "tauaer600", "tauaer999",
                                      "gaer300", "gaer400", "gaer600", "gaer999",
                                      "waer300", "waer400", "waer600", "waer999")]
-                + [("solcon", C.c_double), ("aer_ra_feedback", C.c_int), ("clean_atm_diag", C.c_int)])
+                + [("solcon", C.c_double), ("aer_ra_feedback", C.c_int), ("clean_atm_diag", C.c_int)]
+                + [("icloud", C.c_int)]
+                + [(n, dp) for n in CLOUD3 + CLOUD2]
+                + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
+                + [("g", C.c_double), ("seed_real4", C.c_int)])
 
 
 SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",
@@ -141,8 +149,10 @@ class SwTileOut(C.Structure):
     _fields_ = [(n, dp) for n in SW_TILE_OUT]
 
 
-def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedback, clean_atm_diag, outputs: dict):
-    """RRTMG_SWRAD restatement on a tile; arrays/outputs are float64 numpy in WRF order."""
+def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedback, clean_atm_diag, outputs: dict,
+               cloud: dict = None):
+    """RRTMG_SWRAD restatement on a tile; arrays/outputs are float64 numpy in WRF order.  cloud: icloud,
+    has_reqc/i/s, warm_rain, progn, g, seed_real4 (the cloud arrays themselves travel in `arrays`)."""
     ti = SwTileIn()
     for n in ("ims", "ime", "jms", "jme", "kms", "kme", "its", "ite", "jts", "jte", "kts", "kte"):
         setattr(ti, n, int(dims[n]))
@@ -155,6 +165,11 @@ def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedbac
     ti.solcon = float(solcon)
     ti.aer_ra_feedback = int(aer_ra_feedback)
     ti.clean_atm_diag = int(clean_atm_diag)
+    ti.g = 9.81
+    if cloud:
+        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4"):
+            setattr(ti, n, int(cloud.get(n, 0)))
+        ti.g = float(cloud.get("g", 9.81))
     to = SwTileOut()
     for n in SW_TILE_OUT:
         if outputs.get(n) is not None:

@@ -72,6 +72,19 @@ typedef struct {
     double *cldfmc_out;      /* optional [SW_NGPT][nlay] dump of the sub-column mask */
 } SwColumnIn;
 
+/* WRF hydrometeor state of one column as the wrappers receive it (NULL array = argument absent / F_Q* false) */
+typedef struct {
+    int nk;
+    const double *t, *pdel;                       /* layer temperature (K), thickness (mb) */
+    const double *cldfra, *qc, *qr, *qi, *qs;     /* cloud fraction, mixing ratios (kg/kg) */
+    const double *re_cloud, *re_ice, *re_snow;    /* effective radii (m), used with has_req* */
+    const double *qndrop;                         /* droplet number (1/kg), used with progn = 1 */
+    int has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    double xland, xice, snow, g;
+} OracleCloudWrf;
+int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, double *ciwp, double *cswp,
+                       double *rel, double *rei, double *res, int *flags3);
+
 /* McICA generator and cloud optics (rrtmg_sw_cloud_oracle.c) */
 int sw_oracle_mcica(int nlay, const double *play, const double *cldfrac, int change_seed, int real4, double *cldfmc);
 int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *ciwp,
@@ -102,6 +115,13 @@ typedef struct {
     const double *waer300, *waer400, *waer600, *waer999;
     double solcon;
     int aer_ra_feedback, clean_atm_diag;
+    /* clouds (icloud != 0; SW:10371-10618, 10707-10957).  NULL 3-D array = argument absent / F_Q* false. */
+    int icloud;
+    const double *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d;   /* 3-D */
+    const double *xland, *xice, *snow;                                                              /* 2-D */
+    int has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    double g;
+    int seed_real4;
 } SwTileIn;
 
 typedef struct {

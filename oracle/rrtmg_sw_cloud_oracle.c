@@ -90,8 +90,8 @@ int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const doub
                       double *taucmc, double *ssacmc, double *asmcmc, double *taormc, char *err, int errlen)
 {
     const double cldmin = 1.e-20;
-    if (inflag < 2 || liqflag != 1 || (iceflag != 3 && iceflag != 5))
-        return fail(err, errlen, "oracle cldprmc_sw: only inflag>=2, liqflag=1, iceflag=3|5 are restated");
+    if (inflag < 2 || liqflag != 1 || iceflag < 3 || iceflag > 5)
+        return fail(err, errlen, "oracle cldprmc_sw: only inflag>=2, liqflag=1, iceflag=3|4|5 are restated");
     int ig = 0;
     for (int ib = 0; ib < SW_NBND; ++ib)
         for (int jg = 0; jg < ngc_sw[ib]; ++jg, ++ig)
@@ -182,7 +182,7 @@ int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const doub
                 if (scatsno == 0.) scatsno = cldmin;
                 if (iceflag < 5) ssacmc[q] = (scatliq + scatice) / taucmc[q];
                 else ssacmc[q] = (scatliq + scatice + scatsno) / taucmc[q];
-                if (iceflag == 3) {
+                if (iceflag == 3 || iceflag == 4) {
                     asmcmc[q] = (1.0 / (scatliq + scatice)) *
                                 (scatliq * (gliq - forwliq) / (1.0 - forwliq) + scatice * ((gice - forwice) / (1.0 - forwice)));
                 } else {
@@ -192,5 +192,125 @@ int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const doub
                                  scatsno * ((gsno - forwsno) / (1.0 - forwsno)));
                 }
             }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * In-cloud state of one column as RRTMG_SWRAD / RRTMG_LWRAD build it from the WRF hydrometeor fields
+ * (SW:10371-10618 and SW:10707-10947; the LW wrapper has the same block, LW:11921-12140, 12306-12480).
+ * PARITY UNPINNED: the wrapper modules cannot be compiled here; restated from the source text.
+ * Arrays over the nk model layers, bottom -> top.  Outputs have nk+1 entries (extra top layer: no cloud).
+ * Not restated (refused by the engine as well): is_cammgmp_used, the Ferrier/HWRF F_ICE_PHY variants.
+ * --------------------------------------------------------------------------------------------------------- */
+#include "cld_retab.h"
+
+int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, double *ciwp, double *cswp,
+                       double *rel, double *rei, double *res, int *flags3)
+{
+    const int nk = w->nk;
+    double qc1d[256], qr1d[256], qi1d[256], qs1d[256], recloud1d[256], reice1d[256], resnow1d[256];
+    if (nk > 255) return 1;
+    for (int k = 0; k < nk; ++k) {
+        qc1d[k] = w->qc ? fmax(0., w->qc[k]) : 0.;
+        qr1d[k] = w->qr ? fmax(0., w->qr[k]) : 0.;
+        qi1d[k] = 0.; qs1d[k] = 0.;
+    }
+    if (!w->qi && !w->warm_rain)   /* no ice species: split by temperature, SW:10413-10422 */
+        for (int k = 0; k < nk; ++k)
+            if (w->t[k] < 273.15) { qi1d[k] = qc1d[k]; qs1d[k] = qr1d[k]; qc1d[k] = 0.; qr1d[k] = 0.; }
+    if (w->qi) for (int k = 0; k < nk; ++k) qi1d[k] = fmax(0., w->qi[k]);
+    if (w->qs) for (int k = 0; k < nk; ++k) qs1d[k] = fmax(0., w->qs[k]);
+    int inflg = 2, iceflg = 3, liqflg = 1;
+    for (int k = 0; k < nk; ++k) {
+        const double cf3 = w->cldfra ? w->cldfra[k] : 0.;
+        if (w->has_reqc != 0) {   /* SW:10519-10533 */
+            inflg = 3;
+            double r = fmax(2.5, w->re_cloud[k] * 1.E6);
+            if (r <= 2.5 && cf3 > 0. && (w->xland - 1.5) > 0.) r = 10.5;
+            else if (r <= 2.5 && cf3 > 0. && (w->xland - 1.5) < 0.) r = 7.5;
+            recloud1d[k] = r;
+        } else recloud1d[k] = 5.0;
+        if (w->has_reqi != 0) {   /* SW:10543-10557 */
+            inflg = 4; iceflg = 4;
+            double r = fmax(5., w->re_ice[k] * 1.E6);
+            if (r <= 5. && cf3 > 0.) {
+                int idx = (int)(w->t[k] - 179.);
+                idx = idx < 1 ? 1 : (idx > 75 ? 75 : idx);
+                double corr = w->t[k] - (double)(int)w->t[k];
+                r = CLD_RETAB[idx - 1] * (1. - corr) + CLD_RETAB[idx] * corr;
+                r = fmax(r, 5.0);
+            }
+            reice1d[k] = r;
+        } else reice1d[k] = 10.;
+        if (w->has_reqs != 0) {   /* SW:10563-10568 */
+            inflg = 5; iceflg = 5;
+            resnow1d[k] = fmax(10., w->re_snow[k] * 1.E6);
+        } else resnow1d[k] = 10.0;
+    }
+    if (w->has_reqs == 0 && w->has_reqi != 0 && w->has_reqc != 0) {   /* SW:10595-10604 */
+        inflg = 5; iceflg = 5;
+        for (int k = 0; k < nk; ++k) {
+            resnow1d[k] = fmax(10., w->re_ice[k] * 1.E6);
+            qs1d[k] = w->qi ? w->qi[k] : 0.;
+            qi1d[k] = 0.;
+            reice1d[k] = 10.;
+        }
+    }
+    /* SW:10743-10947 */
+    const double landfrac = 2. - w->xland, landm = landfrac, snowh = 0.001 * w->snow, icefrac = w->xice;
+    for (int k = 0; k < nk; ++k) {
+        const double cf = w->cldfra ? w->cldfra[k] : 0.;
+        cldfrac[k] = cf;
+        double gicewp = (qi1d[k] + qs1d[k]) * w->pdel[k] * 100.0 / w->g * 1000.0;
+        double gliqwp = qc1d[k] * w->pdel[k] * 100.0 / w->g * 1000.0;
+        double cicewp = gicewp / fmax(0.01, cf), cliqwp = gliqwp / fmax(0.01, cf), csnowp = 0.;
+        if (iceflg >= 4) {
+            gicewp = qi1d[k] * w->pdel[k] * 100.0 / w->g * 1000.0;
+            cicewp = gicewp / fmax(0.01, cf);
+        }
+        if (iceflg == 5) {
+            double snow_mass_factor = 1.0;
+            if (resnow1d[k] > 130.) {
+                snow_mass_factor = (130.0 / resnow1d[k]) * (130.0 / resnow1d[k]);
+                resnow1d[k] = 130.0;
+            }
+            double gsnowp = qs1d[k] * snow_mass_factor * w->pdel[k] * 100.0 / w->g * 1000.0;
+            csnowp = gsnowp / fmax(0.01, cf);
+        }
+        double reliq;
+        if (w->progn == 1) {   /* prognostic droplet number, SW:10797-10816 */
+            const double pi = 4. * atan(1.0), third = 1. / 3., rhoh2o = 1.e3, relconst = 3 / (4. * pi * rhoh2o);
+            const double lwpmin = 3.e-5;
+            reliq = 10.;
+            if (w->qndrop && qc1d[k] * w->pdel[k] > lwpmin && w->qndrop[k] > 1000.) {
+                reliq = pow(relconst * qc1d[k] / w->qndrop[k], third);
+                reliq = 1.1 * reliq;
+                reliq = reliq * 1.e6;
+                reliq = fmax(reliq, 4.);
+                reliq = fmin(reliq, 20.);
+            }
+        } else {               /* relcalc, LW:14403-14462 */
+            const double tmelt = 273.16, rliqocean = 14.0, rliqice = 14.0, rliqland = 8.0;
+            reliq = rliqland + (rliqocean - rliqland) * fmin(1.0, fmax(0.0, (tmelt - w->t[k]) * 0.05));
+            reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, snowh * 10.));
+            reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, 1.0 - landm));
+            reliq = reliq + (rliqice - reliq) * fmin(1.0, fmax(0.0, icefrac));
+        }
+        double reice;
+        {                      /* reicalc, LW:14464-14491 */
+            int index = (int)(w->t[k] - 179.);
+            index = index < 1 ? 1 : (index > 94 ? 94 : index);
+            double corr = w->t[k] - (double)(int)w->t[k];
+            reice = CLD_RETAB[index - 1] * (1. - corr) + CLD_RETAB[index] * corr;
+        }
+        if (inflg >= 3) reliq = recloud1d[k];
+        if (iceflg >= 4) reice = reice1d[k];
+        if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+        clwp[k] = cliqwp; ciwp[k] = cicewp; rel[k] = reliq; rei[k] = reice;
+        if (inflg == 5) { cswp[k] = csnowp; res[k] = resnow1d[k]; }
+        else { cswp[k] = 0.0; res[k] = 10.0; }
+    }
+    clwp[nk] = 0.; ciwp[nk] = 0.; cswp[nk] = 0.; rel[nk] = 10.; rei[nk] = 10.; res[nk] = 10.; cldfrac[nk] = 0.;
+    flags3[0] = inflg; flags3[1] = iceflg; flags3[2] = liqflg;
     return 0;
 }

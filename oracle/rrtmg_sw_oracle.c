@@ -1364,6 +1364,29 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
                 SwColumnIn ci = {nlay, play, plev, tlay, tlev, in->tsk[I2(i, j)], h2ovmr, o3vmr, co2vmr, ch4vmr,
                                  n2ovmr, o2vmr, alb, alb, alb, alb, coszrs, 1.0, in->solcon, 0,
                                  tauaer, ssaaer, asmaer, in->clean_atm_diag};
+                double cst[7][MAXLAY], cin[9][MAXLAY];
+                if (in->icloud != 0) {
+                    /* hydrometeors -> in-cloud state, SW:10371-10618, 10707-10947 (oracle_cloud_state) */
+                    const double *src[9] = {in->cldfra3d, in->qc3d, in->qr3d, in->qi3d, in->qs3d, in->re_cloud,
+                                            in->re_ice, in->re_snow, in->qndrop3d};
+                    for (int s = 0; s < 9; ++s)
+                        if (src[s]) for (int k = 0; k < nk; ++k) cin[s][k] = src[s][I3(i, in->kts + k, j)];
+                    double pdel[MAXLAY];
+                    for (int k = 0; k < nk; ++k) pdel[k] = plev[k] - plev[k + 1];
+                    OracleCloudWrf cw = {nk, tlay, pdel,
+                                         src[0] ? cin[0] : NULL, src[1] ? cin[1] : NULL, src[2] ? cin[2] : NULL,
+                                         src[3] ? cin[3] : NULL, src[4] ? cin[4] : NULL, src[5] ? cin[5] : NULL,
+                                         src[6] ? cin[6] : NULL, src[7] ? cin[7] : NULL, src[8] ? cin[8] : NULL,
+                                         in->has_reqc, in->has_reqi, in->has_reqs, in->warm_rain, in->progn,
+                                         in->xland ? in->xland[I2(i, j)] : 1., in->xice ? in->xice[I2(i, j)] : 0.,
+                                         in->snow ? in->snow[I2(i, j)] : 0., in->g};
+                    int fl[3];
+                    if (oracle_cloud_state(&cw, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], fl)) { rc = 1; break; }
+                    ci.cldfrac = cst[0]; ci.clwp = cst[1]; ci.ciwp = cst[2]; ci.cswp = cst[3];
+                    ci.rel = cst[4]; ci.rei = cst[5]; ci.res = cst[6];
+                    ci.inflgsw = fl[0]; ci.iceflgsw = fl[1]; ci.liqflgsw = fl[2];
+                    ci.seed_real4 = in->seed_real4;
+                }
                 SwColumnOut co = {swuflx, swdflx, swhr, swuflxc, swdflxc, swhrc, swuflxcln, swdflxcln,
                                   vd, vd + MAXLAY, vd + 2 * MAXLAY, vd + 3 * MAXLAY, vd + 4 * MAXLAY, vd + 5 * MAXLAY};
                 if (sw_oracle_rrtmg_sw(t, &ci, &co)) { rc = 1; break; }

@@ -32,17 +32,35 @@ def alloc_outputs(st, profiles=True):
     return out
 
 
-def run_oracle_swrad(orc_obj, st, tile=None, clean=1, aer=1, solcon=1370.0, profiles=True):
+CLD3 = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d", "re_cloud", "re_ice", "re_snow", "qndrop3d"]
+CLD2 = ["xland", "xice", "snow"]
+
+
+def cloud_arrays(st, cloud):
+    """Cloud arguments present for this call (cloud = flags returned by synth_clouds.add_clouds, or None)."""
+    if not cloud or not cloud.get("icloud"):
+        return {}
+    need = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d"]
+    need += ["re_cloud"] * bool(cloud.get("has_reqc")) + ["re_ice"] * bool(cloud.get("has_reqi"))
+    need += ["re_snow"] * bool(cloud.get("has_reqs")) + ["qndrop3d"] * (cloud.get("progn") == 1)
+    arr = {n: st.a3[n] for n in need if n in st.a3 and n not in cloud.get("absent", ())}
+    arr.update({n: st.a2[n] for n in CLD2})
+    return arr
+
+
+def run_oracle_swrad(orc_obj, st, tile=None, clean=1, aer=1, solcon=1370.0, profiles=True, cloud=None, seed_real4=0):
     from oracle import oracle as orc
     out = alloc_outputs(st, profiles)
     arrays = {n: st.a2[n] for n in IN2}
     arrays.update({n: st.a3[n] for n in IN3 + AER})
-    orc.swrad_tile(orc_obj, dims_of(st, tile), arrays, solcon, aer, clean, out)
+    arrays.update(cloud_arrays(st, cloud))
+    cl = dict(cloud, seed_real4=seed_real4) if cloud else None
+    orc.swrad_tile(orc_obj, dims_of(st, tile), arrays, solcon, aer, clean, out, cloud=cl)
     return out
 
 
 def run_hip_swrad(eng, st, device=True, real_bytes=8, tile=None, clean=1, aer=1, solcon=1370.0, profiles=True,
-                  drop=()):
+                  drop=(), cloud=None):
     """Call the product through the C-ABI.  device=True: torch CUDA tensors
     (mem=1); device=False: numpy host arrays staged by the library (mem=0)."""
     dt = np.float64 if real_bytes == 8 else np.float32
@@ -51,17 +69,20 @@ def run_hip_swrad(eng, st, device=True, real_bytes=8, tile=None, clean=1, aer=1,
     host.update({n: np.ascontiguousarray(st.a3[n], dtype=dt) for n in IN3})
     if aer:
         host.update({n: np.ascontiguousarray(st.a3[n], dtype=dt) for n in AER})
+    host.update({n: np.ascontiguousarray(v, dtype=dt) for n, v in cloud_arrays(st, cloud).items()})
+    flags = {k: v for k, v in (cloud or {}).items() if k != "absent"}
+    flags.setdefault("icloud", 0)
     outs = {n: np.ascontiguousarray(v, dtype=dt) for n, v in out.items() if n not in drop}
     d = dims_of(st, tile)
     if device:
         import torch
         dev_in = {n: torch.from_numpy(v).cuda() for n, v in host.items()}
         dev_out = {n: torch.from_numpy(v).cuda() for n, v in outs.items()}
-        eng.rrtmg_swrad(solcon=solcon, aer_ra_feedback=aer, clean_atm_diag=clean, icloud=0, **d, **dev_in, **dev_out)
+        eng.rrtmg_swrad(solcon=solcon, aer_ra_feedback=aer, clean_atm_diag=clean, **flags, **d, **dev_in, **dev_out)
         eng.sw_status()
         torch.cuda.synchronize()
         return {n: v.cpu().numpy().astype(np.float64) for n, v in dev_out.items()}
-    eng.rrtmg_swrad(solcon=solcon, aer_ra_feedback=aer, clean_atm_diag=clean, icloud=0, **d, **host, **outs)
+    eng.rrtmg_swrad(solcon=solcon, aer_ra_feedback=aer, clean_atm_diag=clean, **flags, **d, **host, **outs)
     return {n: v.astype(np.float64) for n, v in outs.items()}
 
 

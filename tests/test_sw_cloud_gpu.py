@@ -1,0 +1,83 @@
+"""GPU parity tests of the cloudy (McICA) shortwave path: RRTMG_SWRAD with icloud /= 0 through the HIP C-ABI against
+the CPU oracle (whose column solver incl. the KISS generator is bit-exact against the reference Fortran,
+tests/test_oracle_golden_cloud.py).  The sub-column cloud masks must be identical, so the flux tolerance is the
+same 1e-9 as for the cloud-free path."""
+import numpy as np
+import pytest
+
+from helpers import compare_sw, run_hip_swrad, run_oracle_swrad
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+ATOL = 1e-9
+
+
+def _init(wa, sw_table_file):
+    import torch
+    assert torch.cuda.is_available()
+    wa.engine.rrtmg_swinit(sw_table_file, device=0)
+    return wa.engine
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 1, False), (5, 4, 50, 2, True), (4, 3, 28, 3, False),
+                                                 (3, 3, 60, 4, True)])
+def test_cloudy_swrad_matches_oracle(hip_lib, wa, sw_table_file, sw_oracle, ni, nj, nk, seed, radii):
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260400 + seed, night_fraction=0.1)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260410 + seed, cloudy_fraction=0.6, with_radii=radii)
+    got = run_hip_swrad(eng, st, cloud=cloud)
+    ref = run_oracle_swrad(sw_oracle, st, cloud=cloud)
+    worst = compare_sw(got, ref, RTOL, ATOL)
+    assert worst < 1e-8
+    day = st.a2["xcoszen"] > 0
+    cloudy = (st.a3["cldfra3d"].sum(axis=1) > 0) & day
+    clear = (st.a3["cldfra3d"].sum(axis=1) == 0) & day
+    assert cloudy.any() and clear.any()
+    # clouds change the total-sky TOA flux; cloud-free columns keep clear == total exactly and zero forcing
+    assert np.abs(got["swupt"][cloudy] - got["swuptc"][cloudy]).max() > 1.0
+    np.testing.assert_array_equal(got["swupt"][clear], got["swuptc"][clear])
+    assert (got["swcf"][clear] == 0).all() and (got["swcf"][cloudy] != 0).any()
+
+
+def test_cloudy_tile_subset_host_mode_and_no_clean(hip_lib, wa, sw_table_file, sw_oracle):
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(9, 7, 40, seed=20260420)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260421, cloudy_fraction=0.7)
+    tile = dict(its=2, ite=8, jts=3, jte=6)
+    a = run_hip_swrad(eng, st, device=True, tile=tile, cloud=cloud, clean=0)
+    b = run_hip_swrad(eng, st, device=False, tile=tile, cloud=cloud, clean=0)
+    ref = run_oracle_swrad(sw_oracle, st, tile=tile, cloud=cloud, clean=0)
+    compare_sw(a, ref, RTOL, ATOL)
+    for n in a:
+        np.testing.assert_array_equal(a[n], b[n], err_msg=n)
+
+
+def test_cloudy_real4_state_uses_single_precision_seeds(hip_lib, wa, sw_table_file, sw_oracle):
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(6, 5, 40, seed=20260430)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260431, cloudy_fraction=0.7)
+    for d in (st.a2, st.a3):
+        for n in d:
+            d[n] = d[n].astype(np.float32).astype(np.float64)
+    got = run_hip_swrad(eng, st, real_bytes=4, cloud=cloud)
+    ref = run_oracle_swrad(sw_oracle, st, cloud=cloud, seed_real4=1)
+    compare_sw(got, ref, 3e-7, 2e-4)
+
+
+def test_cloud_refusals_and_fatal_sizes(hip_lib, wa, sw_table_file):
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(3, 2, 30, seed=20260440)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260441, cloudy_fraction=1.0, with_radii=True)
+    with pytest.raises(wa.engine.WrfFatal, match="CAM-MG"):
+        run_hip_swrad(eng, st, cloud=dict(cloud, is_cammgmp_used=True))
+    with pytest.raises(wa.engine.WrfFatal, match="Ferrier"):
+        run_hip_swrad(eng, st, cloud=dict(cloud, mp_physics=5))
+    with pytest.raises(wa.engine.WrfFatal, match="cldfra3d"):
+        run_hip_swrad(eng, st, cloud=dict(cloud, absent=("cldfra3d",)))
+    # a microphysics ice radius beyond the Fu table is fatal in cldprmc_sw (SW:2168-2173)
+    st.a3["re_ice"][...] = 200.0e-6
+    st.a3["cldfra3d"][:, 5, :] = 1.0
+    st.a3["qi3d"][:, 5, :] = 1.0e-4
+    st.a2["xcoszen"][...] = 0.5
+    with pytest.raises(wa.engine.WrfFatal, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
+        run_hip_swrad(eng, st, cloud=cloud)

@@ -111,6 +111,13 @@ extern "C" int rrtmg_hip_sw_init(const char *data_path, int data_real_bytes, dou
     HIPCHK(hipMemcpy(st.dExp, host.exp_tbl.data(), host.exp_tbl.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(st.dG, host.gdesc.data(), host.gdesc.size() * sizeof(GDesc), hipMemcpyHostToDevice));
     HIPCHK(sw_upload_constants(nullptr));
+    HIPCHK(sw_upload_retab());
+    {
+        std::vector<double> cld((size_t)CLD_NTAB * SW_NBND * CLD_STRIDE);
+        sw_cloud_tables(cld.data());
+        if (!st.dCld) HIPCHK(hipMalloc(&st.dCld, cld.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(st.dCld, cld.data(), cld.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (!st.dStatus) HIPCHK(hipMalloc(&st.dStatus, sizeof(int)));
     HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
     st.dev.K = static_cast<const double *>(st.dK);
@@ -165,6 +172,16 @@ extern "C" int rrtmg_hip_sw_table_info(const char *data_path, int data_real_byte
     return 0;
 }
 
+static const char *sw_status_text(int kind)
+{
+    switch (kind) {
+    case 1: return "ERROR: ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case 2: return "ERROR: SNOW GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case 3: return "liquid effective radius out of bounds";
+    default: return "ERROR: Negative total optical depth";
+    }
+}
+
 extern "C" long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *a)
 {
     const long long ni = a->ime - a->ims + 1, nk = a->kme - a->kms + 1, nj = a->jme - a->jms + 1;
@@ -177,8 +194,16 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     SwState &st = sw_state();
     if (!st.ready) return fail(err, "rrtmg_hip_swrad: rrtmg_hip_sw_init has not been called");
     if (a->real_bytes != 4 && a->real_bytes != 8) return fail(err, "rrtmg_hip_swrad: real_bytes must be 4 or 8");
-    if (a->icloud != 0)
-        return fail(err, "rrtmg_hip_swrad: icloud /= 0 (McICA cloudy columns) is not implemented in this release");
+    if (a->icloud != 0) {
+        if (a->is_cammgmp_used)
+            return fail(err, "rrtmg_hip_swrad: is_cammgmp_used (CAM-MG effective radii) is not implemented");
+        if (a->f_ice_phy || a->mp_physics == 5 || a->mp_physics == 15)
+            return fail(err, "rrtmg_hip_swrad: the Ferrier / HWRF hydrometeor splits (F_ICE_PHY, FER_MP_HIRES) are not implemented");
+        if (!a->cldfra3d) return fail(err, "rrtmg_hip_swrad: icloud /= 0 needs cldfra3d");
+        if ((a->has_reqc && !a->re_cloud) || (a->has_reqi && !a->re_ice) || (a->has_reqs && !a->re_snow))
+            return fail(err, "rrtmg_hip_swrad: has_reqc/has_reqi/has_reqs set without re_cloud/re_ice/re_snow");
+        if (!(a->g > 0.)) return fail(err, "rrtmg_hip_swrad: gravity g must be positive when icloud /= 0");
+    }
     const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
     const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk = a->kte - a->kts + 1;
     if (ni_t <= 0 || nj_t <= 0 || nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
@@ -204,6 +229,23 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     k.aer_ra_feedback = a->aer_ra_feedback; k.clean = a->clean_atm_diag; k.o3input = a->o3input;
     k.solcon = a->solcon;
     k.tab = st.dev;
+    k.icloud = a->icloud;
+    if (a->icloud != 0) {
+        if (nk + 1 < 4) return fail(err, "rrtmg_hip_swrad: the McICA seeds need at least four layers");
+        k.has_reqc = a->has_reqc; k.has_reqi = a->has_reqi; k.has_reqs = a->has_reqs;
+        k.warm_rain = a->warm_rain; k.progn = a->progn; k.grav = a->g;
+        k.cldtab = static_cast<const double *>(st.dCld);
+        // KISS jump table of this layer count (permuteseed = 1, SW:10952), built once per nlay
+        std::lock_guard<std::mutex> lock(st.jump_mutex);
+        void *&dj = st.dJump[nk + 1];
+        if (!dj) {
+            std::vector<uint32_t> h((size_t)SW_NGPT * KISS_JUMP_WORDS);
+            kiss_jump_table(nk + 1, 1, SW_NGPT, h.data());
+            HIPCHK(hipMalloc(&dj, h.size() * sizeof(uint32_t)));
+            HIPCHK(hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        k.jump = static_cast<const uint32_t *>(dj);
+    }
 
     Staging stg;
     int *d_status = static_cast<int *>(st.dStatus);
@@ -226,6 +268,13 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         k.swddir = a->swddir; k.swddni = a->swddni; k.swddif = a->swddif;
         k.swupflx = a->swupflx; k.swupflxc = a->swupflxc; k.swupflxcln = a->swupflxcln;
         k.swdnflx = a->swdnflx; k.swdnflxc = a->swdnflxc; k.swdnflxcln = a->swdnflxcln;
+        if (a->icloud != 0) {
+            k.cldfra3d = a->cldfra3d; k.qc3d = a->qc3d; k.qr3d = a->qr3d; k.qi3d = a->qi3d; k.qs3d = a->qs3d;
+            k.re_cloud = a->has_reqc ? a->re_cloud : nullptr; k.re_ice = a->has_reqi ? a->re_ice : nullptr;
+            k.re_snow = a->has_reqs ? a->re_snow : nullptr;
+            k.qndrop3d = a->progn == 1 ? a->qndrop3d : nullptr;
+            k.xland = a->xland; k.xice = a->xice; k.snow = a->snow;
+        }
     } else {
 #define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
 #define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
@@ -239,6 +288,14 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         if (a->aer_ra_feedback == 1) {
             IN3(tauaer300); IN3(tauaer400); IN3(tauaer600); IN3(tauaer999);
             IN3(gaer400); IN3(gaer600); IN3(waer400); IN3(waer600);
+        }
+        if (a->icloud != 0) {
+            IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);
+            if (a->has_reqc) IN3(re_cloud);
+            if (a->has_reqi) IN3(re_ice);
+            if (a->has_reqs) IN3(re_snow);
+            if (a->progn == 1) IN3(qndrop3d);
+            IN2(xland); IN2(xice); IN2(snow);
         }
         OUT(rthratensw, n3); OUT(coszr, n2); OUT(gsw, n2); OUT(swcf, n2);
         OUT(swupt, n2); OUT(swuptc, n2); OUT(swuptcln, n2); OUT(swdnt, n2); OUT(swdntc, n2); OUT(swdntcln, n2);
@@ -265,10 +322,10 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (status != 0) {
-            const int col = status - 1;
+            const int col = (status & 0x0fffffff) - 1;
             char m[RRTMG_HIP_ERRLEN];
-            std::snprintf(m, sizeof m, "ERROR: Negative total optical depth at point i,j=%5d%5d",
-                          a->its + col % ni_t, a->jts + col / ni_t);   // SW:11031-11033
+            std::snprintf(m, sizeof m, "%s at point i,j=%5d%5d", sw_status_text(status >> 28),
+                          a->its + col % ni_t, a->jts + col / ni_t);   // SW:11031-11033, SW:2169-2173
             return fail(err, m);
         }
     }
@@ -287,7 +344,7 @@ extern "C" int rrtmg_hip_sw_status(char *err)
     HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
     if (status != 0) {
         char m[RRTMG_HIP_ERRLEN];
-        std::snprintf(m, sizeof m, "ERROR: Negative total optical depth at tile column %d", status - 1);
+        std::snprintf(m, sizeof m, "%s at tile column %d", sw_status_text(status >> 28), (status & 0x0fffffff) - 1);
         return fail(err, m);
     }
     return 0;
@@ -299,7 +356,10 @@ extern "C" int rrtmg_hip_finalize(void)
     SwState &st = sw_state();
     if (st.dK) { (void)hipFree(st.dK); (void)hipFree(st.dExp); (void)hipFree(st.dG); }
     if (st.dStatus) (void)hipFree(st.dStatus);
-    st.dK = st.dExp = st.dG = st.dStatus = nullptr;
+    if (st.dCld) (void)hipFree(st.dCld);
+    for (auto &kv : st.dJump) if (kv.second) (void)hipFree(kv.second);
+    st.dJump.clear();
+    st.dK = st.dExp = st.dG = st.dStatus = st.dCld = nullptr;
     st.ready = false;
     return 0;
 }

@@ -1,5 +1,7 @@
 // Host-side state of the engine: tables built at init, device copies.
 #pragma once
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,9 @@ struct SwState {
     SwHostTables host;
     SwDeviceTables dev{};
     void *dK = nullptr, *dExp = nullptr, *dG = nullptr, *dStatus = nullptr;
+    void *dCld = nullptr;                  // cloud optics coefficient tables (sw_cloud_tables)
+    std::map<int, void *> dJump;           // KISS jump tables by layer count
+    std::mutex jump_mutex;
 };
 
 SwState &sw_state();

@@ -22,9 +22,25 @@ struct SwKernelArgs {
     void *swupb, *swupbc, *swupbcln, *swdnb, *swdnbc, *swdnbcln;
     void *swvisdir, *swvisdif, *swnirdir, *swnirdif, *swddir, *swddni, *swddif;
     void *swupflx, *swupflxc, *swupflxcln, *swdnflx, *swdnflxc, *swdnflxcln;
-    int *status;                         // device word: 0 ok, 1+col = negative column AOD at that column
+    int *status;                         // device word: 0 ok, (kind << 28) | (1+col); kind 0 = negative column AOD,
+                                         // 1 ice size, 2 snow size, 3 liquid radius out of bounds (cldprmc_sw)
+    // clouds (icloud != 0)
+    int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    double grav;
+    const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
+    const uint32_t *jump;                // KISS jump-ahead table for this layer count: [SW_NGPT][KISS_JUMP_WORDS]
+    const double *cldtab;                // cloud optics coefficients [CLD_NTAB][SW_NBND][CLD_STRIDE]
     SwDeviceTables tab;
 };
+
+// KISS jump-ahead (mcica.hip): per sub-column the transform that advances the four generators by
+// change_seed + isubcol*nlay draws: LCG (A, C), xorshift matrix (32 rows), two multiply-with-carry factors
+constexpr int KISS_JUMP_WORDS = 36;
+void kiss_jump_table(int nlay, int change_seed, int nsub, uint32_t *out /*[nsub][KISS_JUMP_WORDS]*/);
+// cloud optics tables: 0 extliq1 1 ssaliq1 2 asyliq1 3 extice3 4 ssaice3 5 asyice3 6 fdlice3
+constexpr int CLD_NTAB = 7, CLD_STRIDE = 58;
+void sw_cloud_tables(double *out /*[CLD_NTAB][SW_NBND][CLD_STRIDE]*/);
+hipError_t sw_upload_retab();
 
 size_t sw_lds_bytes(int nk);
 hipError_t sw_upload_constants(hipStream_t stream);

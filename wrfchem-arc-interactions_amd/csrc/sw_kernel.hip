@@ -29,6 +29,7 @@
 
 #include "rrtmg_common.h"
 #include "sw_kernel.h"
+#include "cld_retab.h"
 
 namespace rrtmg {
 
@@ -266,6 +267,11 @@ struct ColView {
     double *ckpt;       // [4 waves][nck][2][64]
     double *flux;       // [4 waves][nlev][2]
     double *sfc;        // [4 waves][8] surface-only sums
+    double *fluxc;      // [2 waves][nlev][2] clear-sky (aerosol) fluxes of a cloudy column
+    // in-cloud state per layer (icloud != 0): cloud fraction, liquid / ice / snow water path, table fractions
+    double *cldf, *clwp, *ciwp, *cswp, *fliq, *fice, *fsno;
+    int *iliq, *iice, *isno;   // table indices (1-based as in cldprmc_sw), 0 = size out of bounds
+    int *seeds;                // [4] KISS seeds of the column
     int nlp;            // padded layer count (multiple of BLK)
 };
 
@@ -282,8 +288,12 @@ __device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nle
     v.ckpt = p; p += 4 * nck * 2 * 64;
     v.flux = p; p += 4 * nlev * 2;
     v.sfc = p; p += 4 * 8;
+    v.fluxc = p; p += 2 * nlev * 2;
+    v.cldf = p; p += nlp; v.clwp = p; p += nlp; v.ciwp = p; p += nlp; v.cswp = p; p += nlp;
+    v.fliq = p; p += nlp; v.fice = p; p += nlp; v.fsno = p; p += nlp;
     int *q = reinterpret_cast<int *>(p);
     v.rb0 = q; q += nlp; v.rb1 = q; q += nlp; v.inds = q; q += nlp; v.indf = q; q += nlp; v.jp = q; q += nlp + 1;
+    v.iliq = q; q += nlp; v.iice = q; q += nlp; v.isno = q; q += nlp; v.seeds = q; q += 4;
     return v;
 }
 
@@ -347,13 +357,123 @@ __device__ __forceinline__ void gas_optics(const SwDeviceTables &tb, const ColVi
     taur = c.colmol[k] * rayl;
 }
 
+// ice effective radius versus temperature (retab, LW:11424-11442), uploaded by sw_upload_retab()
+__constant__ double c_retab[95];
+
+// kissvec, SW:1900-1932: one draw of the column's generator (32-bit wrap-around arithmetic, logical shifts)
+struct KissState { uint32_t s1, s2, s3, s4; };
+__device__ __forceinline__ double kiss_next(KissState &k)
+{
+#pragma clang fp contract(off)   // kiss*2.328306e-10 + 0.5 is a product and a sum in the reference, not an FMA
+    k.s1 = 69069u * k.s1 + 1327217885u;
+    k.s2 ^= k.s2 << 13;
+    k.s2 ^= k.s2 >> 17;
+    k.s2 ^= k.s2 << 5;
+    k.s3 = 18000u * (k.s3 & 65535u) + (k.s3 >> 16);
+    k.s4 = 30903u * (k.s4 & 65535u) + (k.s4 >> 16);
+    const int32_t kiss = (int32_t)(k.s1 + k.s2 + (k.s3 << 16) + k.s4);
+    return (double)kiss * 2.328306e-10 + 0.5;
+}
+// advance by the number of draws encoded in J (kiss_jump_table, mcica.hip)
+__device__ __forceinline__ void kiss_jump(KissState &k, const uint32_t *J)
+{
+    k.s1 = J[0] * k.s1 + J[1];
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) r ^= J[2 + j] & (0u - ((k.s2 >> j) & 1u));
+    k.s2 = r;
+    k.s3 = (uint32_t)(((uint64_t)k.s3 * J[34]) % (18000u * 65536u - 1u));
+    k.s4 = (uint32_t)(((uint64_t)k.s4 * J[35]) % (30903u * 65536u - 1u));
+}
+
+// Cloud optical properties of one cloudy sub-column layer: cldprmc_sw, SW:2062-2388, for inflag >= 2, liqflag = 1,
+// iceflag = 3, 4 or 5 (what RRTMG_SWRAD can select, SW:10514-10604).  Table indices and interpolation fractions
+// were prepared per layer by the prologue.  bad: 1 ice, 2 snow, 3 liquid size out of bounds (fatal in the reference).
+__device__ __forceinline__ void cloud_optics(const double *T, const ColView &c, int band, int k, int iceflag,
+                                             double &taucmc, double &ssacmc, double &asmcmc, double &taormc, int &bad)
+{
+    const double cldmin = 1.e-20;
+    const double ciwp = c.ciwp[k], clwp = c.clwp[k], cswp = iceflag == 5 ? c.cswp[k] : 0.;
+    taucmc = 0.; ssacmc = 1.; asmcmc = 0.; taormc = 0.;
+    if (!(ciwp + clwp + cswp >= cldmin)) return;
+    auto tab = [&](int t, int i) { return T[(t * SW_NBND + band) * CLD_STRIDE + i]; };
+    double extcoice = 0., ssacoice = 0., gice = 0., forwice = 0.;
+    double extcosno = 0., ssacosno = 0., gsno = 0., forwsno = 0.;
+    double extcoliq = 0., ssacoliq = 0., gliq = 0., forwliq = 0.;
+    if ((ciwp + cswp) != 0.0) {
+        const int ix = c.iice[k];
+        if (ix == 0) { bad = 1; return; }
+        const double f = c.fice[k];
+        extcoice = tab(3, ix - 1) + f * (tab(3, ix) - tab(3, ix - 1));
+        ssacoice = tab(4, ix - 1) + f * (tab(4, ix) - tab(4, ix - 1));
+        gice = tab(5, ix - 1) + f * (tab(5, ix) - tab(5, ix - 1));
+        const double fdelta = tab(6, ix - 1) + f * (tab(6, ix) - tab(6, ix - 1));
+        forwice = fdelta + fdiv(0.5, ssacoice);
+        forwice = forwice > gice ? gice : forwice;
+    }
+    if (cswp > 0.0 && iceflag == 5) {
+        const int ix = c.isno[k];
+        if (ix == 0) { bad = 2; return; }
+        const double f = c.fsno[k];
+        extcosno = tab(3, ix - 1) + f * (tab(3, ix) - tab(3, ix - 1));
+        ssacosno = tab(4, ix - 1) + f * (tab(4, ix) - tab(4, ix - 1));
+        gsno = tab(5, ix - 1) + f * (tab(5, ix) - tab(5, ix - 1));
+        const double fdelta = tab(6, ix - 1) + f * (tab(6, ix) - tab(6, ix - 1));
+        forwsno = fdelta + fdiv(0.5, ssacosno);
+        forwsno = forwsno > gsno ? gsno : forwsno;
+    }
+    if (clwp != 0.0) {
+        const int ix = c.iliq[k];
+        if (ix == 0) { bad = 3; return; }
+        const double f = c.fliq[k];
+        extcoliq = tab(0, ix - 1) + f * (tab(0, ix) - tab(0, ix - 1));
+        ssacoliq = tab(1, ix - 1) + f * (tab(1, ix) - tab(1, ix - 1));
+        if (f < 0. && ssacoliq > 1.) ssacoliq = tab(1, ix - 1);
+        gliq = tab(2, ix - 1) + f * (tab(2, ix) - tab(2, ix - 1));
+        forwliq = gliq * gliq;
+    }
+    const double tauliqorig = clwp * extcoliq, tauiceorig = ciwp * extcoice;
+    const double ssaliq = fdiv(ssacoliq * (1. - forwliq), 1. - forwliq * ssacoliq);
+    const double tauliq = (1. - forwliq * ssacoliq) * tauliqorig;
+    const double ssaice = fdiv(ssacoice * (1. - forwice), 1. - forwice * ssacoice);
+    const double tauice = (1. - forwice * ssacoice) * tauiceorig;
+    const double scatliq = ssaliq * tauliq;
+    double scatice = ssaice * tauice, scatsno = 0.0;
+    if (iceflag < 5) {
+        taormc = tauliqorig + tauiceorig;
+        taucmc = tauliq + tauice;
+    } else {
+        const double tausnoorig = cswp * extcosno;
+        taormc = tauliqorig + tauiceorig + tausnoorig;
+        const double ssasno = fdiv(ssacosno * (1. - forwsno), 1. - forwsno * ssacosno);
+        const double tausno = (1. - forwsno * ssacosno) * tausnoorig;
+        scatsno = ssasno * tausno;
+        taucmc = tauliq + tauice + tausno;
+    }
+    if (taucmc == 0.) taucmc = cldmin;
+    if (scatice == 0.) scatice = cldmin;
+    if (scatsno == 0.) scatsno = cldmin;
+    const double gl = fdiv(scatliq * (gliq - forwliq), 1.0 - forwliq);
+    const double gi = scatice * fdiv(gice - forwice, 1.0 - forwice);
+    if (iceflag < 5) {
+        ssacmc = fdiv(scatliq + scatice, taucmc);
+        asmcmc = frcp(scatliq + scatice) * (gl + gi);
+    } else {
+        ssacmc = fdiv(scatliq + scatice + scatsno, taucmc);
+        asmcmc = frcp(scatliq + scatice + scatsno) * (gl + gi + scatsno * fdiv(gsno - forwsno, 1.0 - forwsno));
+    }
+}
+
 // optical properties of layer k as seen by the two-stream solver (spcvmc_sw
 // layer preparation, SW:8443-8501) followed by reftra and the delta-scaled
 // direct-beam transmittance (SW:8568-8578).  dbt_nodel: unscaled direct beam
 // (SW:8459-8469), only requested by the aerosol pass on its way down.
+// cloudy: this sub-column (lane) has cloud in layer k -- total-sky properties per SW:8505-8510, 8476-8486.
 template <bool NODEL>
 __device__ __forceinline__ void layer_rt(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
-                                         bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel)
+                                         bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel,
+                                         bool cloudy = false, int iceflag = 3, const double *cldtab = nullptr,
+                                         int *bad = nullptr)
 {
     double taug, taur;
     gas_optics(tb, c, L, k, lower, taug, taur);
@@ -365,12 +485,25 @@ __device__ __forceinline__ void layer_rt(const SwDeviceTables &tb, const ColView
     double zomcc = taur * 1.0 + ta * wa;
     double zgcc = fdiv(ga * wa * ta, zomcc);
     zomcc = fdiv(zomcc, ztauc);
-    if (NODEL) dbt_nodel = exp_lookup(tb, ztauc * rprmu0);
+    const double ztau_un = ztauc;
     double zf = zgcc * zgcc;
     double zwf = zomcc * zf;
     ztauc = (1.0 - zwf) * ztauc;
     zomcc = fdiv(zomcc - zwf, fmax((1.0 - zwf), 1.0E-30));
     zgcc = fdiv(zgcc - zf, fmax((1.0 - zf), 1.0E-30));
+    double taor = 0.;
+    if (cloudy) {
+        double tc, oc, gc;
+        int b = 0;
+        cloud_optics(cldtab, c, L.band, k, iceflag, tc, oc, gc, taor, b);
+        if (b) *bad = b;
+        const double ztauo = ztauc + tc;
+        double zomco = ztauc * zomcc + tc * oc;
+        zgcc = fdiv(tc * oc * gc + ztauc * zomcc * zgcc, zomco);
+        zomcc = fdiv(zomco, ztauo);
+        ztauc = ztauo;
+    }
+    if (NODEL) dbt_nodel = exp_lookup(tb, (ztau_un + taor) * rprmu0);
     o.dbt = exp_lookup(tb, ztauc * rprmu0);
     reftra_fast(tb, ztauc, zomcc, zgcc, prmu0, o.dbt, o);
 }
@@ -533,6 +666,138 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             c.rb1[k] = lowerp ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
             c.inds[k] = indself - 1;
             c.indf[k] = indfor - 1;
+            if (a.icloud != 0) {
+                // hydrometeors -> in-cloud water paths and effective sizes, SW:10371-10618 and 10743-10947
+                double cf = 0., clwp = 0., ciwp = 0., cswp = 0., reliq = 10., reice = 10., resno = 10.;
+                if (!top) {
+                    const size_t q = base3 + (size_t)k * sk;
+                    double qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;
+                    double qr = a.qr3d ? fmax(0., ldr(a.qr3d, q, r4)) : 0.;
+                    double qi = 0., qs = 0.;
+                    if (!a.qi3d && !a.warm_rain && tavel < 273.15) { qi = qc; qs = qr; qc = 0.; qr = 0.; }
+                    if (a.qi3d) qi = fmax(0., ldr(a.qi3d, q, r4));
+                    if (a.qs3d) qs = fmax(0., ldr(a.qs3d, q, r4));
+                    cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
+                    const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;
+                    int iceflg = 3, inflg = 2;
+                    double recloud = 5.0, reice1 = 10., resnow1 = 10.0;
+                    if (a.has_reqc != 0) {
+                        inflg = 3;
+                        recloud = fmax(2.5, ldr(a.re_cloud, q, r4) * 1.E6);
+                        if (recloud <= 2.5 && cf > 0. && (xland - 1.5) > 0.) recloud = 10.5;
+                        else if (recloud <= 2.5 && cf > 0. && (xland - 1.5) < 0.) recloud = 7.5;
+                    }
+                    if (a.has_reqi != 0) {
+                        inflg = 4; iceflg = 4;
+                        reice1 = fmax(5., ldr(a.re_ice, q, r4) * 1.E6);
+                        if (reice1 <= 5. && cf > 0.) {
+                            int idx = (int)(tavel - 179.);
+                            idx = idx < 1 ? 1 : (idx > 75 ? 75 : idx);
+                            const double corr = tavel - (double)(int)tavel;
+                            reice1 = c_retab[idx - 1] * (1. - corr) + c_retab[idx] * corr;
+                            reice1 = fmax(reice1, 5.0);
+                        }
+                    }
+                    if (a.has_reqs != 0) {
+                        inflg = 5; iceflg = 5;
+                        resnow1 = fmax(10., ldr(a.re_snow, q, r4) * 1.E6);
+                    }
+                    if (a.has_reqs == 0 && a.has_reqi != 0 && a.has_reqc != 0) {
+                        inflg = 5; iceflg = 5;
+                        resnow1 = fmax(10., ldr(a.re_ice, q, r4) * 1.E6);
+                        qs = a.qi3d ? ldr(a.qi3d, q, r4) : 0.;
+                        qi = 0.;
+                        reice1 = 10.;
+                    }
+                    const double pdel = plev_b - plev_t;
+                    double gicewp = (qi + qs) * pdel * 100.0 / a.grav * 1000.0;
+                    const double gliqwp = qc * pdel * 100.0 / a.grav * 1000.0;
+                    if (iceflg >= 4) gicewp = qi * pdel * 100.0 / a.grav * 1000.0;
+                    ciwp = gicewp / fmax(0.01, cf);
+                    clwp = gliqwp / fmax(0.01, cf);
+                    if (iceflg == 5) {
+                        double snow_mass_factor = 1.0;
+                        if (resnow1 > 130.) {
+                            snow_mass_factor = (130.0 / resnow1) * (130.0 / resnow1);
+                            resnow1 = 130.0;
+                        }
+                        const double gsnowp = qs * snow_mass_factor * pdel * 100.0 / a.grav * 1000.0;
+                        cswp = gsnowp / fmax(0.01, cf);
+                    }
+                    if (a.progn == 1) {   // prognostic droplet number, SW:10797-10816
+                        const double pi = 4. * atan(1.0), third = 1. / 3., rhoh2o = 1.e3, relconst = 3 / (4. * pi * rhoh2o);
+                        reliq = 10.;
+                        const double qnd = a.qndrop3d ? ldr(a.qndrop3d, q, r4) : 0.;
+                        if (a.qndrop3d && qc * pdel > 3.e-5 && qnd > 1000.) {
+                            reliq = pow(relconst * qc / qnd, third);
+                            reliq = 1.1 * reliq;
+                            reliq = reliq * 1.e6;
+                            reliq = fmax(reliq, 4.);
+                            reliq = fmin(reliq, 20.);
+                        }
+                    } else {              // relcalc, LW:14403-14462
+                        const double landm = 2. - xland, snowh = 0.001 * (a.snow ? ldr(a.snow, i2, r4) : 0.);
+                        const double icefrac = a.xice ? ldr(a.xice, i2, r4) : 0.;
+                        reliq = 8.0 + (14.0 - 8.0) * fmin(1.0, fmax(0.0, (273.16 - tavel) * 0.05));
+                        reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, snowh * 10.));
+                        reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, 1.0 - landm));
+                        reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, icefrac));
+                    }
+                    {                     // reicalc, LW:14464-14491
+                        int index = (int)(tavel - 179.);
+                        index = index < 1 ? 1 : (index > 94 ? 94 : index);
+                        const double corr = tavel - (double)(int)tavel;
+                        reice = c_retab[index - 1] * (1. - corr) + c_retab[index] * corr;
+                    }
+                    if (inflg >= 3) reliq = recloud;
+                    if (iceflg >= 4) reice = reice1;
+                    if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+                    if (inflg == 5) resno = resnow1; else { cswp = 0.0; resno = 10.0; }
+                }
+                c.cldf[k] = cf < 1.0e-20 ? 0. : cf;   // generate_stochastic_clouds_sw, SW:1677-1684
+                c.clwp[k] = clwp; c.ciwp[k] = ciwp; c.cswp[k] = cswp;
+                // table positions of cldprmc_sw (SW:2168-2176, 2212-2219, 2268-2276); 0 = out of bounds
+                {
+                    const bool ok = !(reice < 5.0 || reice > 140.0);
+                    const double factor = (reice - 2.) / 3.;
+                    int index = (int)factor;
+                    if (index == 46) index = 45;
+                    c.iice[k] = ok ? index : 0;
+                    c.fice[k] = factor - (double)index;
+                }
+                {
+                    const bool ok = !(resno < 5.0 || resno > 140.0);
+                    const double factor = (resno - 2.) / 3.;
+                    int index = (int)factor;
+                    if (index == 46) index = 45;
+                    c.isno[k] = ok ? index : 0;
+                    c.fsno[k] = factor - (double)index;
+                }
+                {
+                    const bool ok = !(reliq < 1.5 || reliq > 60.);
+                    int index = (int)(reliq - 1.5);
+                    if (index == 0) index = 1;
+                    if (index == 58) index = 57;
+                    c.iliq[k] = ok ? index : 0;
+                    c.fliq[k] = reliq - 1.5 - (double)index;
+                }
+                if (k < 4) {
+                    // KISS seeds from the fractional part of the mid-layer pressure in Pa, SW:1696-1699; a REAL*4
+                    // build of the reference does this arithmetic in single precision
+                    // (no FMA contraction here: fusing pm*100 into the subtraction changes the truncated integer)
+#pragma clang fp contract(off)
+                    int seed;
+                    if (r4) {
+                        const float pl = reinterpret_cast<const float *>(a.p3d)[base3 + (size_t)k * sk] / 100.f;
+                        const float pm = pl * 1.e2f;
+                        seed = (int)((pm - (float)(int)pm) * (float)1000000000);
+                    } else {
+                        const double pm = pavel * 1.e2;
+                        seed = (int)((pm - (double)(int)pm) * 1000000000.);
+                    }
+                    c.seeds[k] = seed;
+                }
+            }
         } else {
             // identity padding layers above the real top: never evaluated, keep LDS defined
             c.fac00[k] = c.fac01[k] = c.fac10[k] = c.fac11[k] = 0.;
@@ -586,7 +851,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
 
     // ======================= main phase: lanes = g-points =======================
     const int chunk = wave & 1, pass = wave >> 1;
-    const bool aer_on = (pass == 0);
     const bool active = lane < CHUNK;
     const int g = chunk * CHUNK + (active ? lane : CHUNK - 1);
     const GDesc gd = tb.gdesc[g];
@@ -594,53 +858,74 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     L.lo = gd.lo; L.up = gd.up; L.ng = gd.ng; L.off_self = gd.off_self; L.off_for = gd.off_for;
     L.band = gd.band; L.off_rayla = gd.off_rayla;
 
-    double *flux = c.flux + (size_t)wave * nlev * 2;
-    if (pass == 1 && a.clean <= 0) {
-        // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
-        for (int l = lane; l < nlev; l += 64) { flux[2 * l] = 0.; flux[2 * l + 1] = 0.; }
-    } else {
-        const double prmu0 = coszrs <= 1.e-10 ? 1.e-10 : coszrs;   // SW:9254-9255
-        // solar source at the layer selected per band (SW:3363-3380, 3533-3538, 4297) -> incoming flux
-        double sfluxzen;
-        {
-            int laysolfr;
-            if (gd.solar_kind == SOL_UPPER) {
-                laysolfr = nlay;   // 1-based, as in the reference
-                for (int lay = laytrop + 1; lay <= nlay; ++lay)
-                    if (c.jp[lay - 2] < gd.layreffr && c.jp[lay - 1] >= gd.layreffr) laysolfr = lay;
-            } else {
-                laysolfr = laytrop;
-                if (gd.solar_kind == SOL_LOWER)
-                    for (int lay = 1; lay <= laytrop; ++lay)
-                        if (c.jp[lay - 1] < gd.layreffr && c.jp[lay] >= gd.layreffr)
-                            laysolfr = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+    // McICA: this lane's sub-column of binary cloud (generate_stochastic_clouds_sw, SW:1737-1772, icld = 2):
+    // bit k of cmask = cloudy in layer k.  The lane jumps the column's KISS sequence to its own nlay draws.
+    uint64_t cmask = 0;
+    int iceflag = 3;
+    if (a.icloud != 0) {
+        if (a.has_reqi != 0) iceflag = 4;
+        if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
+        KissState ks = {(uint32_t)c.seeds[0], (uint32_t)c.seeds[1], (uint32_t)c.seeds[2], (uint32_t)c.seeds[3]};
+        kiss_jump(ks, a.jump + (size_t)g * KISS_JUMP_WORDS);
+        double prev = 0.;
+        for (int l = 0; l < nlay; ++l) {
+            double cur = kiss_next(ks);
+            if (l > 0) {
+                const double cb = c.cldf[l - 1];
+                cur = prev > 1. - cb ? prev : cur * (1. - cb);
             }
-            const int ks = laysolfr - 1;
-            const bool lowers = (laysolfr <= laytrop);
-            const GRegime &R = lowers ? gd.lo : gd.up;
-            int jsi = 0;
-            double fs = 0.;
-            if (gd.nsf > 1) {
-                const int spa = (R.cfg >> CFG_SPA_SHIFT) & 7, spb = (R.cfg >> CFG_SPB_SHIFT) & 7;
-                double colA = c.col[spa * nlp + ks], colB = c.col[spb * nlp + ks];
-                double speccomb = colA + R.strrat * colB;
-                double specparm = colA / speccomb;
-                specparm = specparm >= tb.oneminus ? tb.oneminus : specparm;
-                double specmult = ((R.cfg & CFG_MULT4) ? 4. : 8.) * specparm;
-                jsi = (int)specmult;
-                fs = specmult - (double)jsi;
-            }
-            const double *Sf = tb.K + gd.off_sflux + (size_t)jsi * gd.ng;
-            double s0 = Sf[0];
-            double s1 = gd.nsf > 1 ? Sf[gd.ng] : s0;
-            sfluxzen = gd.nsf > 1 ? s0 + fs * (s1 - s0) : gd.scalekur * s0;
+            if (cur >= 1. - c.cldf[l]) cmask |= (uint64_t)1 << l;
+            prev = cur;
         }
-        const double adjflux = 1.0 * (a.solcon / 1.36822e+03);   // adjes = 1, dyofyr = 0 (SW:10623-10626, 9735-9739)
-        const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
-        const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
+    }
+    const int col_cloudy = a.icloud != 0 ? __syncthreads_or(cmask != 0) : 0;
 
+    const double prmu0 = coszrs <= 1.e-10 ? 1.e-10 : coszrs;   // SW:9254-9255
+    // solar source at the layer selected per band (SW:3363-3380, 3533-3538, 4297) -> incoming flux
+    double sfluxzen;
+    {
+        int laysolfr;
+        if (gd.solar_kind == SOL_UPPER) {
+            laysolfr = nlay;   // 1-based, as in the reference
+            for (int lay = laytrop + 1; lay <= nlay; ++lay)
+                if (c.jp[lay - 2] < gd.layreffr && c.jp[lay - 1] >= gd.layreffr) laysolfr = lay;
+        } else {
+            laysolfr = laytrop;
+            if (gd.solar_kind == SOL_LOWER)
+                for (int lay = 1; lay <= laytrop; ++lay)
+                    if (c.jp[lay - 1] < gd.layreffr && c.jp[lay] >= gd.layreffr)
+                        laysolfr = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+        }
+        const int ks = laysolfr - 1;
+        const bool lowers = (laysolfr <= laytrop);
+        const GRegime &R = lowers ? gd.lo : gd.up;
+        int jsi = 0;
+        double fs = 0.;
+        if (gd.nsf > 1) {
+            const int spa = (R.cfg >> CFG_SPA_SHIFT) & 7, spb = (R.cfg >> CFG_SPB_SHIFT) & 7;
+            double colA = c.col[spa * nlp + ks], colB = c.col[spb * nlp + ks];
+            double speccomb = colA + R.strrat * colB;
+            double specparm = colA / speccomb;
+            specparm = specparm >= tb.oneminus ? tb.oneminus : specparm;
+            double specmult = ((R.cfg & CFG_MULT4) ? 4. : 8.) * specparm;
+            jsi = (int)specmult;
+            fs = specmult - (double)jsi;
+        }
+        const double *Sf = tb.K + gd.off_sflux + (size_t)jsi * gd.ng;
+        double s0 = Sf[0];
+        double s1 = gd.nsf > 1 ? Sf[gd.ng] : s0;
+        sfluxzen = gd.nsf > 1 ? s0 + fs * (s1 - s0) : gd.scalekur * s0;
+    }
+    const double adjflux = 1.0 * (a.solcon / 1.36822e+03);   // adjes = 1, dyofyr = 0 (SW:10623-10626, 9735-9739)
+    const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
+    const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
+    double *ck = c.ckpt + (size_t)wave * nblk * 2 * 64;
+    int bad = 0;
+
+    // One spcvmc_sw pass of this wave's 56 sub-columns: aer_on = with aerosol optical depth, mask = the
+    // sub-column's cloudy layers (0: clear sky).  Fluxes per level go to flux[2l], flux[2l+1].
+    auto run_pass = [&](const bool aer_on, const uint64_t mask, double *flux, const bool want_sfc) {
         // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
-        double *ck = c.ckpt + (size_t)wave * nblk * 2 * 64;
         double rup = alb, rupd = alb;
         for (int k = 0; k < nlay; ++k) {
             if ((k & (BLK - 1)) == 0) {
@@ -649,7 +934,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             }
             RT rt;
             double dummy;
-            layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy);
+            layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy, (mask >> k) & 1, iceflag, a.cldtab, &bad);
             // vrtqdr_sw, SW:7997-8015
             double zreflect = frcp(1. -rupd * rt.refd);
             double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
@@ -668,8 +953,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             for (int j = 0; j < BLK; ++j) {
                 const int k = b * BLK + j;
                 if (k < nlay) {
-                    if (aer_on) layer_rt<true>(tb, c, L, k, k < laytrop, true, prmu0, rt[j], dn[j]);
-                    else { layer_rt<false>(tb, c, L, k, k < laytrop, false, prmu0, rt[j], dn[j]); dn[j] = 1.; }
+                    const bool cl = (mask >> k) & 1;
+                    if (want_sfc) layer_rt<true>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad);
+                    else { layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad); dn[j] = 1.; }
                 } else {
                     rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
                 }
@@ -704,8 +990,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             double fd = tdbt + (tdn - tdbt + tdbt * alb * rdnd) * zreflect;
             double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
             if (lane == 0) { flux[0] = su; flux[1] = sd; }
-            if (pass == 0) {
-                // surface-only direct / UV-visible / near-IR sums (SW:8633-8647 at ikl = 1)
+            if (want_sfc) {
+                // surface-only direct / UV-visible / near-IR sums of the total-sky call (SW:8633-8647 at ikl = 1)
                 const double uv = gd.uvband ? zincflx : 0., ni = gd.uvband ? 0. : zincflx;
                 double dirbb = wave_sum(zincflx * tdbt_nodel);
                 double uvfd = wave_sum(uv * fd), uvdir = wave_sum(uv * tdbt_nodel);
@@ -716,7 +1002,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
                 }
             }
         }
+    };
+
+    double *flux = c.flux + (size_t)wave * nlev * 2;
+    if (pass == 1 && a.clean <= 0) {
+        // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
+        for (int l = lane; l < nlev; l += 64) { flux[2 * l] = 0.; flux[2 * l + 1] = 0.; }
+    } else {
+        // waves 0,1: total sky with aerosol (call #1); waves 2,3: total sky without aerosol (call #2, SW:9439-9467)
+        run_pass(pass == 0, cmask, flux, pass == 0);
     }
+    if (col_cloudy) {
+        // a cloudy column also needs the clear-sky fluxes of call #1 (zbbcu / zbbcd, SW:8405-8416, 8590-8593):
+        // a third pass without cloud on the two aerosol waves; cloud-free columns reuse the total-sky result
+        __syncthreads();
+        if (pass == 0) run_pass(true, 0, c.fluxc + (size_t)wave * nlev * 2, false);
+    }
+    if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
 
     // ======================= epilogue: lanes = levels =======================
@@ -726,10 +1028,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
         const int l = tid;
         const double up = fA0[2 * l] + fA1[2 * l], dn = fA0[2 * l + 1] + fA1[2 * l + 1];
         const double upc = fC0[2 * l] + fC1[2 * l], dnc = fC0[2 * l + 1] + fC1[2 * l + 1];
-        if (a.swupflx) {   // (i, kts:kte+2, j), SW:11156-11165; clear == total without cloud
+        // clear sky: third pass of a cloudy column, else identical to the total-sky result (SW:8428, 8556)
+        const double *fK0 = col_cloudy ? c.fluxc : fA0, *fK1 = col_cloudy ? c.fluxc + (size_t)nlev * 2 : fA1;
+        const double upk = fK0[2 * l] + fK1[2 * l], dnk = fK0[2 * l + 1] + fK1[2 * l + 1];
+        if (a.swupflx) {   // (i, kts:kte+2, j), SW:11156-11165
             const size_t q = base3f + (size_t)l * sk;
-            str(a.swupflx, q, r4, up); str(a.swupflxc, q, r4, up); str(a.swupflxcln, q, r4, upc);
-            str(a.swdnflx, q, r4, dn); str(a.swdnflxc, q, r4, dn); str(a.swdnflxcln, q, r4, dnc);
+            str(a.swupflx, q, r4, up); str(a.swupflxc, q, r4, upk); str(a.swupflxcln, q, r4, upc);
+            str(a.swdnflx, q, r4, dn); str(a.swdnflxc, q, r4, dnk); str(a.swdnflxcln, q, r4, dnc);
         }
         if (l < nk && a.rthratensw) {
             // heating rate of layer l, SW:9428-9434, then SW:11167-11170
@@ -743,8 +1048,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
         if (l == 0) {
             if (a.gsw) str(a.gsw, i2, r4, dn - up);
             if (a.swupt) {
-                str(a.swupb, i2, r4, up); str(a.swupbc, i2, r4, up); str(a.swupbcln, i2, r4, upc);
-                str(a.swdnb, i2, r4, dn); str(a.swdnbc, i2, r4, dn); str(a.swdnbcln, i2, r4, dnc);
+                str(a.swupb, i2, r4, up); str(a.swupbc, i2, r4, upk); str(a.swupbcln, i2, r4, upc);
+                str(a.swdnb, i2, r4, dn); str(a.swdnbc, i2, r4, dnk); str(a.swdnbcln, i2, r4, dnc);
             }
             const double *s0 = c.sfc, *s1 = c.sfc + 8;
             const double dirbb = s0[0] + s1[0], uvfd = s0[1] + s1[1], uvdir = s0[2] + s1[2], nifd = s0[3] + s1[3],
@@ -760,10 +1065,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             }
         }
         if (l == nlay) {
-            if (a.swcf) str(a.swcf, i2, r4, (dn - up) - (dn - up));   // SW:11126: clear == total without cloud
+            if (a.swcf) str(a.swcf, i2, r4, (dn - up) - (dnk - upk));   // SW:11126
             if (a.swupt) {
-                str(a.swupt, i2, r4, up); str(a.swuptc, i2, r4, up); str(a.swuptcln, i2, r4, upc);
-                str(a.swdnt, i2, r4, dn); str(a.swdntc, i2, r4, dn); str(a.swdntcln, i2, r4, dnc);
+                str(a.swupt, i2, r4, up); str(a.swuptc, i2, r4, upk); str(a.swuptcln, i2, r4, upc);
+                str(a.swdnt, i2, r4, dn); str(a.swdntc, i2, r4, dnk); str(a.swdntcln, i2, r4, dnc);
             }
         }
     }
@@ -774,8 +1079,8 @@ size_t sw_lds_bytes(int nk)
 {
     const int nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
-    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND) + (size_t)4 * nblk * 2 * 64 + (size_t)4 * nlev * 2 + 32;
-    size_t ni = (size_t)nlp * 5 + 1;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)4 * nblk * 2 * 64 + (size_t)6 * nlev * 2 + 32;
+    size_t ni = (size_t)nlp * 8 + 1 + 4;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
 
@@ -818,6 +1123,11 @@ hipError_t sw_upload_constants(hipStream_t)
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_o3ann), o3ann, sizeof o3ann)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ppwrkh), ppwrkh, sizeof ppwrkh)) != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_wavemid), wavemid, sizeof wavemid);
+}
+
+hipError_t sw_upload_retab()
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_retab), CLD_RETAB, sizeof(double) * 95);
 }
 
 hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream)

@@ -38,12 +38,21 @@ _OUT2 = ["coszr", "gsw", "swcf",
 _OUT3F = ["swupflx", "swupflxc", "swupflxcln", "swdnflx", "swdnflxc", "swdnflxcln"]
 
 
+# cloud arguments of RRTMG_SWRAD / RRTMG_LWRAD used when icloud /= 0 (SW:9901-9945)
+_CLD3 = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d", "re_cloud", "re_ice", "re_snow", "qndrop3d"]
+_CLD2 = ["xland", "xice", "snow"]
+_CLDFLAGS = ["has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "is_cammgmp_used", "f_ice_phy", "mp_physics"]
+
+
 class SwradArgs(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("ims", "ime", "jms", "jme", "kms", "kme",
                                          "its", "ite", "jts", "jte", "kts", "kte", "real_bytes", "mem")]
                 + [("stream", C.c_void_p), ("solcon", C.c_double)]
                 + [(n, C.c_int) for n in ("aer_ra_feedback", "clean_atm_diag", "icloud", "o3input")]
-                + [(n, C.c_void_p) for n in _IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F])
+                + [(n, C.c_void_p) for n in _IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F]
+                + [(n, C.c_void_p) for n in _CLD3 + _CLD2]
+                + [(n, C.c_int) for n in _CLDFLAGS]
+                + [("g", C.c_double)])
 
 
 _lib = None
@@ -109,7 +118,9 @@ def _ptr(a):
 
 
 def rrtmg_swrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
-                solcon, aer_ra_feedback=0, clean_atm_diag=0, icloud=0, o3input=0, stream=None, **arrays):
+                solcon, aer_ra_feedback=0, clean_atm_diag=0, icloud=0, o3input=0, stream=None,
+                has_reqc=0, has_reqi=0, has_reqs=0, warm_rain=False, progn=0, is_cammgmp_used=False, f_ice_phy=False,
+                mp_physics=0, g=9.81, **arrays):
     """RRTMG_SWRAD (SW:9901-11207).  Keyword names are the reference's dummy
     argument names in lower case; arrays absent from ``arrays`` are "not
     PRESENT".  3-D arrays have shape (nj, nk_mem, ni) == Fortran (ims:ime,kms:kme,jms:jme)."""
@@ -123,7 +134,11 @@ def rrtmg_swrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
     a.clean_atm_diag = int(clean_atm_diag)
     a.icloud = int(icloud)
     a.o3input = int(o3input)
-    known = set(_IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F)
+    for n, v in dict(has_reqc=has_reqc, has_reqi=has_reqi, has_reqs=has_reqs, warm_rain=warm_rain, progn=progn,
+                     is_cammgmp_used=is_cammgmp_used, f_ice_phy=f_ice_phy, mp_physics=mp_physics).items():
+        setattr(a, n, int(v))
+    a.g = float(g)
+    known = set(_IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F + _CLD3 + _CLD2)
     unknown = set(arrays) - known
     if unknown:
         raise TypeError(f"unknown RRTMG_SWRAD arguments: {sorted(unknown)}")
