@@ -16,7 +16,10 @@ class LwColumnIn(C.Structure):
     _fields_ = [("nlay", C.c_int), ("play", dp), ("plev", dp), ("tlay", dp), ("tlev", dp), ("tsfc", C.c_double),
                 ("h2ovmr", dp), ("o3vmr", dp), ("co2vmr", dp), ("ch4vmr", dp), ("n2ovmr", dp), ("o2vmr", dp),
                 ("cfc11vmr", dp), ("cfc12vmr", dp), ("cfc22vmr", dp), ("ccl4vmr", dp), ("emis", dp),
-                ("tauaer", dp), ("clean_atm_diag", C.c_int)]
+                ("tauaer", dp), ("clean_atm_diag", C.c_int),
+                ("cldfrac", dp), ("clwp", dp), ("ciwp", dp), ("cswp", dp), ("rel", dp), ("rei", dp), ("res", dp),
+                ("inflglw", C.c_int), ("iceflglw", C.c_int), ("liqflglw", C.c_int), ("seed_real4", C.c_int),
+                ("cldfmc_out", dp)]
 
 
 class LwColumnOut(C.Structure):
@@ -82,6 +85,18 @@ class LwOracle:
             keep = {k: np.ascontiguousarray(cols[k][ic], dtype=np.float64) for k in LW_COL_IN}
             ci = LwColumnIn(nlay, _p(keep["play"]), _p(keep["plev"]), _p(keep["tlay"]), _p(keep["tlev"]),
                             float(cols["tsfc"][ic]), *[_p(keep[k]) for k in LW_COL_IN[4:]], clean)
+            if "cldfrac" in cols:   # in-cloud state for the McICA path (see rrtmg_oracle.h)
+                ck = {k: np.ascontiguousarray(cols[k][ic], dtype=np.float64)
+                      for k in ("cldfrac", "clwp", "ciwp", "cswp", "rel", "rei", "res")}
+                keep.update(ck)
+                for k in ck:
+                    setattr(ci, k, _p(ck[k]))
+                fl = cols["cldflags"][ic] if np.ndim(cols["cldflags"]) > 1 else cols["cldflags"]
+                ci.inflglw, ci.iceflglw, ci.liqflglw = int(fl[0]), int(fl[1]), int(fl[2])
+                ci.seed_real4 = int(cols.get("seed_real4", 0))
+                keep["mask"] = np.zeros((140, nlay))
+                ci.cldfmc_out = _p(keep["mask"])
+                out.setdefault("cldfmc", np.zeros((ncol, 140, nlay)))
             rows = [np.zeros(out[n].shape[1]) for n in LW_COL_OUT]
             co = LwColumnOut(*[_p(r) for r in rows])
             rc = _lib().lw_oracle_rrtmg_lw(self.h, C.byref(ci), C.byref(co))
@@ -89,6 +104,8 @@ class LwOracle:
                 raise RuntimeError(f"lw_oracle_rrtmg_lw rc={rc}")
             for n, r in zip(LW_COL_OUT, rows):
                 out[n][ic] = r
+            if "cldfrac" in cols:
+                out["cldfmc"][ic] = keep["mask"]
         return out
 
 

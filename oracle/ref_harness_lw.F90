@@ -6,7 +6,12 @@
 ! tables from a RRTMG_LW_DATA-layout file (READ field order of lw_kgb01..16,
 ! LW:13021-14387), calls rrtmg_lw_ini and rrtmg_lw (clean + aerosol calls).
 !
-! usage: ref_lw <tables> <columns.bin> <out.bin>
+! usage: ref_lw <tables> <columns.bin> <out.bin> [clouds]
+!
+! With the fourth argument "clouds" every column record is followed by the in-cloud state RRTMG_LWRAD hands to the
+! McICA generator (cldfrac, clwp, ciwp, cswp, rel, rei, res per layer and inflglw/iceflglw/liqflglw); the harness
+! then calls the reference's mcica_subcol_lw (icld = 2, permuteseed = 150, irng = 0 as at LW:12553-12563) before
+! rrtmg_lw, and also dumps the sub-column cloud mask.
 
 subroutine wrf_error_fatal(msg)
   character(len=*), intent(in) :: msg
@@ -19,8 +24,13 @@ program ref_lw
   use parrrtm, only : nbndlw, ngptlw
   use rrtmg_lw_init, only : rrtmg_lw_ini
   use rrtmg_lw_rad, only : rrtmg_lw
+  use mcica_subcol_gen_lw, only : mcica_subcol_lw
   implicit none
-  character(len=512) :: ftab, fcol, fout
+  character(len=512) :: ftab, fcol, fout, fmode
+  logical :: clouds
+  integer(kind=im) :: irng, permuteseed, iflags(3)
+  real(kind=rb), allocatable :: cldfrac(:,:), clwp(:,:), ciwp(:,:), cswp(:,:), rel(:,:), rei(:,:), res(:,:)
+  real(kind=rb), allocatable :: taucld(:,:,:)
   integer :: ncol, nlay, iclean, nrep, ic, irep
   integer(kind=im) :: icld, inflglw, iceflglw, liqflglw
   real(kind=rb) :: cpdair
@@ -38,6 +48,11 @@ program ref_lw
   call get_command_argument(1, ftab)
   call get_command_argument(2, fcol)
   call get_command_argument(3, fout)
+  clouds = .false.
+  if (command_argument_count() >= 4) then
+     call get_command_argument(4, fmode)
+     clouds = trim(fmode) == 'clouds'
+  end if
   call read_tables(trim(ftab))
   cpdair = 7.0_rb * 287.0_rb / 2.0_rb
   call rrtmg_lw_ini(cpdair)
@@ -52,6 +67,8 @@ program ref_lw
   allocate(cswpmcl(ngptlw,1,nlay), reicmcl(1,nlay), relqmcl(1,nlay), resnmcl(1,nlay), tauaer(1,nlay,nbndlw))
   allocate(uflx(1,nlay+1), dflx(1,nlay+1), hr(1,nlay), uflxc(1,nlay+1), dflxc(1,nlay+1), hrc(1,nlay))
   allocate(uflxcln(1,nlay+1), dflxcln(1,nlay+1), buf(nlay*nbndlw))
+  allocate(cldfrac(1,nlay), clwp(1,nlay), ciwp(1,nlay), cswp(1,nlay), rel(1,nlay), rei(1,nlay), res(1,nlay))
+  allocate(taucld(nbndlw,1,nlay))
   cldfmcl = 0._rb; taucmcl = 0._rb; ciwpmcl = 0._rb; clwpmcl = 0._rb; cswpmcl = 0._rb
   reicmcl = 10._rb; relqmcl = 10._rb; resnmcl = 10._rb
   inflglw = 2; iceflglw = 3; liqflglw = 1
@@ -63,6 +80,16 @@ program ref_lw
      read(21) cfc11vmr(1,:), cfc12vmr(1,:), cfc22vmr(1,:), ccl4vmr(1,:)
      read(21) emis(1,:)
      read(21) buf; tauaer(1,:,:) = reshape(buf, (/nlay, nbndlw/))
+     if (clouds) then
+        read(21) cldfrac(1,:), clwp(1,:), ciwp(1,:), cswp(1,:), rel(1,:), rei(1,:), res(1,:)
+        read(21) iflags
+        inflglw = iflags(1); iceflglw = iflags(2); liqflglw = iflags(3)
+        taucld = 0._rb
+        icld = 2; irng = 0; permuteseed = 150
+        call mcica_subcol_lw(1, 1, nlay, icld, permuteseed, irng, play, &
+             cldfrac, ciwp, clwp, cswp, rei, rel, res, taucld, cldfmcl, &
+             ciwpmcl, clwpmcl, cswpmcl, reicmcl, relqmcl, resnmcl, taucmcl)
+     end if
      do irep = 1, max(1, nrep)
         icld = 2
         call rrtmg_lw(1, nlay, icld, play, plev, tlay, tlev, tsfc, &
@@ -71,6 +98,7 @@ program ref_lw
              tauaer, uflx, dflx, hr, uflxc, dflxc, hrc, uflxcln, dflxcln, iclean)
      end do
      write(22) uflx(1,:), dflx(1,:), hr(1,:), uflxc(1,:), dflxc(1,:), hrc(1,:), uflxcln(1,:), dflxcln(1,:)
+     if (clouds) write(22) cldfmcl(:,1,:)
   end do
   call system_clock(t1)
   secs = real(t1 - t0, 8) / real(trate, 8)

@@ -917,7 +917,193 @@ static void rtrnmc_lw(const LwTables *t, const LwCol *c, const double (*taut)[MA
     htr[nlayers] = 0.0;
 }
 
-/* rrtmg_lw for one cloud-free column, LW:10942-11062 (+ inatm LW:11248-11340) */
+/* rtrnmc with McICA clouds, LW:3135-3410 in full: cldfmc / taucmc are [LW_NGPT][nlayers] (0-based layers).  A layer
+ * in which ANY sub-column is cloudy (icldlyr) takes the three-regime "cloudy" arithmetic for every g-point, and the
+ * clear-sky stream is carried separately from the first cloudy layer downwards (iclddn). */
+static void rtrnmc_lw_cloudy(const LwTables *t, const LwCol *c, const double (*taut)[MAXLAY], const double *cldfmc,
+                             const double *taucmc, double *totuflux, double *totdflux, double *htr, double *totuclfl,
+                             double *totdclfl, double *htrc)
+{
+    static const double a0[LW_NBND] = {1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33,
+                                       1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
+    static const double a1[LW_NBND] = {0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40,
+                                       -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+    static const double a2[LW_NBND] = {0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062,
+                                       0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+    const double wtdiff = 0.5, rec_6 = 0.166667;
+    const int nlayers = c->nlayers;
+    double secdiff[LW_NBND], urad[MAXLAY], drad[MAXLAY], clrurad[MAXLAY], clrdrad[MAXLAY];
+    double atrans[MAXLAY], atot[MAXLAY], bbugas[MAXLAY], bbutot[MAXLAY], fnet[MAXLAY], fnetc[MAXLAY];
+    int icldlyr[MAXLAY];
+    for (int ibnd = 1; ibnd <= LW_NBND; ++ibnd) {
+        if (ibnd == 1 || ibnd == 4 || ibnd >= 10) secdiff[ibnd - 1] = 1.66;
+        else {
+            secdiff[ibnd - 1] = a0[ibnd - 1] + a1[ibnd - 1] * exp(a2[ibnd - 1] * c->pwvcm);
+            if (secdiff[ibnd - 1] > 1.80) secdiff[ibnd - 1] = 1.80;
+            if (secdiff[ibnd - 1] < 1.50) secdiff[ibnd - 1] = 1.50;
+        }
+    }
+    for (int lay = 0; lay <= nlayers; ++lay) {
+        urad[lay] = 0.0; drad[lay] = 0.0; totuflux[lay] = 0.0; totdflux[lay] = 0.0;
+        clrurad[lay] = 0.0; clrdrad[lay] = 0.0; totuclfl[lay] = 0.0; totdclfl[lay] = 0.0;
+    }
+    for (int lay = 1; lay <= nlayers; ++lay) {
+        icldlyr[lay] = 0;
+        for (int ig = 0; ig < LW_NGPT; ++ig)
+            if (cldfmc[(size_t)ig * nlayers + lay - 1] == 1.) icldlyr[lay] = 1;
+    }
+    int igc = 1;
+    for (int iband = 1; iband <= LW_NBND; ++iband) {
+        for (; igc <= ngs[iband - 1]; ++igc) {
+            const double *cf = cldfmc + (size_t)(igc - 1) * nlayers, *tc = taucmc + (size_t)(igc - 1) * nlayers;
+            double radld = 0., radclrd = 0.;
+            int iclddn = 0;
+            for (int lev = nlayers; lev >= 1; --lev) {
+                const double cfm = cf[lev - 1];
+                double odcld = 0., efclfrac = 0.;
+                if (cfm == 1.) {
+                    odcld = secdiff[iband - 1] * tc[lev - 1];
+                    double transcld = exp(-odcld);
+                    double abscld = 1. - transcld;
+                    efclfrac = abscld * cfm;
+                }
+                double plfrac = c->fracs[igc - 1][lev];
+                double blay = c->planklay[iband - 1][lev];
+                double dplankup = c->planklev[iband - 1][lev] - blay;
+                double dplankdn = c->planklev[iband - 1][lev - 1] - blay;
+                double odepth = secdiff[iband - 1] * taut[igc - 1][lev];
+                if (odepth < 0.0) odepth = 0.0;
+                double bbd;
+                if (icldlyr[lev] == 1) {
+                    iclddn = 1;
+                    double odtot = odepth + odcld;
+                    double gassrc, bbdtot;
+                    if (odtot < 0.06) {
+                        atrans[lev] = odepth - 0.5 * odepth * odepth;
+                        double odepth_rec = rec_6 * odepth;
+                        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans[lev];
+                        atot[lev] = odtot - 0.5 * odtot * odtot;
+                        double odtot_rec = rec_6 * odtot;
+                        bbdtot = plfrac * (blay + dplankdn * odtot_rec);
+                        bbd = plfrac * (blay + dplankdn * odepth_rec);
+                        bbugas[lev] = plfrac * (blay + dplankup * odepth_rec);
+                        bbutot[lev] = plfrac * (blay + dplankup * odtot_rec);
+                    } else if (odepth <= 0.06) {
+                        atrans[lev] = odepth - 0.5 * odepth * odepth;
+                        double odepth_rec = rec_6 * odepth;
+                        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans[lev];
+                        odtot = odepth + odcld;
+                        double tblind = odtot / (t->bpade + odtot);
+                        int ittot = (int)(10000.0 * tblind + 0.5);
+                        double tfactot = t->tfn_tbl[ittot];
+                        bbdtot = plfrac * (blay + tfactot * dplankdn);
+                        bbd = plfrac * (blay + dplankdn * odepth_rec);
+                        atot[lev] = 1. - t->exp_tbl[ittot];
+                        bbugas[lev] = plfrac * (blay + dplankup * odepth_rec);
+                        bbutot[lev] = plfrac * (blay + tfactot * dplankup);
+                    } else {
+                        double tblind = odepth / (t->bpade + odepth);
+                        int itgas = (int)(10000.0 * tblind + 0.5);
+                        odepth = t->tau_tbl[itgas];
+                        atrans[lev] = 1. - t->exp_tbl[itgas];
+                        double tfacgas = t->tfn_tbl[itgas];
+                        gassrc = atrans[lev] * plfrac * (blay + tfacgas * dplankdn);
+                        odtot = odepth + odcld;
+                        tblind = odtot / (t->bpade + odtot);
+                        int ittot = (int)(10000.0 * tblind + 0.5);
+                        double tfactot = t->tfn_tbl[ittot];
+                        bbdtot = plfrac * (blay + tfactot * dplankdn);
+                        bbd = plfrac * (blay + tfacgas * dplankdn);
+                        atot[lev] = 1. - t->exp_tbl[ittot];
+                        bbugas[lev] = plfrac * (blay + tfacgas * dplankup);
+                        bbutot[lev] = plfrac * (blay + tfactot * dplankup);
+                    }
+                    radld = radld - radld * (atrans[lev] + efclfrac * (1. - atrans[lev])) + gassrc +
+                            cfm * (bbdtot * atot[lev] - gassrc);
+                    drad[lev - 1] = drad[lev - 1] + radld;
+                } else {
+                    if (odepth <= 0.06) {
+                        atrans[lev] = odepth - 0.5 * odepth * odepth;
+                        odepth = rec_6 * odepth;
+                        bbd = plfrac * (blay + dplankdn * odepth);
+                        bbugas[lev] = plfrac * (blay + dplankup * odepth);
+                    } else {
+                        double tblind = odepth / (t->bpade + odepth);
+                        int itr = (int)(10000.0 * tblind + 0.5);
+                        double transc = t->exp_tbl[itr];
+                        atrans[lev] = 1. - transc;
+                        double tausfac = t->tfn_tbl[itr];
+                        bbd = plfrac * (blay + tausfac * dplankdn);
+                        bbugas[lev] = plfrac * (blay + tausfac * dplankup);
+                    }
+                    radld = radld + (bbd - radld) * atrans[lev];
+                    drad[lev - 1] = drad[lev - 1] + radld;
+                }
+                if (iclddn == 1) {
+                    radclrd = radclrd + (bbd - radclrd) * atrans[lev];
+                    clrdrad[lev - 1] = clrdrad[lev - 1] + radclrd;
+                } else {
+                    radclrd = radld;
+                    clrdrad[lev - 1] = drad[lev - 1];
+                }
+            }
+            double rad0 = c->fracs[igc - 1][1] * c->plankbnd[iband - 1];
+            double reflect = 1. - c->semiss[iband - 1];
+            double radlu = rad0 + reflect * radld;
+            double radclru = rad0 + reflect * radclrd;
+            urad[0] = urad[0] + radlu;
+            clrurad[0] = clrurad[0] + radclru;
+            for (int lev = 1; lev <= nlayers; ++lev) {
+                const double cfm = cf[lev - 1];
+                if (icldlyr[lev] == 1) {
+                    double efclfrac = 0.;
+                    if (cfm == 1.) efclfrac = (1. - exp(-(secdiff[iband - 1] * tc[lev - 1]))) * cfm;
+                    double gassrc = bbugas[lev] * atrans[lev];
+                    radlu = radlu - radlu * (atrans[lev] + efclfrac * (1. - atrans[lev])) + gassrc +
+                            cfm * (bbutot[lev] * atot[lev] - gassrc);
+                    urad[lev] = urad[lev] + radlu;
+                } else {
+                    radlu = radlu + (bbugas[lev] - radlu) * atrans[lev];
+                    urad[lev] = urad[lev] + radlu;
+                }
+                if (iclddn == 1) {
+                    radclru = radclru + (bbugas[lev] - radclru) * atrans[lev];
+                    clrurad[lev] = clrurad[lev] + radclru;
+                } else {
+                    radclru = radlu;
+                    clrurad[lev] = urad[lev];
+                }
+            }
+        }
+        for (int lev = nlayers; lev >= 0; --lev) {
+            double uflux = urad[lev] * wtdiff, dflux = drad[lev] * wtdiff;
+            urad[lev] = 0.0; drad[lev] = 0.0;
+            totuflux[lev] = totuflux[lev] + uflux * delwave[iband - 1];
+            totdflux[lev] = totdflux[lev] + dflux * delwave[iband - 1];
+            double uclfl = clrurad[lev] * wtdiff, dclfl = clrdrad[lev] * wtdiff;
+            clrurad[lev] = 0.0; clrdrad[lev] = 0.0;
+            totuclfl[lev] = totuclfl[lev] + uclfl * delwave[iband - 1];
+            totdclfl[lev] = totdclfl[lev] + dclfl * delwave[iband - 1];
+        }
+    }
+    totuflux[0] = totuflux[0] * t->fluxfac; totdflux[0] = totdflux[0] * t->fluxfac;
+    fnet[0] = totuflux[0] - totdflux[0];
+    totuclfl[0] = totuclfl[0] * t->fluxfac; totdclfl[0] = totdclfl[0] * t->fluxfac;
+    fnetc[0] = totuclfl[0] - totdclfl[0];
+    for (int lev = 1; lev <= nlayers; ++lev) {
+        totuflux[lev] = totuflux[lev] * t->fluxfac; totdflux[lev] = totdflux[lev] * t->fluxfac;
+        fnet[lev] = totuflux[lev] - totdflux[lev];
+        totuclfl[lev] = totuclfl[lev] * t->fluxfac; totdclfl[lev] = totdclfl[lev] * t->fluxfac;
+        fnetc[lev] = totuclfl[lev] - totdclfl[lev];
+        int l = lev - 1;
+        htr[l] = t->heatfac * (fnet[l] - fnet[lev]) / (c->pz[l] - c->pz[lev]);
+        htrc[l] = t->heatfac * (fnetc[l] - fnetc[lev]) / (c->pz[l] - c->pz[lev]);
+    }
+    htr[nlayers] = 0.0;
+    htrc[nlayers] = 0.0;
+}
+
+/* rrtmg_lw for one column, LW:10942-11062 (+ inatm LW:11248-11340) */
 int lw_oracle_rrtmg_lw(const LwTables *t, const LwColumnIn *in, LwColumnOut *out)
 {
     const int nlayers = in->nlay;
@@ -972,6 +1158,31 @@ int lw_oracle_rrtmg_lw(const LwTables *t, const LwColumnIn *in, LwColumnOut *out
                 taut[igc][k] = c->taug[igc][k] + in->tauaer[ib * nlayers + k - 1];   /* LW:11004-11008 */
 
     double fu[MAXLAY], fd[MAXLAY], hr[MAXLAY];
+    if (in->cldfrac) {
+        /* mcica_subcol_lw (called by RRTMG_LWRAD with permuteseed = 150, LW:12555-12563) + cldprmc (LW:10975) */
+        const size_t n = (size_t)LW_NGPT * nlayers;
+        double *cldfmc = (double *)malloc(2 * n * sizeof(double)), *taucmc = cldfmc + n;
+        int rc = oracle_mcica(LW_NGPT, nlayers, in->play, in->cldfrac, 150, in->seed_real4, cldfmc);
+        if (!rc) rc = lw_oracle_cldprmc(nlayers, in->inflglw, in->iceflglw, in->liqflglw, cldfmc, in->ciwp, in->clwp,
+                                        in->cswp, in->rei, in->rel, in->res, taucmc, NULL, 0);
+        if (rc) { free(cldfmc); free(taut); free(c); return 10 + rc; }
+        if (in->cldfmc_out) memcpy(in->cldfmc_out, cldfmc, n * sizeof(double));
+        double fuc[MAXLAY], fdc[MAXLAY], hrc[MAXLAY];
+        if (in->clean_atm_diag > 0) {
+            rtrnmc_lw_cloudy(t, c, (const double(*)[MAXLAY])c->taug, cldfmc, taucmc, fu, fd, hr, fuc, fdc, hrc);
+            for (int k = 0; k <= nlayers; ++k) { out->uflxcln[k] = fu[k]; out->dflxcln[k] = fd[k]; }
+        } else {
+            for (int k = 0; k <= nlayers; ++k) { out->uflxcln[k] = 0.0; out->dflxcln[k] = 0.0; }
+        }
+        rtrnmc_lw_cloudy(t, c, (const double(*)[MAXLAY])taut, cldfmc, taucmc, fu, fd, hr, fuc, fdc, hrc);
+        for (int k = 0; k <= nlayers; ++k) {
+            out->uflx[k] = fu[k]; out->dflx[k] = fd[k];
+            out->uflxc[k] = fuc[k]; out->dflxc[k] = fdc[k];
+        }
+        for (int k = 0; k <= nlayers - 1; ++k) { out->hr[k] = hr[k]; out->hrc[k] = hrc[k]; }
+        free(cldfmc); free(taut); free(c);
+        return 0;
+    }
     if (in->clean_atm_diag > 0) {
         rtrnmc_lw(t, c, (const double(*)[MAXLAY])c->taug, fu, fd, hr);                 /* LW:11023-11027 */
         for (int k = 0; k <= nlayers; ++k) { out->uflxcln[k] = fu[k]; out->dflxcln[k] = fd[k]; }

@@ -86,6 +86,11 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
                        double *rel, double *rei, double *res, int *flags3);
 
 /* McICA generator and cloud optics (rrtmg_sw_cloud_oracle.c) */
+int oracle_mcica(int nsub, int nlay, const double *play, const double *cldfrac, int change_seed, int real4,
+                 double *cldfmc);
+int lw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *ciwp,
+                      const double *clwp, const double *cswp, const double *rei, const double *rel, const double *res,
+                      double *taucmc, char *err, int errlen);
 int sw_oracle_mcica(int nlay, const double *play, const double *cldfrac, int change_seed, int real4, double *cldfmc);
 int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *ciwp,
                       const double *clwp, const double *cswp, const double *rei, const double *rel, const double *res,
@@ -166,6 +171,11 @@ typedef struct {
     const double *emis;      /* [LW_NBND] */
     const double *tauaer;
     int clean_atm_diag;
+    /* clouds (cldfrac == NULL: cloud-free): in-cloud state on all nlay layers (zero above the model top), as
+     * RRTMG_LWRAD hands it to mcica_subcol_lw (LW:12335-12563; icld = 2, permuteseed = 150, irng = 0) */
+    const double *cldfrac, *clwp, *ciwp, *cswp, *rel, *rei, *res;
+    int inflglw, iceflglw, liqflglw, seed_real4;
+    double *cldfmc_out;      /* optional [LW_NGPT][nlay] */
 } LwColumnIn;
 
 typedef struct {

@@ -51,28 +51,35 @@ static int32_t kiss_seed(double play_mb, int real4)
 }
 
 /* mcica_subcol_sw + generate_stochastic_clouds_sw for one column, icld = 2 (maximum-random), irng = 0.
- * play [nlay] in mb bottom->top, cldfrac [nlay]; cldfmc [SW_NGPT][nlay] (0 or 1).  Returns nonzero on the
- * reference's STOP conditions. */
-int sw_oracle_mcica(int nlay, const double *play, const double *cldfrac, int change_seed, int real4, double *cldfmc)
+ * play [nlay] in mb bottom->top, cldfrac [nlay]; cldfmc [nsub][nlay] (0 or 1).  Returns nonzero on the
+ * reference's STOP conditions.  The longwave generator (generate_stochastic_clouds, LW:2208-2578) is the same
+ * code with 140 sub-columns. */
+int oracle_mcica(int nsub, int nlay, const double *play, const double *cldfrac, int change_seed, int real4,
+                 double *cldfmc)
 {
     const double cldmin = 1.0e-20;
-    if (nlay < 4 || nlay > 256) return 1;
+    if (nlay < 4 || nlay > 256 || nsub > 140) return 1;
     if (play[0] * 1.e2 < play[1] * 1.e2) return 2;   /* KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS */
     double cldf[256];
     for (int l = 0; l < nlay; ++l) cldf[l] = cldfrac[l] < cldmin ? 0. : cldfrac[l];
     Kiss k = {kiss_seed(play[0], real4), kiss_seed(play[1], real4), kiss_seed(play[2], real4), kiss_seed(play[3], real4)};
     for (int i = 0; i < change_seed; ++i) (void)kiss_next(&k);
-    static _Thread_local double cdf[SW_NGPT][256];
-    for (int is = 0; is < SW_NGPT; ++is)
+    static _Thread_local double cdf[140][256];
+    for (int is = 0; is < nsub; ++is)
         for (int l = 0; l < nlay; ++l) cdf[is][l] = kiss_next(&k);
     for (int l = 1; l < nlay; ++l)
-        for (int is = 0; is < SW_NGPT; ++is) {
+        for (int is = 0; is < nsub; ++is) {
             if (cdf[is][l - 1] > 1. - cldf[l - 1]) cdf[is][l] = cdf[is][l - 1];
             else cdf[is][l] = cdf[is][l] * (1. - cldf[l - 1]);
         }
-    for (int is = 0; is < SW_NGPT; ++is)
+    for (int is = 0; is < nsub; ++is)
         for (int l = 0; l < nlay; ++l) cldfmc[is * nlay + l] = cdf[is][l] >= 1. - cldf[l] ? 1. : 0.;
     return 0;
+}
+
+int sw_oracle_mcica(int nlay, const double *play, const double *cldfrac, int change_seed, int real4, double *cldfmc)
+{
+    return oracle_mcica(SW_NGPT, nlay, play, cldfrac, change_seed, real4, cldfmc);
 }
 
 static int fail(char *err, int errlen, const char *msg)
@@ -312,5 +319,68 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
     }
     clwp[nk] = 0.; ciwp[nk] = 0.; cswp[nk] = 0.; rel[nk] = 10.; rei[nk] = 10.; res[nk] = 10.; cldfrac[nk] = 0.;
     flags3[0] = inflg; flags3[1] = iceflg; flags3[2] = liqflg;
+    return 0;
+}
+
+/* cldprmc (longwave), LW:2620-2914, inflag >= 2, liqflag = 1, iceflag = 3, 4 or 5: cloud absorption optical
+ * depth per sub-column and layer, taucmc [LW_NGPT][nlay]. */
+#include "lw_cld_tables.h"
+static const int ngc_lw[LW_NBND] = {10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2};
+
+int lw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const double *cldfmc, const double *ciwp,
+                      const double *clwp, const double *cswp, const double *rei, const double *rel, const double *res,
+                      double *taucmc, char *err, int errlen)
+{
+    const double cldmin = 1.e-20;
+    if (inflag < 2 || liqflag != 1 || iceflag < 3 || iceflag > 5)
+        return fail(err, errlen, "oracle cldprmc: only inflag>=2, liqflag=1, iceflag=3|4|5 are restated");
+    int ig = 0;
+    for (int ib = 0; ib < LW_NBND; ++ib)
+        for (int jg = 0; jg < ngc_lw[ib]; ++jg, ++ig)
+            for (int lay = 0; lay < nlay; ++lay) {
+                const size_t q = (size_t)ig * nlay + lay;
+                taucmc[q] = 0.;
+                const double cf = cldfmc[q];
+                const double ciwpmc = cf > 0. ? ciwp[lay] : 0., clwpmc = cf > 0. ? clwp[lay] : 0.;
+                const double cswpmc = cf > 0. ? cswp[lay] : 0.;
+                const double cwp = ciwpmc + clwpmc + cswpmc;
+                if (!(cf >= cldmin && (cwp >= cldmin || taucmc[q] >= cldmin))) continue;
+                double abscoice = 0., abscosno = 0., abscoliq = 0.;
+                if ((ciwpmc + cswpmc) == 0.0) {
+                } else {
+                    const double radice = rei[lay];
+                    if (radice < 5.0 || radice > 140.0)
+                        return fail(err, errlen, "ERROR: ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS");
+                    double factor = (radice - 2.) / 3.;
+                    int index = (int)factor;
+                    if (index == 46) index = 45;
+                    double fint = factor - (double)index;
+                    const double *a = LWCLD_ABSICE3[ib];
+                    abscoice = a[index - 1] + fint * (a[index] - (a[index - 1]));
+                }
+                if (cswpmc > 0.0 && iceflag == 5) {
+                    const double radsno = res[lay];
+                    if (radsno < 5.0 || radsno > 140.0)
+                        return fail(err, errlen, "ERROR: SNOW GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS");
+                    double factor = (radsno - 2.) / 3.;
+                    int index = (int)factor;
+                    if (index == 46) index = 45;
+                    double fint = factor - (double)index;
+                    const double *a = LWCLD_ABSICE3[ib];
+                    abscosno = a[index - 1] + fint * (a[index] - (a[index - 1]));
+                }
+                if (clwpmc == 0.0) {
+                } else {
+                    const double radliq = rel[lay];
+                    if (radliq < 2.5 || radliq > 60.) return fail(err, errlen, "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS");
+                    int index = (int)(radliq - 1.5);
+                    if (index == 0) index = 1;
+                    if (index == 58) index = 57;
+                    double fint = radliq - 1.5 - (double)index;
+                    const double *a = LWCLD_ABSLIQ1[ib];
+                    abscoliq = a[index - 1] + fint * (a[index] - (a[index - 1]));
+                }
+                taucmc[q] = ciwpmc * abscoice + clwpmc * abscoliq + cswpmc * abscosno;
+            }
     return 0;
 }

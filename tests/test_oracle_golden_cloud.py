@@ -45,6 +45,44 @@ def test_sw_cloud_fixture_properties(name):
     assert np.abs(g["ref_swuflxcln"][cloudy, -1] - g["ref_swuflxc"][cloudy, -1]).max() > 1.0
 
 
+LW_NAMES = ["lw_cloud_cols_k40_ice3", "lw_cloud_cols_k50_ice5"]
+
+
+@pytest.fixture(scope="module")
+def lw_oracle(oracle_mod, tmp_path_factory, wa):
+    from oracle import oracle_lw
+    p = tmp_path_factory.mktemp("tables_lw_cloud") / "RRTMG_LW_DATA"
+    wa.synth.write_lw_data(str(p), seed=20260003, real_bytes=8)
+    return oracle_lw.LwOracle(str(p))
+
+
+@pytest.mark.parametrize("name", LW_NAMES)
+def test_lw_cloudy_column_solver_matches_reference_bitwise(lw_oracle, name):
+    """mcica_subcol_lw (permuteseed 150) + cldprmc + the cloudy branches of rtrnmc, both calls."""
+    from oracle import oracle_lw
+    g, cols = _load(name)
+    out = lw_oracle.rrtmg_lw(cols, clean=1)
+    np.testing.assert_array_equal(out["cldfmc"], g["ref_cldfmc"], err_msg="McICA sub-column mask (KISS)")
+    for n in oracle_lw.LW_COL_OUT:
+        np.testing.assert_array_equal(out[n], g["ref_" + n], err_msg=n)
+
+
+@pytest.mark.parametrize("name", LW_NAMES)
+def test_lw_cloud_fixture_properties(name):
+    g, cols = _load(name)
+    mask = g["ref_cldfmc"]
+    cloudy = mask.sum(axis=(1, 2)) > 0
+    assert cloudy.any() and (~cloudy).any()
+    nk = cols["play"].shape[1] - 13
+    assert mask[:, :, nk:].sum() == 0                     # no cloud in the buffer layers
+    # cloud-free columns: clear == total exactly; clouds lower the outgoing longwave radiation
+    np.testing.assert_array_equal(g["ref_uflx"][~cloudy], g["ref_uflxc"][~cloudy])
+    assert (g["ref_uflx"][cloudy, -1] <= g["ref_uflxc"][cloudy, -1]).all()
+    assert (g["ref_uflxc"][cloudy, -1] - g["ref_uflx"][cloudy, -1]).max() > 5.0
+    # the two McICA streams differ: shortwave uses permuteseed 1, longwave 150
+    assert mask.shape[1] == 140
+
+
 def test_kiss_seed_single_precision_variant_differs(sw_oracle):
     """seed_real4 reproduces a stock REAL*4 build's seeds (fractional Pa in single precision): another mask."""
     g, cols = _load(NAMES[0])

@@ -88,8 +88,66 @@ def run_ref_sw_cloud(tables, cols, clean=1, nrep=1):
         return out, r.stdout
 
 
+def run_ref_lw_cloud(tables, cols, clean=1):
+    from tools.make_golden_lw import LW_COL_OUT
+    exe = os.path.join(REF, "ref_lw")
+    ncol, nlay = cols["play"].shape
+    with tempfile.TemporaryDirectory() as td:
+        fc, fo = os.path.join(td, "c.bin"), os.path.join(td, "o.bin")
+        with open(fc, "wb") as f:
+            f.write(struct.pack("<4i", ncol, nlay, clean, 1))
+            for ic in range(ncol):
+                for k in ("play", "plev", "tlay", "tlev"):
+                    f.write(cols[k][ic].astype("<f8").tobytes())
+                f.write(struct.pack("<d", cols["tsfc"][ic]))
+                for k in ("h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr", "cfc11vmr", "cfc12vmr",
+                          "cfc22vmr", "ccl4vmr", "emis"):
+                    f.write(cols[k][ic].astype("<f8").tobytes())
+                f.write(np.ascontiguousarray(cols["tauaer"][ic]).astype("<f8").tobytes())
+                for k in ("cldfrac", "clwp", "ciwp", "cswp", "rel", "rei", "res"):
+                    f.write(cols[k][ic].astype("<f8").tobytes())
+                f.write(cols["cldflags"][ic].astype("<i4").tobytes())
+        subprocess.run([exe, tables, fc, fo, "clouds"], check=True, capture_output=True, text=True)
+        raw = np.fromfile(fo, dtype="<f8")
+        per = sum(nlay + e for _, e in LW_COL_OUT) + 140 * nlay
+        raw = raw.reshape(ncol, per)
+        out, o = {}, 0
+        for name, e in LW_COL_OUT:
+            n = nlay + e
+            out[name] = raw[:, o:o + n].copy()
+            o += n
+        out["cldfmc"] = raw[:, o:].reshape(ncol, nlay, 140).transpose(0, 2, 1).copy()
+        return out
+
+
+def main_lw():
+    from tools.make_golden_lw import lw_columns_from_state
+    with tempfile.TemporaryDirectory() as td:
+        tab = os.path.join(td, "RRTMG_LW_DATA")
+        synth.write_lw_data(tab, seed=20260003, real_bytes=8)
+        for name, (ni, nj, nk, seed, iceflag) in {
+            "lw_cloud_cols_k40_ice3": (6, 4, 40, 20260031, 3),
+            "lw_cloud_cols_k50_ice5": (4, 3, 50, 20260032, 5),
+        }.items():
+            st = synth.make_wrf_state(ni, nj, nk, seed=seed)
+            cols = lw_columns_from_state(st, 0)
+            cl = synth_cloud_columns(cols, seed + 100, iceflag)
+            # no cloud in the buffer layers above the model top (LW:12543-12553); liquid radius >= 2.5 um (LW cldprmc)
+            for k in ("cldfrac", "clwp", "ciwp", "cswp"):
+                cl[k][:, nk:] = 0.0
+            cols.update(cl)
+            ref = run_ref_lw_cloud(tab, cols, clean=1)
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), table_seed=20260003,
+                                **{"in_" + k: v for k, v in cols.items()},
+                                **{"ref_" + k: v for k, v in ref.items()})
+            cloudy = (ref["cldfmc"].sum(axis=(1, 2)) > 0).sum()
+            print(name, "columns", cols["play"].shape, "cloudy columns", cloudy,
+                  "max |total-clear| OLR", np.abs(ref["uflx"][:, -1] - ref["uflxc"][:, -1]).max())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    main_lw()
     with tempfile.TemporaryDirectory() as td:
         tab = os.path.join(td, "RRTMG_SW_DATA")
         synth.write_sw_data(tab, seed=20260001, real_bytes=8)
