@@ -153,6 +153,16 @@ typedef struct rrtmg_hip_lwrad_args {
     void *lwupt, *lwuptc, *lwuptcln, *lwdnt, *lwdntc, *lwdntcln;   /* optional as a group */
     void *lwupb, *lwupbc, *lwupbcln, *lwdnb, *lwdnbc, *lwdnbcln;
     void *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;   /* optional, (i,kms:kme+2,j) */
+    /* clouds, used when icloud != 0 (RRTMG_LWRAD arguments of the same names, LW:11451-11486): same meaning as in
+     * rrtmg_hip_swrad_args; the longwave McICA stream uses permuteseed 150 (LW:12555) */
+    const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d;
+    const void *re_cloud, *re_ice, *re_snow;
+    const void *qndrop3d;
+    const void *xland, *xice, *snow;
+    int has_reqc, has_reqi, has_reqs;
+    int warm_rain, progn;
+    int is_cammgmp_used, f_ice_phy, mp_physics;
+    double g;
 } rrtmg_hip_lwrad_args;
 
 int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *args, char *err);

@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-from .oracle import lib as _baselib, dp, _p
+from .oracle import lib as _baselib, dp, _p, CLOUD2, CLOUD3
 
 LW_COL_OUT = ["uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "uflxcln", "dflxcln"]
 LW_COL_IN = ["play", "plev", "tlay", "tlev", "h2ovmr", "o3vmr", "co2vmr", "ch4vmr", "n2ovmr", "o2vmr",
@@ -30,7 +30,11 @@ class LwTileIn(C.Structure):
     _fields_ = ([(n, C.c_int) for n in ("ims", "ime", "jms", "jme", "kms", "kme",
                                          "its", "ite", "jts", "jte", "kts", "kte", "nlayers")]
                 + [(n, dp) for n in ("emiss", "tsk", "t3d", "t8w", "p3d", "p8w", "pi3d", "qv3d")]
-                + [("tauaerlw", dp * 16), ("aer_ra_feedback", C.c_int), ("clean_atm_diag", C.c_int)])
+                + [("tauaerlw", dp * 16), ("aer_ra_feedback", C.c_int), ("clean_atm_diag", C.c_int)]
+                + [("icloud", C.c_int)]
+                + [(n, dp) for n in CLOUD3 + CLOUD2]
+                + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
+                + [("g", C.c_double), ("seed_real4", C.c_int)])
 
 
 LW_TILE_OUT = ["rthratenlw", "glw", "olr", "lwcf",
@@ -109,7 +113,8 @@ class LwOracle:
         return out
 
 
-def lwrad_tile(orc: LwOracle, dims: dict, nlay: int, arrays: dict, aer_ra_feedback, clean_atm_diag, outputs: dict):
+def lwrad_tile(orc: LwOracle, dims: dict, nlay: int, arrays: dict, aer_ra_feedback, clean_atm_diag, outputs: dict,
+               cloud: dict = None):
     ti = LwTileIn()
     for n in ("ims", "ime", "jms", "jme", "kms", "kme", "its", "ite", "jts", "jte", "kts", "kte"):
         setattr(ti, n, int(dims[n]))
@@ -125,6 +130,16 @@ def lwrad_tile(orc: LwOracle, dims: dict, nlay: int, arrays: dict, aer_ra_feedba
         ti.tauaerlw[b] = _p(a)
     ti.aer_ra_feedback = int(aer_ra_feedback)
     ti.clean_atm_diag = int(clean_atm_diag)
+    ti.g = 9.81
+    if cloud:
+        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4"):
+            setattr(ti, n, int(cloud.get(n, 0)))
+        ti.g = float(cloud.get("g", 9.81))
+        for n in CLOUD3 + CLOUD2:
+            if arrays.get(n) is not None:
+                a = np.ascontiguousarray(arrays[n], dtype=np.float64)
+                keep.append(a)
+                setattr(ti, n, _p(a))
     to = LwTileOut()
     for n in LW_TILE_OUT:
         if outputs.get(n) is not None:

@@ -1319,6 +1319,36 @@ int lw_oracle_lwrad_tile(const LwTables *t, const LwTileIn *in, LwTileOut *out, 
                              gas + 2 * MAXLAY, gas + 3 * MAXLAY, gas + 4 * MAXLAY, gas + 5 * MAXLAY, gas + 6 * MAXLAY,
                              gas + 7 * MAXLAY, emis, tauaer, in->clean_atm_diag};
             LwColumnOut co = {uflx, dflx, hr, uflxc, dflxc, hrc, uflxcln, dflxcln};
+            double cst[7][MAXLAY], cin[9][MAXLAY], t1d[MAXLAY], pdel[MAXLAY];
+            if (in->icloud != 0) {
+                /* hydrometeors -> in-cloud state, LW:11921-12140, 12335-12553 (same block as the SW wrapper; relcalc
+                 * and reicalc see tlay with the top model layer already overwritten, LW:12246-12250) */
+                const double *src[9] = {in->cldfra3d, in->qc3d, in->qr3d, in->qi3d, in->qs3d, in->re_cloud,
+                                        in->re_ice, in->re_snow, in->qndrop3d};
+                for (int s = 0; s < 9; ++s)
+                    if (src[s]) for (int k = 0; k < nk; ++k) cin[s][k] = src[s][I3(i, in->kts + k, j)];
+                for (int k = 0; k < nk; ++k) {
+                    pdel[k] = plev[k] - plev[k + 1];
+                    t1d[k] = in->t3d[I3(i, in->kts + k, j)];
+                }
+                OracleCloudWrf cw = {nk, t1d, pdel, tlay,
+                                     src[0] ? cin[0] : NULL, src[1] ? cin[1] : NULL, src[2] ? cin[2] : NULL,
+                                     src[3] ? cin[3] : NULL, src[4] ? cin[4] : NULL, src[5] ? cin[5] : NULL,
+                                     src[6] ? cin[6] : NULL, src[7] ? cin[7] : NULL, src[8] ? cin[8] : NULL,
+                                     in->has_reqc, in->has_reqi, in->has_reqs, in->warm_rain, in->progn,
+                                     in->xland ? in->xland[I2(i, j)] : 1., in->xice ? in->xice[I2(i, j)] : 0.,
+                                     in->snow ? in->snow[I2(i, j)] : 0., in->g};
+                int fl[3];
+                if (oracle_cloud_state(&cw, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], fl)) { rc = 1; break; }
+                for (int k = nk; k < nlayers; ++k) {   /* LW:12543-12553 */
+                    cst[0][k] = 0.; cst[1][k] = 0.; cst[2][k] = 0.; cst[3][k] = 0.;
+                    cst[4][k] = 10.; cst[5][k] = 10.; cst[6][k] = 10.;
+                }
+                ci.cldfrac = cst[0]; ci.clwp = cst[1]; ci.ciwp = cst[2]; ci.cswp = cst[3];
+                ci.rel = cst[4]; ci.rei = cst[5]; ci.res = cst[6];
+                ci.inflglw = fl[0]; ci.iceflglw = fl[1]; ci.liqflglw = fl[2];
+                ci.seed_real4 = in->seed_real4;
+            }
             if (lw_oracle_rrtmg_lw(t, &ci, &co)) { rc = 1; break; }
             size_t q2 = I2(i, j);
             if (out->glw) out->glw[q2] = dflx[0];

@@ -75,7 +75,9 @@ typedef struct {
 /* WRF hydrometeor state of one column as the wrappers receive it (NULL array = argument absent / F_Q* false) */
 typedef struct {
     int nk;
-    const double *t, *pdel;                       /* layer temperature (K), thickness (mb) */
+    const double *t, *pdel;                       /* layer temperature t3d (K), thickness (mb) */
+    const double *t_rad;                          /* tlay as relcalc / reicalc see it (LW overwrites tlay(kte),
+                                                     LW:12246-12250); NULL = t */
     const double *cldfra, *qc, *qr, *qi, *qs;     /* cloud fraction, mixing ratios (kg/kg) */
     const double *re_cloud, *re_ice, *re_snow;    /* effective radii (m), used with has_req* */
     const double *qndrop;                         /* droplet number (1/kg), used with progn = 1 */
@@ -196,6 +198,13 @@ typedef struct {
     const double *t3d, *t8w, *p3d, *p8w, *pi3d, *qv3d;       /* 3-D */
     const double *tauaerlw[LW_NBND];                         /* tauaerlw1..16 */
     int aer_ra_feedback, clean_atm_diag;
+    /* clouds (icloud != 0; LW:11921-12140, 12335-12563), as in SwTileIn */
+    int icloud;
+    const double *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d;   /* 3-D */
+    const double *xland, *xice, *snow;                                                              /* 2-D */
+    int has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    double g;
+    int seed_real4;
 } LwTileIn;
 
 typedef struct {

@@ -298,16 +298,18 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
             }
         } else {               /* relcalc, LW:14403-14462 */
             const double tmelt = 273.16, rliqocean = 14.0, rliqice = 14.0, rliqland = 8.0;
-            reliq = rliqland + (rliqocean - rliqland) * fmin(1.0, fmax(0.0, (tmelt - w->t[k]) * 0.05));
+            const double tr = w->t_rad ? w->t_rad[k] : w->t[k];
+            reliq = rliqland + (rliqocean - rliqland) * fmin(1.0, fmax(0.0, (tmelt - tr) * 0.05));
             reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, snowh * 10.));
             reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, 1.0 - landm));
             reliq = reliq + (rliqice - reliq) * fmin(1.0, fmax(0.0, icefrac));
         }
         double reice;
         {                      /* reicalc, LW:14464-14491 */
-            int index = (int)(w->t[k] - 179.);
+            const double tr = w->t_rad ? w->t_rad[k] : w->t[k];
+            int index = (int)(tr - 179.);
             index = index < 1 ? 1 : (index > 94 ? 94 : index);
-            double corr = w->t[k] - (double)(int)w->t[k];
+            double corr = tr - (double)(int)tr;
             reice = CLD_RETAB[index - 1] * (1. - corr) + CLD_RETAB[index] * corr;
         }
         if (inflg >= 3) reliq = recloud1d[k];

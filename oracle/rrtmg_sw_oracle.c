@@ -1373,7 +1373,7 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
                         if (src[s]) for (int k = 0; k < nk; ++k) cin[s][k] = src[s][I3(i, in->kts + k, j)];
                     double pdel[MAXLAY];
                     for (int k = 0; k < nk; ++k) pdel[k] = plev[k] - plev[k + 1];
-                    OracleCloudWrf cw = {nk, tlay, pdel,
+                    OracleCloudWrf cw = {nk, tlay, pdel, NULL,
                                          src[0] ? cin[0] : NULL, src[1] ? cin[1] : NULL, src[2] ? cin[2] : NULL,
                                          src[3] ? cin[3] : NULL, src[4] ? cin[4] : NULL, src[5] ? cin[5] : NULL,
                                          src[6] ? cin[6] : NULL, src[7] ? cin[7] : NULL, src[8] ? cin[8] : NULL,

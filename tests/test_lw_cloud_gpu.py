@@ -1,0 +1,93 @@
+"""GPU parity tests of the cloudy (McICA) longwave path: RRTMG_LWRAD with icloud /= 0 through the HIP C-ABI against
+the CPU oracle (column solver incl. the KISS generator bit-exact against the reference Fortran,
+tests/test_oracle_golden_cloud.py).  Same tolerance as the cloud-free path."""
+import numpy as np
+import pytest
+
+from helpers import compare_sw
+from helpers_lw import run_hip_lwrad, run_oracle_lwrad
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+ATOL = 1e-9
+P_TOP = 5000.0
+
+
+@pytest.fixture(scope="module")
+def lw_table_file(tmp_path_factory, wa):
+    p = tmp_path_factory.mktemp("tables_lw_cld") / "RRTMG_LW_DATA"
+    wa.synth.write_lw_data(str(p), seed=20260003, real_bytes=8)
+    return str(p)
+
+
+@pytest.fixture(scope="module")
+def lw_oracle(oracle_mod, lw_table_file):
+    from oracle import oracle_lw
+    return oracle_lw.LwOracle(lw_table_file)
+
+
+def _init(wa, lw_table_file, nk):
+    import torch
+    assert torch.cuda.is_available()
+    eng = wa.engine_lw
+    eng.rrtmg_lwinit(P_TOP, lw_table_file, kme=nk + 1, device=0)
+    return eng, eng.lw_nlayers(nk + 1, P_TOP)
+
+
+@pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 1, False), (5, 4, 50, 2, True), (4, 3, 28, 3, False),
+                                                 (3, 3, 60, 4, True)])
+def test_cloudy_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed, radii):
+    eng, nlay = _init(wa, lw_table_file, nk)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260500 + seed)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260510 + seed, cloudy_fraction=0.6, with_radii=radii)
+    got = run_hip_lwrad(eng, st, cloud=cloud)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, cloud=cloud)
+    worst = compare_sw(got, ref, RTOL, ATOL)
+    assert worst < 1e-8
+    cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
+    assert cloudy.any() and (~cloudy).any()
+    # clouds trap longwave: OLR below its clear-sky value, positive cloud forcing; cloud-free columns untouched
+    assert (got["lwcf"][cloudy] >= 0).all() and got["lwcf"][cloudy].max() > 1.0
+    np.testing.assert_array_equal(got["lwupt"][~cloudy], got["lwuptc"][~cloudy])
+    assert (got["lwcf"][~cloudy] == 0).all()
+    assert (got["olr"] == got["lwupt"]).all() and (got["glw"] == got["lwdnb"]).all()
+
+
+def test_cloudy_lw_tile_subset_host_mode_and_no_clean(hip_lib, wa, lw_table_file, lw_oracle):
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(9, 7, 40, seed=20260520)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260521, cloudy_fraction=0.7)
+    tile = dict(its=2, ite=8, jts=3, jte=6)
+    a = run_hip_lwrad(eng, st, device=True, tile=tile, cloud=cloud, clean=0)
+    b = run_hip_lwrad(eng, st, device=False, tile=tile, cloud=cloud, clean=0)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, tile=tile, cloud=cloud, clean=0)
+    compare_sw(a, ref, RTOL, ATOL)
+    for n in a:
+        np.testing.assert_array_equal(a[n], b[n], err_msg=n)
+
+
+def test_cloudy_lw_real4_state_uses_single_precision_seeds(hip_lib, wa, lw_table_file, lw_oracle):
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(6, 5, 40, seed=20260530)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260531, cloudy_fraction=0.7)
+    for d in (st.a2, st.a3):
+        for n in d:
+            d[n] = d[n].astype(np.float32).astype(np.float64)
+    got = run_hip_lwrad(eng, st, real_bytes=4, cloud=cloud)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, cloud=cloud, seed_real4=1)
+    compare_sw(got, ref, 3e-7, 2e-4)
+
+
+def test_lw_cloud_refusals_and_fatal_sizes(hip_lib, wa, lw_table_file):
+    eng, nlay = _init(wa, lw_table_file, 30)
+    st = wa.synth.make_wrf_state(3, 2, 30, seed=20260540)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260541, cloudy_fraction=1.0, with_radii=True)
+    with pytest.raises(wa.engine.WrfFatal, match="CAM-MG"):
+        run_hip_lwrad(eng, st, cloud=dict(cloud, is_cammgmp_used=True))
+    with pytest.raises(wa.engine.WrfFatal, match="cldfra3d"):
+        run_hip_lwrad(eng, st, cloud=dict(cloud, absent=("cldfra3d",)))
+    st.a3["re_ice"][...] = 200.0e-6
+    st.a3["cldfra3d"][:, 5, :] = 1.0
+    st.a3["qi3d"][:, 5, :] = 1.0e-4
+    with pytest.raises(wa.engine.WrfFatal, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
+        run_hip_lwrad(eng, st, cloud=cloud)

@@ -11,6 +11,7 @@
 #include "../../include/rrtmg_hip.h"
 #include "lw_common.h"
 #include "lw_kernel.h"
+#include "sw_kernel.h"   // kiss_jump_table
 #include "lw_ref_tables.h"
 #include "lw_state.h"
 
@@ -108,6 +109,13 @@ extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, dou
     HIPCHK(upload(&st.dChi, host.chi_mls));
     HIPCHK(upload(&st.dG, host.gdesc));
     HIPCHK(lw_upload_constants(LWREF_PREFLOG, LWREF_TREF));
+    HIPCHK(lw_upload_retab());
+    {
+        std::vector<double> cld((size_t)2 * LW_NBND * 58);
+        lw_cloud_tables(cld.data());
+        if (!st.dCld) HIPCHK(hipMalloc(&st.dCld, cld.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(st.dCld, cld.data(), cld.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (!st.dStatus) HIPCHK(hipMalloc(&st.dStatus, sizeof(int)));
     HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
     st.dev.K = static_cast<const double *>(st.dK);
@@ -165,13 +173,31 @@ extern "C" int rrtmg_hip_lw_table_info(const char *data_path, int data_real_byte
     return 0;
 }
 
+static const char *lw_status_text(int kind)
+{
+    switch (kind) {
+    case 1: return "ERROR: ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case 2: return "ERROR: SNOW GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case 3: return "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS";
+    default: return "ERROR: Negative total lw optical depth";
+    }
+}
+
 extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
 {
     LwState &st = lw_state();
     if (!st.ready) return failw(err, "rrtmg_hip_lwrad: rrtmg_hip_lw_init has not been called");
     if (a->real_bytes != 4 && a->real_bytes != 8) return failw(err, "rrtmg_hip_lwrad: real_bytes must be 4 or 8");
-    if (a->icloud != 0)
-        return failw(err, "rrtmg_hip_lwrad: icloud /= 0 (McICA cloudy columns) is not implemented in this release");
+    if (a->icloud != 0) {
+        if (a->is_cammgmp_used)
+            return failw(err, "rrtmg_hip_lwrad: is_cammgmp_used (CAM-MG effective radii) is not implemented");
+        if (a->f_ice_phy || a->mp_physics == 5 || a->mp_physics == 15)
+            return failw(err, "rrtmg_hip_lwrad: the Ferrier / HWRF hydrometeor splits (F_ICE_PHY, FER_MP_HIRES) are not implemented");
+        if (!a->cldfra3d) return failw(err, "rrtmg_hip_lwrad: icloud /= 0 needs cldfra3d");
+        if ((a->has_reqc && !a->re_cloud) || (a->has_reqi && !a->re_ice) || (a->has_reqs && !a->re_snow))
+            return failw(err, "rrtmg_hip_lwrad: has_reqc/has_reqi/has_reqs set without re_cloud/re_ice/re_snow");
+        if (!(a->g > 0.)) return failw(err, "rrtmg_hip_lwrad: gravity g must be positive when icloud /= 0");
+    }
     const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
     const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk = a->kte - a->kts + 1;
     if (ni_t <= 0 || nj_t <= 0 || nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
@@ -198,6 +224,24 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     k.aer_ra_feedback = a->aer_ra_feedback; k.clean = a->clean_atm_diag; k.o3input = a->o3input;
     k.tab = st.dev;
     k.status = static_cast<int *>(st.dStatus);
+    k.icloud = a->icloud;
+    if (a->icloud != 0) {
+        if (nk > 64) return failw(err, "rrtmg_hip_lwrad: icloud /= 0 supports at most 64 model layers");
+        if (nk < 4) return failw(err, "rrtmg_hip_lwrad: the McICA seeds need at least four layers");
+        k.has_reqc = a->has_reqc; k.has_reqi = a->has_reqi; k.has_reqs = a->has_reqs;
+        k.warm_rain = a->warm_rain; k.progn = a->progn; k.grav = a->g;
+        k.cldtab = static_cast<const double *>(st.dCld);
+        // KISS jump table: NLAYERS draws per sub-column, permuteseed = 150 (LW:12555)
+        std::lock_guard<std::mutex> lock(st.scratch_mutex);
+        void *&dj = st.dJump[nl];
+        if (!dj) {
+            std::vector<uint32_t> h((size_t)LW_NGPT * KISS_JUMP_WORDS);
+            kiss_jump_table(nl, 150, LW_NGPT, h.data());
+            HIPCHK(hipMalloc(&dj, h.size() * sizeof(uint32_t)));
+            HIPCHK(hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        k.jump = static_cast<const uint32_t *>(dj);
+    }
     Staging stg;
     if (a->mem != 1) HIPCHK(hipMemsetAsync(st.dStatus, 0, sizeof(int), stream));
     struct OutCopy { void *host; void *dev; size_t bytes; };
@@ -212,6 +256,13 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         k.lwdnb = a->lwdnb; k.lwdnbc = a->lwdnbc; k.lwdnbcln = a->lwdnbcln;
         k.lwupflx = a->lwupflx; k.lwupflxc = a->lwupflxc; k.lwupflxcln = a->lwupflxcln;
         k.lwdnflx = a->lwdnflx; k.lwdnflxc = a->lwdnflxc; k.lwdnflxcln = a->lwdnflxcln;
+        if (a->icloud != 0) {
+            k.cldfra3d = a->cldfra3d; k.qc3d = a->qc3d; k.qr3d = a->qr3d; k.qi3d = a->qi3d; k.qs3d = a->qs3d;
+            k.re_cloud = a->has_reqc ? a->re_cloud : nullptr; k.re_ice = a->has_reqi ? a->re_ice : nullptr;
+            k.re_snow = a->has_reqs ? a->re_snow : nullptr;
+            k.qndrop3d = a->progn == 1 ? a->qndrop3d : nullptr;
+            k.xland = a->xland; k.xice = a->xice; k.snow = a->snow;
+        }
     } else {
 #define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
 #define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
@@ -224,6 +275,14 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         IN3(t3d); IN3(t8w); IN3(p3d); IN3(p8w); IN3(pi3d); IN3(qv3d); IN3(o33d);
         if (a->aer_ra_feedback == 1)
             for (int b = 0; b < 16; ++b) HIPCHK(stg.in(a->tauaerlw[b], n3, stream, &k.tauaerlw[b]));
+        if (a->icloud != 0) {
+            IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);
+            if (a->has_reqc) IN3(re_cloud);
+            if (a->has_reqi) IN3(re_ice);
+            if (a->has_reqs) IN3(re_snow);
+            if (a->progn == 1) IN3(qndrop3d);
+            IN2(xland); IN2(xice); IN2(snow);
+        }
         OUT(rthratenlw, n3); OUT(glw, n2); OUT(olr, n2); OUT(lwcf, n2);
         OUT(lwupt, n2); OUT(lwuptc, n2); OUT(lwuptcln, n2); OUT(lwdnt, n2); OUT(lwdntc, n2); OUT(lwdntcln, n2);
         OUT(lwupb, n2); OUT(lwupbc, n2); OUT(lwupbcln, n2); OUT(lwdnb, n2); OUT(lwdnbc, n2); OUT(lwdnbcln, n2);
@@ -274,10 +333,10 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         HIPCHK(hipMemcpyAsync(&status, st.dStatus, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (status != 0) {
-            const int col = status - 1;
+            const int col = (status & 0x0fffffff) - 1;
             char m[RRTMG_HIP_ERRLEN];
-            std::snprintf(m, sizeof m, "ERROR: Negative total lw optical depth at point i,j=%5d%5d",
-                          a->its + col % ni_t, a->jts + col / ni_t);   // LW:12613-12615
+            std::snprintf(m, sizeof m, "%s at point i,j=%5d%5d", lw_status_text(status >> 28),
+                          a->its + col % ni_t, a->jts + col / ni_t);   // LW:12613-12615, LW:2831-2836
             return failw(err, m);
         }
     }
@@ -295,7 +354,7 @@ extern "C" int rrtmg_hip_lw_status(char *err)
     HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
     if (status != 0) {
         char m[RRTMG_HIP_ERRLEN];
-        std::snprintf(m, sizeof m, "ERROR: Negative total lw optical depth at tile column %d", status - 1);
+        std::snprintf(m, sizeof m, "%s at tile column %d", lw_status_text(status >> 28), (status & 0x0fffffff) - 1);
         return failw(err, m);
     }
     return 0;
@@ -304,7 +363,9 @@ extern "C" int rrtmg_hip_lw_status(char *err)
 extern "C" int rrtmg_hip_lw_finalize(void)
 {
     LwState &st = lw_state();
-    void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus};
+    void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus, &st.dCld};
+    for (auto &kv : st.dJump) if (kv.second) (void)hipFree(kv.second);
+    st.dJump.clear();
     for (void **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
     {
         std::lock_guard<std::mutex> lock(st.scratch_mutex);

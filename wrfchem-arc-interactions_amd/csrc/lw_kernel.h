@@ -24,12 +24,24 @@ struct LwKernelArgs {
     // taug / frac [slot][layer][140]; rec [slot][lw_rec_doubles(nlayers)]
     double *taug, *frac, *rec;
     int col0;                           // first tile column of this batch
+    // clouds (icloud != 0), as in SwKernelArgs
+    int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    double grav;
+    const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
+    const uint32_t *jump;               // KISS jump table for NLAYERS draws per sub-column: [LW_NGPT][36]
+    const double *cldtab;               // [2][LW_NBND][58]: absliq1, absice3 (lwcldpr, LW:9858-10496)
     LwDeviceTables tab;
 };
 
+void lw_cloud_tables(double *out /*[2][LW_NBND][58]*/);
+hipError_t lw_upload_retab();
+
 // per-column record handed from lw_gas_kernel to lw_rt_kernel:
 // planklay[16][nl] planklev[16][nl+1] taua[16][nl] secdiff[16] plankbnd[16] pz[nl+1]
-__host__ __device__ inline size_t lw_rec_doubles(int nl) { return (size_t)49 * nl + 49; }
+// followed by the in-cloud state of the column (written when icloud != 0):
+// cldf clwp ciwp cswp fliq fice fsno [nl] each, iliq iice isno [nl] each (integers stored as doubles), seeds[4]
+__host__ __device__ inline size_t lw_rec_base_doubles(int nl) { return (size_t)49 * nl + 49; }
+__host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_base_doubles(nl) + (size_t)10 * nl + 4; }
 // scratch doubles one column needs (taug + frac + record)
 inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_rec_doubles(nl); }
 

@@ -17,6 +17,9 @@
 
 #include "lw_common.h"
 #include "lw_kernel.h"
+#include "sw_kernel.h"   // KISS_JUMP_WORDS
+#include "mcica_device.h"
+#include "cld_retab.h"
 
 namespace rrtmg {
 
@@ -29,6 +32,7 @@ __constant__ double c_lw_preflog[59];
 __constant__ double c_lw_tref[59];
 __constant__ double c_lw_o3ann[31];
 __constant__ double c_lw_ppwrkh[32];
+__constant__ double c_lw_retab[95];   // ice effective radius versus temperature (LW:11424-11442)
 // mean pressure / temperature profile for the buffer layers, LW:11802-11821
 __constant__ double c_pprof[60] = {
     1000.00, 855.47, 731.82, 626.05, 535.57, 458.16, 391.94, 335.29, 286.83, 245.38, 209.91, 179.57,
@@ -98,9 +102,20 @@ __device__ __forceinline__ double exp_neg(double x)
     return ldexp(p, (int)n);
 }
 
+// rad + (bb - rad)*at, LW:3296: the difference is kept out of FMA contraction with the product that formed bb, so that
+// the clean, the aerosol and the clear-sky stream round alike (equal inputs -> bitwise equal fluxes)
+__device__ __forceinline__ double relax(double rad, double bb, double at)
+{
+#pragma clang fp contract(off)
+    const double d = bb - rad;
+    return __builtin_fma(d, at, rad);
+}
+
 // sums of two values over the wave: lane 0 ends with sum(a), lane 32 with sum(b)
 __device__ __forceinline__ double wave_sum2(double a, double b, int lane)
 {
+    // no FMA contraction with the caller's products: the two sums must round alike (equal inputs -> equal sums)
+#pragma clang fp contract(off)
     const bool hi = lane & 32;
     double send = hi ? a : b, keep = hi ? b : a;
     double v = keep + __shfl_xor(send, 32, 64);
@@ -159,7 +174,7 @@ __device__ __forceinline__ LCol carve_rt(double *base, int nl)
     c.taua = p; p += LW_NBND * nl;
     c.secdiff = p; p += LW_NBND; c.plankbnd = p; p += LW_NBND;
     c.pz = p; p += nl + 1;
-    c.flux = p; p += 3 * 4 * (nl + 1);
+    c.flux = base + lw_rec_doubles(nl);   // after the cloud part of the record; [3 waves][6][nl+1]
     return c;
 }
 
@@ -314,6 +329,102 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, 
     bbu = small ? plfrac * (blay + dplankup * tausfac) : plfrac * (blay + tausfac * dplankup);
 }
 
+// One quantised entry of the reference's lookup tables (rrtmg_lw_ini, LW:7940-7957), re-evaluated from its index
+// as in layer_src: tau_tbl, exp_tbl (transmittance) and tfn_tbl.
+__device__ __forceinline__ void lw_tbl_entry(const LwDeviceTables &tb, double od, double &tau_t, double &transc, double &tfn)
+{
+    const double tblind = fdiv(od, tb.bpade + od);
+    int itr = (int)(10000.0 * tblind + 0.5);
+    const bool last = itr >= LW_NTBL;
+    itr = last ? LW_NTBL - 1 : itr;
+    const double fi = (double)itr;
+    tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
+    transc = fmax(exp_neg(tau_t), 1.e-20);
+    const double omt = 1. - transc;
+    tfn = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp(tau_t * omt));
+    tau_t = last ? 1.e10 : tau_t;
+    transc = last ? 1.e-20 : transc;
+    tfn = last ? 1.0 : tfn;
+}
+
+// A layer in which some sub-column is cloudy: the three optical-depth regimes of rtrnmc, LW:3216-3282.
+// odcld = secdiff * cloud optical depth of this sub-column (0 where it is clear).
+struct LwCldSrc { double atrans, atot, bbd, bbdtot, bbugas, bbutot; };
+__device__ __forceinline__ void layer_src_cld(const LwDeviceTables &tb, double tau, double secdiff, double plfrac,
+                                              double blay, double dplankup, double dplankdn, double odcld, LwCldSrc &o)
+{
+    const double rec_6 = 0.166667;
+    double odepth = secdiff * tau;
+    odepth = odepth < 0.0 ? 0.0 : odepth;
+    double odtot = odepth + odcld;
+    if (odtot < 0.06) {
+        o.atrans = odepth - 0.5 * odepth * odepth;
+        const double odepth_rec = rec_6 * odepth;
+        o.atot = odtot - 0.5 * odtot * odtot;
+        const double odtot_rec = rec_6 * odtot;
+        o.bbdtot = plfrac * (blay + dplankdn * odtot_rec);
+        o.bbd = plfrac * (blay + dplankdn * odepth_rec);
+        o.bbugas = plfrac * (blay + dplankup * odepth_rec);
+        o.bbutot = plfrac * (blay + dplankup * odtot_rec);
+    } else if (odepth <= 0.06) {
+        o.atrans = odepth - 0.5 * odepth * odepth;
+        const double odepth_rec = rec_6 * odepth;
+        double tt, transc, tfactot;
+        lw_tbl_entry(tb, odtot, tt, transc, tfactot);
+        o.bbdtot = plfrac * (blay + tfactot * dplankdn);
+        o.bbd = plfrac * (blay + dplankdn * odepth_rec);
+        o.atot = 1. - transc;
+        o.bbugas = plfrac * (blay + dplankup * odepth_rec);
+        o.bbutot = plfrac * (blay + tfactot * dplankup);
+    } else {
+        double tgas, transg, tfacgas;
+        lw_tbl_entry(tb, odepth, tgas, transg, tfacgas);
+        o.atrans = 1. - transg;
+        odtot = tgas + odcld;            // odepth = tau_tbl(itgas), LW:3262
+        double tt, transc, tfactot;
+        lw_tbl_entry(tb, odtot, tt, transc, tfactot);
+        o.bbdtot = plfrac * (blay + tfactot * dplankdn);
+        o.bbd = plfrac * (blay + tfacgas * dplankdn);
+        o.atot = 1. - transc;
+        o.bbugas = plfrac * (blay + tfacgas * dplankup);
+        o.bbutot = plfrac * (blay + tfactot * dplankup);
+    }
+}
+
+// cloud absorption optical depth of a cloudy sub-column layer: cldprmc, LW:2800-2908 (inflag >= 2, liqflag 1,
+// iceflag 3/4/5).  cb = cloud part of the column record; T = [2][16][58] absliq1, absice3.
+// bad: 1 ice, 2 snow, 3 liquid size out of bounds (fatal in the reference).
+__device__ __forceinline__ double lw_cloud_tau(const double *T, const double *cb, int nl, int band, int k, int iceflag,
+                                               int &bad)
+{
+    const double cldmin = 1.e-20;
+    const double clwp = cb[1 * nl + k], ciwp = cb[2 * nl + k], cswp = cb[3 * nl + k];
+    if (!(ciwp + clwp + cswp >= cldmin)) return 0.;
+    double abscoice = 0., abscosno = 0., abscoliq = 0.;
+    if ((ciwp + cswp) != 0.0) {
+        const int ix = (int)cb[8 * nl + k];
+        if (ix == 0) { bad = 1; return 0.; }
+        const double f = cb[5 * nl + k];
+        const double *A = T + (1 * LW_NBND + band) * 58;
+        abscoice = A[ix - 1] + f * (A[ix] - (A[ix - 1]));
+    }
+    if (cswp > 0.0 && iceflag == 5) {
+        const int ix = (int)cb[9 * nl + k];
+        if (ix == 0) { bad = 2; return 0.; }
+        const double f = cb[6 * nl + k];
+        const double *A = T + (1 * LW_NBND + band) * 58;
+        abscosno = A[ix - 1] + f * (A[ix] - (A[ix - 1]));
+    }
+    if (clwp != 0.0) {
+        const int ix = (int)cb[7 * nl + k];
+        if (ix == 0) { bad = 3; return 0.; }
+        const double f = cb[4 * nl + k];
+        const double *A = T + (0 * LW_NBND + band) * 58;
+        abscoliq = A[ix - 1] + f * (A[ix] - (A[ix - 1]));
+    }
+    return ciwp * abscoice + clwp * abscoliq + cswp * abscosno;
+}
+
 // pressure (mb) of level l (0-based, l = 0 surface), LW:12149-12152, 12207-12212
 __device__ double plev_at(const LwKernelArgs &a, size_t base3, size_t sk, int l, int nk, int nl)
 {
@@ -377,7 +488,7 @@ __device__ __forceinline__ int batch_slot()
 
 // Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
 // fractions of every (layer, g-point) (taumol, lanes = g-points) -> scratch.
-__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) lw_gas_kernel(const LwKernelArgs a)
+__global__ void __launch_bounds__(LW_THREADS) lw_gas_kernel(const LwKernelArgs a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
@@ -565,6 +676,140 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         c.rb0[k] = lower ? ((jp - 1) * 5 + (jtt - 1)) : ((jp - 13) * 5 + (jtt - 1));
         c.rb1[k] = lower ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
         c.inds[k] = indself - 1; c.indf[k] = indfor - 1; c.indm[k] = indminor - 1;
+        if (a.icloud != 0) {
+            // hydrometeors -> in-cloud water paths and effective sizes, LW:11921-12140 and 12335-12553 (the block the
+            // SW wrapper has too; relcalc / reicalc see tlay with the top model layer already overwritten); written
+            // to the cloud part of the column record for lw_rt_kernel.  Buffer layers carry no cloud.
+            double cf = 0., clwp = 0., ciwp = 0., cswp = 0., reliq = 10., reice = 10., resno = 10.;
+            int iceflg = 3;
+            if (k < nk) {
+                const size_t q = base3 + (size_t)k * sk;
+                const double t1d = ldr(a.t3d, q, r4);
+                double qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;
+                double qr = a.qr3d ? fmax(0., ldr(a.qr3d, q, r4)) : 0.;
+                double qi = 0., qs = 0.;
+                if (!a.qi3d && !a.warm_rain && t1d < 273.15) { qi = qc; qs = qr; qc = 0.; qr = 0.; }
+                if (a.qi3d) qi = fmax(0., ldr(a.qi3d, q, r4));
+                if (a.qs3d) qs = fmax(0., ldr(a.qs3d, q, r4));
+                cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
+                const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;
+                int inflg = 2;
+                double recloud = 5.0, reice1 = 10., resnow1 = 10.0;
+                if (a.has_reqc != 0) {
+                    inflg = 3;
+                    recloud = fmax(2.5, ldr(a.re_cloud, q, r4) * 1.E6);
+                    if (recloud <= 2.5 && cf > 0. && (xland - 1.5) > 0.) recloud = 10.5;
+                    else if (recloud <= 2.5 && cf > 0. && (xland - 1.5) < 0.) recloud = 7.5;
+                }
+                if (a.has_reqi != 0) {
+                    inflg = 4; iceflg = 4;
+                    reice1 = fmax(5., ldr(a.re_ice, q, r4) * 1.E6);
+                    if (reice1 <= 5. && cf > 0.) {
+                        int idx = (int)(t1d - 179.);
+                        idx = idx < 1 ? 1 : (idx > 75 ? 75 : idx);
+                        const double corr = t1d - (double)(int)t1d;
+                        reice1 = c_lw_retab[idx - 1] * (1. - corr) + c_lw_retab[idx] * corr;
+                        reice1 = fmax(reice1, 5.0);
+                    }
+                }
+                if (a.has_reqs != 0) {
+                    inflg = 5; iceflg = 5;
+                    resnow1 = fmax(10., ldr(a.re_snow, q, r4) * 1.E6);
+                }
+                if (a.has_reqs == 0 && a.has_reqi != 0 && a.has_reqc != 0) {
+                    inflg = 5; iceflg = 5;
+                    resnow1 = fmax(10., ldr(a.re_ice, q, r4) * 1.E6);
+                    qs = a.qi3d ? ldr(a.qi3d, q, r4) : 0.;
+                    qi = 0.;
+                    reice1 = 10.;
+                }
+                const double pdel = plev_b - plev_t;
+                double gicewp = (qi + qs) * pdel * 100.0 / a.grav * 1000.0;
+                const double gliqwp = qc * pdel * 100.0 / a.grav * 1000.0;
+                if (iceflg >= 4) gicewp = qi * pdel * 100.0 / a.grav * 1000.0;
+                ciwp = gicewp / fmax(0.01, cf);
+                clwp = gliqwp / fmax(0.01, cf);
+                if (iceflg == 5) {
+                    double snow_mass_factor = 1.0;
+                    if (resnow1 > 130.) {
+                        snow_mass_factor = (130.0 / resnow1) * (130.0 / resnow1);
+                        resnow1 = 130.0;
+                    }
+                    const double gsnowp = qs * snow_mass_factor * pdel * 100.0 / a.grav * 1000.0;
+                    cswp = gsnowp / fmax(0.01, cf);
+                }
+                if (a.progn == 1) {
+                    const double pi = 4. * atan(1.0), third = 1. / 3., rhoh2o = 1.e3, relconst = 3 / (4. * pi * rhoh2o);
+                    reliq = 10.;
+                    const double qnd = a.qndrop3d ? ldr(a.qndrop3d, q, r4) : 0.;
+                    if (a.qndrop3d && qc * pdel > 3.e-5 && qnd > 1000.) {
+                        reliq = pow(relconst * qc / qnd, third);
+                        reliq = 1.1 * reliq;
+                        reliq = reliq * 1.e6;
+                        reliq = fmax(reliq, 4.);
+                        reliq = fmin(reliq, 20.);
+                    }
+                } else {              // relcalc, LW:14403-14462
+                    const double landm = 2. - xland, snowh = 0.001 * (a.snow ? ldr(a.snow, i2, r4) : 0.);
+                    const double icefrac = a.xice ? ldr(a.xice, i2, r4) : 0.;
+                    reliq = 8.0 + (14.0 - 8.0) * fmin(1.0, fmax(0.0, (273.16 - tavel) * 0.05));
+                    reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, snowh * 10.));
+                    reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, 1.0 - landm));
+                    reliq = reliq + (14.0 - reliq) * fmin(1.0, fmax(0.0, icefrac));
+                }
+                {                     // reicalc, LW:14464-14491
+                    int index = (int)(tavel - 179.);
+                    index = index < 1 ? 1 : (index > 94 ? 94 : index);
+                    const double corr = tavel - (double)(int)tavel;
+                    reice = c_lw_retab[index - 1] * (1. - corr) + c_lw_retab[index] * corr;
+                }
+                if (inflg >= 3) reliq = recloud;
+                if (iceflg >= 4) reice = reice1;
+                if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+                if (inflg == 5) resno = resnow1; else { cswp = 0.0; resno = 10.0; }
+            }
+            double *cb = rec + lw_rec_base_doubles(nl);
+            cb[0 * nl + k] = cf < 1.0e-20 ? 0. : cf;
+            cb[1 * nl + k] = clwp; cb[2 * nl + k] = ciwp; cb[3 * nl + k] = cswp;
+            {   // cldprmc table positions, LW:2830-2842, 2866-2872, 2890-2899; 0 = size out of bounds
+                const bool ok = !(reice < 5.0 || reice > 140.0);
+                const double factor = (reice - 2.) / 3.;
+                int index = (int)factor;
+                if (index == 46) index = 45;
+                cb[8 * nl + k] = ok ? (double)index : 0.;
+                cb[5 * nl + k] = factor - (double)index;
+            }
+            {
+                const bool ok = !(resno < 5.0 || resno > 140.0);
+                const double factor = (resno - 2.) / 3.;
+                int index = (int)factor;
+                if (index == 46) index = 45;
+                cb[9 * nl + k] = ok ? (double)index : 0.;
+                cb[6 * nl + k] = factor - (double)index;
+            }
+            {
+                const bool ok = !(reliq < 2.5 || reliq > 60.);
+                int index = (int)(reliq - 1.5);
+                if (index == 0) index = 1;
+                if (index == 58) index = 57;
+                cb[7 * nl + k] = ok ? (double)index : 0.;
+                cb[4 * nl + k] = reliq - 1.5 - (double)index;
+            }
+            if (k < 4) {
+                // KISS seeds, LW:2330-2334 (fractional Pa of the four lowest layers; single precision in a REAL*4 build)
+#pragma clang fp contract(off)
+                int seed;
+                if (r4) {
+                    const float pl = reinterpret_cast<const float *>(a.p3d)[base3 + (size_t)k * sk] / 100.f;
+                    const float pm = pl * 1.e2f;
+                    seed = (int)((pm - (float)(int)pm) * (float)1000000000);
+                } else {
+                    const double pm = pavel * 1.e2;
+                    seed = (int)((pm - (double)(int)pm) * 1000000000.);
+                }
+                cb[10 * nl + k] = (double)seed;
+            }
+        }
     }
     // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers)
     for (int item = tid; item < LW_NBND * nl; item += LW_THREADS) {
@@ -610,7 +855,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
-    for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_doubles(nl) - (nl + 1) + l] = c.pz[l];
+    for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 1) + l] = c.pz[l];
 
     // ======================= gas optics: lanes = g-points, loop over layers =======================
     const int gbeg = wave * LW_CHUNK;
@@ -652,9 +897,13 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     LCol c = carve_rt(lds, nl);
     {
         const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
-        const int n = (int)lw_rec_doubles(nl);
+        const int n = (int)(a.icloud != 0 ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
         for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
     }
+    // cloud part of the record: cldf clwp ciwp cswp fliq fice fsno iliq iice isno [nl] each, seeds[4]
+    const double *cb = lds + lw_rec_base_doubles(nl);
+    __shared__ unsigned long long s_lmask;
+    if (tid == 0) s_lmask = 0ull;
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
     const size_t i2 = j0 * a.ni_m + i0;
@@ -675,66 +924,159 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
     __syncthreads();
     const double secdiff = c.secdiff[band];
-    double *fl = c.flux + (size_t)wave * 4 * nlev;
+    double *fl = c.flux + (size_t)wave * 6 * nlev;   // down clean, down total, up clean, up total, down clear, up clear
     const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
 
+    // McICA (generate_stochastic_clouds, LW:2208-2578, icld = 2): this lane's sub-column of binary cloud over the
+    // model layers (the buffer layers above carry none); lmask = layers in which any sub-column is cloudy
+    // (icldlyr, LW:3163-3186) -- those take the "cloudy layer" arithmetic for every g-point.
+    uint64_t cmask = 0;
+    int iceflag = 3;
+    if (a.icloud != 0) {
+        if (a.has_reqi != 0) iceflag = 4;
+        if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
+        KissState ks = {(uint32_t)(int)cb[10 * nl + 0], (uint32_t)(int)cb[10 * nl + 1], (uint32_t)(int)cb[10 * nl + 2],
+                        (uint32_t)(int)cb[10 * nl + 3]};
+        kiss_jump(ks, a.jump + (size_t)g * KISS_JUMP_WORDS);
+        double prev = 0.;
+        for (int l = 0; l < nk; ++l) {
+            double cur = kiss_next(ks);
+            if (l > 0) {
+                const double cbl = cb[l - 1];
+                cur = prev > 1. - cbl ? prev : cur * (1. - cbl);
+            }
+            if (cur >= 1. - cb[l]) cmask |= (uint64_t)1 << l;
+            prev = cur;
+        }
+        uint64_t m = active ? cmask : 0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
+        if (lane == 0 && m) atomicOr(&s_lmask, (unsigned long long)m);
+        __syncthreads();
+    }
+    const uint64_t lmask = a.icloud != 0 ? (uint64_t)s_lmask : 0;
+    const bool col_cloudy = lmask != 0;
+    int bad = 0;
+
     // ---- downward sweep (top -> surface), LW:3207-3312 ----
-    double radld_c = 0., radld_t = 0., frac0 = 0.;
-    if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; }
+    double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
+    bool iclddn = false;
+    if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; fl[4 * nlev + nl] = 0.; }
     double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
     for (int k = nl - 1; k >= 0; --k) {
         const double taug = tnext, plfrac = fnext;
         if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-        double at, bbd, bbu;
-        layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
-        radld_t = radld_t + (bbd - radld_t) * at;
-        if (clean_on) {
-            // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-            if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
-            radld_c = radld_c + (bbd - radld_c) * at;
+        const bool lay_cld = k < 64 && ((lmask >> k) & 1);
+        if (!lay_cld) {
+            double at, bbd, bbu;
+            layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
+            radld_t = relax(radld_t, bbd, at);
+            radclr = iclddn ? relax(radclr, bbd, at) : radld_t;   // LW:3304-3311
+            if (clean_on) {
+                // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
+                if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                radld_c = relax(radld_c, bbd, at);
+            }
+        } else {
+            iclddn = true;
+            const bool cl = (cmask >> k) & 1;
+            const double cfm = cl ? 1. : 0.;
+            double odcld = 0., efcl = 0.;
+            if (cl) {
+                odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);   // LW:3172-3176
+                efcl = 1. - exp_neg(odcld);
+            }
+            LwCldSrc s;
+            layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            double gassrc = s.bbd * s.atrans;
+            radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+            radclr = radclr + (s.bbd - radclr) * s.atrans;
+            if (clean_on) {
+                layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                gassrc = s.bbd * s.atrans;
+                radld_c = radld_c - radld_c * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+            }
         }
-        double s = wave_sum2(wgt * radld_c, wgt * radld_t, lane);
-        if (lane == 0) fl[0 * nlev + k] = s;
-        if (lane == 32) fl[1 * nlev + k] = s;
+        double s2 = wave_sum2(wgt * radld_c, wgt * radld_t, lane);
+        if (lane == 0) fl[0 * nlev + k] = s2;
+        if (lane == 32) fl[1 * nlev + k] = s2;
+        if (col_cloudy) {
+            const double sc = wave_sum2(wgt * radclr, 0., lane);
+            if (lane == 0) fl[4 * nlev + k] = sc;
+        }
         frac0 = plfrac;
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
     const double rad0 = frac0 * c.plankbnd[band];
     const double reflect = 1. - semiss;
-    double radlu_c = rad0 + reflect * radld_c, radlu_t = rad0 + reflect * radld_t;
+    double radlu_c = __builtin_fma(reflect, radld_c, rad0), radlu_t = __builtin_fma(reflect, radld_t, rad0),
+           radclru = __builtin_fma(reflect, radclr, rad0);
     {
-        double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
-        if (lane == 0) fl[2 * nlev] = s;
-        if (lane == 32) fl[3 * nlev] = s;
+        double s2 = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
+        if (lane == 0) fl[2 * nlev] = s2;
+        if (lane == 32) fl[3 * nlev] = s2;
+        if (col_cloudy) {
+            const double sc = wave_sum2(wgt * radclru, 0., lane);
+            if (lane == 0) fl[5 * nlev] = sc;
+        }
     }
     // ---- upward sweep (surface -> top), LW:3331-3356 ----
     for (int k = 0; k < nl; ++k) {   // tnext / fnext hold layer 0 after the downward sweep
         const double taug = tnext, plfrac = fnext;
         if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-        double at, bbd, bbu;
-        layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
-        radlu_t = radlu_t + (bbu - radlu_t) * at;
-        if (clean_on) {
-            // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-            if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
-            radlu_c = radlu_c + (bbu - radlu_c) * at;
+        const bool lay_cld = k < 64 && ((lmask >> k) & 1);
+        if (!lay_cld) {
+            double at, bbd, bbu;
+            layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            radlu_t = relax(radlu_t, bbu, at);
+            radclru = col_cloudy ? relax(radclru, bbu, at) : radlu_t;   // LW:3348-3354 (iclddn of the column)
+            if (clean_on) {
+                // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
+                if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                radlu_c = relax(radlu_c, bbu, at);
+            }
+        } else {
+            const bool cl = (cmask >> k) & 1;
+            const double cfm = cl ? 1. : 0.;
+            double odcld = 0., efcl = 0.;
+            if (cl) {
+                odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);
+                efcl = 1. - exp_neg(odcld);
+            }
+            LwCldSrc s;
+            layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            double gassrc = s.bbugas * s.atrans;
+            radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
+            radclru = radclru + (s.bbugas - radclru) * s.atrans;
+            if (clean_on) {
+                layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                gassrc = s.bbugas * s.atrans;
+                radlu_c = radlu_c - radlu_c * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
+            }
         }
-        double s = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
-        if (lane == 0) fl[2 * nlev + k + 1] = s;
-        if (lane == 32) fl[3 * nlev + k + 1] = s;
+        double s2 = wave_sum2(wgt * radlu_c, wgt * radlu_t, lane);
+        if (lane == 0) fl[2 * nlev + k + 1] = s2;
+        if (lane == 32) fl[3 * nlev + k + 1] = s2;
+        if (col_cloudy) {
+            const double sc = wave_sum2(wgt * radclru, 0., lane);
+            if (lane == 0) fl[5 * nlev + k + 1] = sc;
+        }
     }
+    if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
 
     // ======================= epilogue: lanes = levels =======================
-    const double *f0 = c.flux, *f1 = c.flux + (size_t)4 * nlev, *f2 = c.flux + (size_t)8 * nlev;
+    const double *f0 = c.flux, *f1 = c.flux + (size_t)6 * nlev, *f2 = c.flux + (size_t)12 * nlev;
     for (int l = tid; l < nlev; l += LW_THREADS) {
         auto tot = [&](int q, int lev) { return (f0[q * nlev + lev] + f1[q * nlev + lev] + f2[q * nlev + lev]) * tb.fluxfac; };
         const double dnc = clean_on ? tot(0, l) : 0., dn = tot(1, l), upc = clean_on ? tot(2, l) : 0., up = tot(3, l);
+        // clear sky (aerosol call): own stream in a cloudy column, else the total-sky values (LW:3304-3311)
+        const double dnk = col_cloudy ? tot(4, l) : dn, upk = col_cloudy ? tot(5, l) : up;
         if (a.lwupflx && l <= nk + 1) {   // kts:kte+2, LW:12677-12684
             const size_t q = base3f + (size_t)l * sk;
-            str(a.lwupflx, q, r4, up); str(a.lwupflxc, q, r4, up); str(a.lwdnflx, q, r4, dn); str(a.lwdnflxc, q, r4, dn);
+            str(a.lwupflx, q, r4, up); str(a.lwupflxc, q, r4, upk); str(a.lwdnflx, q, r4, dn); str(a.lwdnflxc, q, r4, dnk);
             str(a.lwupflxcln, q, r4, upc); str(a.lwdnflxcln, q, r4, dnc);
         }
         if (l < nk && a.rthratenlw) {
@@ -748,15 +1090,15 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
         if (l == 0) {
             if (a.glw) str(a.glw, i2, r4, dn);
             if (a.lwupt) {
-                str(a.lwupb, i2, r4, up); str(a.lwupbc, i2, r4, up); str(a.lwdnb, i2, r4, dn); str(a.lwdnbc, i2, r4, dn);
+                str(a.lwupb, i2, r4, up); str(a.lwupbc, i2, r4, upk); str(a.lwdnb, i2, r4, dn); str(a.lwdnbc, i2, r4, dnk);
                 str(a.lwupbcln, i2, r4, upc); str(a.lwdnbcln, i2, r4, dnc);
             }
         }
         if (l == nl) {
             if (a.olr) str(a.olr, i2, r4, up);
-            if (a.lwcf) str(a.lwcf, i2, r4, up - up);   // cloud-free: uflxc == uflx
+            if (a.lwcf) str(a.lwcf, i2, r4, upk - up);   // LW:12658
             if (a.lwupt) {
-                str(a.lwupt, i2, r4, up); str(a.lwuptc, i2, r4, up); str(a.lwdnt, i2, r4, dn); str(a.lwdntc, i2, r4, dn);
+                str(a.lwupt, i2, r4, up); str(a.lwuptc, i2, r4, upk); str(a.lwdnt, i2, r4, dn); str(a.lwdntc, i2, r4, dnk);
                 str(a.lwuptcln, i2, r4, upc); str(a.lwdntcln, i2, r4, dnc);
             }
         }
@@ -772,7 +1114,7 @@ size_t lw_gas_lds_bytes(int nl)
 }
 size_t lw_rt_lds_bytes(int nl)
 {
-    return (lw_rec_doubles(nl) + (size_t)3 * 4 * (nl + 1)) * sizeof(double);
+    return (lw_rec_doubles(nl) + (size_t)3 * 6 * (nl + 1)) * sizeof(double);
 }
 
 hipError_t lw_upload_constants(const double *preflog, const double *tref)
@@ -808,6 +1150,11 @@ hipError_t lw_upload_constants(const double *preflog, const double *tref)
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lw_ppwrkh), ppwrkh, sizeof ppwrkh)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lw_preflog), preflog, 59 * sizeof(double))) != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_lw_tref), tref, 59 * sizeof(double));
+}
+
+hipError_t lw_upload_retab()
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_lw_retab), CLD_RETAB, sizeof(double) * 95);
 }
 
 hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream)

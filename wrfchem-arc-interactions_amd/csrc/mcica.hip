@@ -17,6 +17,8 @@
 
 #include "sw_kernel.h"
 #include "sw_cld_tables.h"
+#include "lw_cld_tables.h"
+#include "lw_kernel.h"
 
 namespace rrtmg {
 
@@ -97,6 +99,15 @@ void sw_cloud_tables(double *out)
             out[(5 * SW_NBND + b) * CLD_STRIDE + i] = SWCLD_ASYICE3[b][i];
             out[(6 * SW_NBND + b) * CLD_STRIDE + i] = SWCLD_FDLICE3[b][i];
         }
+    }
+}
+
+void lw_cloud_tables(double *out)
+{
+    std::memset(out, 0, sizeof(double) * 2 * LW_NBND * 58);
+    for (int b = 0; b < LW_NBND; ++b) {
+        for (int i = 0; i < 58; ++i) out[(0 * LW_NBND + b) * 58 + i] = LWCLD_ABSLIQ1[b][i];
+        for (int i = 0; i < 46; ++i) out[(1 * LW_NBND + b) * 58 + i] = LWCLD_ABSICE3[b][i];
     }
 }
 

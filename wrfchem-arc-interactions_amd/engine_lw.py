@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from .engine import CP, ERRLEN, WrfFatal, _check, _ptr, load_library
+from .engine import CP, ERRLEN, WrfFatal, _CLD2, _CLD3, _CLDFLAGS, _check, _ptr, load_library
 
 _IN2 = ["emiss", "tsk"]
 _IN3 = ["t3d", "t8w", "p3d", "p8w", "pi3d", "qv3d", "o33d"]
@@ -25,7 +25,10 @@ class LwradArgs(C.Structure):
                 + [(n, C.c_int) for n in ("aer_ra_feedback", "clean_atm_diag", "icloud", "o3input")]
                 + [(n, C.c_void_p) for n in _IN2 + _IN3]
                 + [("tauaerlw", C.c_void_p * 16)]
-                + [(n, C.c_void_p) for n in _OUT])
+                + [(n, C.c_void_p) for n in _OUT]
+                + [(n, C.c_void_p) for n in _CLD3 + _CLD2]
+                + [(n, C.c_int) for n in _CLDFLAGS]
+                + [("g", C.c_double)])
 
 
 EXPORTS_LW = ["rrtmg_hip_lw_init", "rrtmg_hip_lw_nlayers", "rrtmg_hip_lwrad", "rrtmg_hip_lw_status",
@@ -60,7 +63,9 @@ def rrtmg_lwinit(p_top, data_path: str, kme: int, data_real_bytes: int = 8, cpda
 
 
 def rrtmg_lwrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
-                aer_ra_feedback=0, clean_atm_diag=0, icloud=0, o3input=0, stream=None, **arrays):
+                aer_ra_feedback=0, clean_atm_diag=0, icloud=0, o3input=0, stream=None,
+                has_reqc=0, has_reqi=0, has_reqs=0, warm_rain=False, progn=0, is_cammgmp_used=False, f_ice_phy=False,
+                mp_physics=0, g=9.81, **arrays):
     """RRTMG_LWRAD (LW:11451-12700); keyword names are the reference's dummy argument names in lower case."""
     lib = _lib()
     a = LwradArgs()
@@ -71,7 +76,11 @@ def rrtmg_lwrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
     a.clean_atm_diag = int(clean_atm_diag)
     a.icloud = int(icloud)
     a.o3input = int(o3input)
-    known = set(_IN2 + _IN3 + _AER + _OUT)
+    for n, v in dict(has_reqc=has_reqc, has_reqi=has_reqi, has_reqs=has_reqs, warm_rain=warm_rain, progn=progn,
+                     is_cammgmp_used=is_cammgmp_used, f_ice_phy=f_ice_phy, mp_physics=mp_physics).items():
+        setattr(a, n, int(v))
+    a.g = float(g)
+    known = set(_IN2 + _IN3 + _AER + _OUT + _CLD3 + _CLD2)
     unknown = set(arrays) - known
     if unknown:
         raise TypeError(f"unknown RRTMG_LWRAD arguments: {sorted(unknown)}")
