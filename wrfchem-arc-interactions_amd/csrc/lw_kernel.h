@@ -46,7 +46,7 @@ __host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_base_do
 inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_rec_doubles(nl); }
 
 size_t lw_gas_lds_bytes(int nlayers);
-size_t lw_rt_lds_bytes(int nlayers);
+size_t lw_rt_lds_bytes(int nlayers, bool cloud = true);
 hipError_t lw_upload_constants(const double *preflog, const double *tref);
 // runs ncol columns in batches of at most cap_cols through the two kernels; `scratch` holds
 // cap_cols * lw_scratch_doubles(nlayers) doubles

@@ -164,7 +164,7 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
     return c;
 }
 // transfer kernel: LDS image of the record (same order) followed by the flux slots
-__device__ __forceinline__ LCol carve_rt(double *base, int nl)
+__device__ __forceinline__ LCol carve_rt(double *base, int nl, bool cloud)
 {
     LCol c{};
     c.nl = nl;
@@ -174,7 +174,8 @@ __device__ __forceinline__ LCol carve_rt(double *base, int nl)
     c.taua = p; p += LW_NBND * nl;
     c.secdiff = p; p += LW_NBND; c.plankbnd = p; p += LW_NBND;
     c.pz = p; p += nl + 1;
-    c.flux = base + lw_rec_doubles(nl);   // after the cloud part of the record; [3 waves][6][nl+1]
+    // after the cloud part of the record when there is one; [3 waves][4 or 6][nl+1]
+    c.flux = base + (cloud ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
     return c;
 }
 
@@ -488,7 +489,7 @@ __device__ __forceinline__ int batch_slot()
 
 // Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
 // fractions of every (layer, g-point) (taumol, lanes = g-points) -> scratch.
-__global__ void __launch_bounds__(LW_THREADS) lw_gas_kernel(const LwKernelArgs a)
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) lw_gas_kernel(const LwKernelArgs a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
@@ -894,7 +895,8 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     const int nk = a.nk, nl = a.nlayers;
     const int slot = batch_slot();
     const int col = a.col0 + slot;
-    LCol c = carve_rt(lds, nl);
+    LCol c = carve_rt(lds, nl, a.icloud != 0);
+    const int nslot = a.icloud != 0 ? 6 : 4;   // flux slots per wave: + clear-sky down / up with clouds
     {
         const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
         const int n = (int)(a.icloud != 0 ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
@@ -924,7 +926,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
     __syncthreads();
     const double secdiff = c.secdiff[band];
-    double *fl = c.flux + (size_t)wave * 6 * nlev;   // down clean, down total, up clean, up total, down clear, up clear
+    double *fl = c.flux + (size_t)wave * nslot * nlev;   // down clean, down total, up clean, up total, down clear, up clear
     const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
 
     // McICA (generate_stochastic_clouds, LW:2208-2578, icld = 2): this lane's sub-column of binary cloud over the
@@ -961,7 +963,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     // ---- downward sweep (top -> surface), LW:3207-3312 ----
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
     bool iclddn = false;
-    if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; fl[4 * nlev + nl] = 0.; }
+    if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; if (nslot == 6) fl[4 * nlev + nl] = 0.; }
     double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
     for (int k = nl - 1; k >= 0; --k) {
         const double taug = tnext, plfrac = fnext;
@@ -1068,7 +1070,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     __syncthreads();
 
     // ======================= epilogue: lanes = levels =======================
-    const double *f0 = c.flux, *f1 = c.flux + (size_t)6 * nlev, *f2 = c.flux + (size_t)12 * nlev;
+    const double *f0 = c.flux, *f1 = c.flux + (size_t)nslot * nlev, *f2 = c.flux + (size_t)2 * nslot * nlev;
     for (int l = tid; l < nlev; l += LW_THREADS) {
         auto tot = [&](int q, int lev) { return (f0[q * nlev + lev] + f1[q * nlev + lev] + f2[q * nlev + lev]) * tb.fluxfac; };
         const double dnc = clean_on ? tot(0, l) : 0., dn = tot(1, l), upc = clean_on ? tot(2, l) : 0., up = tot(3, l);
@@ -1112,8 +1114,9 @@ size_t lw_gas_lds_bytes(int nl)
     size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
-size_t lw_rt_lds_bytes(int nl)
+size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
+    if (!cloud) return (lw_rec_base_doubles(nl) + (size_t)3 * 4 * (nl + 1)) * sizeof(double);
     return (lw_rec_doubles(nl) + (size_t)3 * 6 * (nl + 1)) * sizeof(double);
 }
 
@@ -1160,7 +1163,7 @@ hipError_t lw_upload_retab()
 hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream)
 {
     const int nl = a.nlayers;
-    const size_t lds_gas = lw_gas_lds_bytes(nl), lds_rt = lw_rt_lds_bytes(nl);
+    const size_t lds_gas = lw_gas_lds_bytes(nl), lds_rt = lw_rt_lds_bytes(nl, a.icloud != 0);
     static size_t attr_gas = 0, attr_rt = 0;
     if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_gas_kernel),
