@@ -3,7 +3,8 @@
 PROGRAM plumbing_lw
    USE module_ra_rrtmg_lw, ONLY : rrtmg_lwrad, rrtmg_lwinit
    IMPLICIT NONE
-   INTEGER :: ni, nj, nk, clean
+   INTEGER :: ni, nj, nk, clean, icloud
+   REAL, ALLOCATABLE, DIMENSION(:,:,:) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
    INTEGER :: ids,ide,jds,jde,kds,kde, ims,ime,jms,jme,kms,kme, its,ite,jts,jte,kts,kte
    REAL :: p_top
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: t3d,t8w,p3d,p8w,pi3d,rho3d,dz8w,qv3d,rthratenlw, re_c,re_i,re_s
@@ -16,6 +17,8 @@ PROGRAM plumbing_lw
    CALL get_command_argument(2, fout)
    OPEN(11, file=TRIM(fin), access='stream', form='unformatted', status='old')
    READ(11) ni, nj, nk, clean
+   icloud = clean / 10            ! header word: clean_atm_diag + 10*icloud
+   clean = MOD(clean, 10)
    READ(11) p_top
    ids=1; ide=ni+1; jds=1; jde=nj+1; kds=1; kde=nk+1
    ims=1; ime=ni; jms=1; jme=nj; kms=1; kme=nk+1
@@ -33,6 +36,10 @@ PROGRAM plumbing_lw
    READ(11) emiss, tsk
    READ(11) t3d, t8w, p3d, p8w, pi3d, qv3d
    READ(11) tl
+   ALLOCATE(cldfra3d(ims:ime,kms:kme,jms:jme), qc3d(ims:ime,kms:kme,jms:jme), qr3d(ims:ime,kms:kme,jms:jme))
+   ALLOCATE(qi3d(ims:ime,kms:kme,jms:jme), qs3d(ims:ime,kms:kme,jms:jme))
+   cldfra3d = 0.; qc3d = 0.; qr3d = 0.; qi3d = 0.; qs3d = 0.
+   IF (icloud /= 0) READ(11) cldfra3d, qc3d, qr3d, qi3d, qs3d
    CLOSE(11)
    rho3d = 1.; dz8w = 100.; xland = 1.; xice = 0.; snow = 0.; re_c = 0.; re_i = 0.; re_s = 0.
    rthratenlw = -7777.; glw = -7777.; olr = -7777.; lwcf = -7777.
@@ -48,7 +55,9 @@ PROGRAM plumbing_lw
         GLW=glw, OLR=olr, LWCF=lwcf, EMISS=emiss,                     &
         p8w=p8w, p3d=p3d, pi3d=pi3d,                                  &
         dz8w=dz8w, tsk=tsk, t3d=t3d, t8w=t8w, rho3d=rho3d, R=287., G=9.81, &
-        ICLOUD=0, WARM_RAIN=.FALSE.,                                  &
+        ICLOUD=icloud, WARM_RAIN=.FALSE.,                             &
+        CLDFRA3D=cldfra3d, QC3D=qc3d, QR3D=qr3d, QI3D=qi3d, QS3D=qs3d, &
+        F_QV=.TRUE., F_QC=.TRUE., F_QR=.TRUE., F_QI=.TRUE., F_QS=.TRUE., F_QG=.FALSE., &
         IS_CAMMGMP_USED=.FALSE.,                                      &
         XLAND=xland, XICE=xice, SNOW=snow,                            &
         QV3D=qv3d,                                                    &

@@ -4,7 +4,8 @@
 PROGRAM plumbing_sw
    USE module_ra_rrtmg_sw, ONLY : rrtmg_swrad, rrtmg_swinit
    IMPLICIT NONE
-   INTEGER :: ni, nj, nk, clean
+   INTEGER :: ni, nj, nk, clean, icloud
+   REAL, ALLOCATABLE, DIMENSION(:,:,:) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
    INTEGER :: ids,ide,jds,jde,kds,kde, ims,ime,jms,jme,kms,kme, its,ite,jts,jte,kts,kte
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: t3d,t8w,p3d,p8w,pi3d,rho3d,dz8w,qv3d,rthratensw, re_c,re_i,re_s
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: tauaer300,tauaer400,tauaer600,tauaer999,gaer300,gaer400,gaer600,gaer999
@@ -18,6 +19,8 @@ PROGRAM plumbing_sw
    CALL get_command_argument(2, fout)
    OPEN(11, file=TRIM(fin), access='stream', form='unformatted', status='old')
    READ(11) ni, nj, nk, clean
+   icloud = clean / 10            ! header word: clean_atm_diag + 10*icloud
+   clean = MOD(clean, 10)
    ids=1; ide=ni+1; jds=1; jde=nj+1; kds=1; kde=nk+1
    ims=1; ime=ni; jms=1; jme=nj; kms=1; kme=nk+1
    its=1; ite=ni; jts=1; jte=nj; kts=1; kte=nk
@@ -40,6 +43,10 @@ PROGRAM plumbing_sw
    READ(11) t3d, t8w, p3d, p8w, pi3d, qv3d
    READ(11) tauaer300, tauaer400, tauaer600, tauaer999, gaer300, gaer400, gaer600, gaer999
    READ(11) waer300, waer400, waer600, waer999
+   ALLOCATE(cldfra3d(ims:ime,kms:kme,jms:jme), qc3d(ims:ime,kms:kme,jms:jme), qr3d(ims:ime,kms:kme,jms:jme))
+   ALLOCATE(qi3d(ims:ime,kms:kme,jms:jme), qs3d(ims:ime,kms:kme,jms:jme))
+   cldfra3d = 0.; qc3d = 0.; qr3d = 0.; qi3d = 0.; qs3d = 0.
+   IF (icloud /= 0) READ(11) cldfra3d, qc3d, qr3d, qi3d, qs3d
    CLOSE(11)
    rho3d = 1.; dz8w = 100.; xlat = 0.; xlong = 0.; xland = 1.; xice = 0.; snow = 0.
    re_c = 0.; re_i = 0.; re_s = 0.
@@ -63,7 +70,9 @@ PROGRAM plumbing_sw
         dz8w=dz8w, IS_CAMMGMP_USED=.FALSE., R=287., G=9.81,           &
         RE_CLOUD=re_c, RE_ICE=re_i, RE_SNOW=re_s,                     &
         has_reqc=0, has_reqi=0, has_reqs=0,                           &
-        ICLOUD=0, WARM_RAIN=.FALSE.,                                  &
+        ICLOUD=icloud, WARM_RAIN=.FALSE.,                             &
+        CLDFRA3D=cldfra3d, QC3D=qc3d, QR3D=qr3d, QI3D=qi3d, QS3D=qs3d, &
+        F_QV=.TRUE., F_QC=.TRUE., F_QR=.TRUE., F_QI=.TRUE., F_QS=.TRUE., F_QG=.FALSE., &
         XLAND=xland, XICE=xice, SNOW=snow,                            &
         QV3D=qv3d, NO_SRC=1, sf_surface_physics=2,                    &
         TAUAER300=tauaer300, TAUAER400=tauaer400,                     &

@@ -39,6 +39,14 @@ MODULE module_ra_rrtmg_lw
       TYPE(c_ptr) :: lwupt, lwuptc, lwuptcln, lwdnt, lwdntc, lwdntcln
       TYPE(c_ptr) :: lwupb, lwupbc, lwupbcln, lwdnb, lwdnbc, lwdnbcln
       TYPE(c_ptr) :: lwupflx, lwupflxc, lwupflxcln, lwdnflx, lwdnflxc, lwdnflxcln
+      TYPE(c_ptr) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
+      TYPE(c_ptr) :: re_cloud, re_ice, re_snow
+      TYPE(c_ptr) :: qndrop3d
+      TYPE(c_ptr) :: xland, xice, snow
+      INTEGER(c_int) :: has_reqc, has_reqi, has_reqs
+      INTEGER(c_int) :: warm_rain, progn
+      INTEGER(c_int) :: is_cammgmp_used, f_ice_phy, mp_physics
+      REAL(c_double) :: g
    END TYPE lwrad_args
 
    INTERFACE
@@ -115,12 +123,12 @@ CONTAINS
       REAL, DIMENSION(ims:ime,jms:jme), INTENT(INOUT), TARGET :: glw, olr, lwcf
       REAL, DIMENSION(ims:ime,jms:jme), INTENT(IN), TARGET :: emiss, tsk
       REAL, INTENT(IN) :: r, g
-      REAL, DIMENSION(ims:ime,jms:jme), INTENT(IN) :: xland, xice, snow
+      REAL, DIMENSION(ims:ime,jms:jme), INTENT(IN), TARGET :: xland, xice, snow
       INTEGER, INTENT(IN) :: yr
       REAL, INTENT(IN) :: julian
       REAL, DIMENSION(ims:ime,kms:kme,jms:jme), OPTIONAL, INTENT(IN), TARGET :: &
            cldfra3d, lradius, iradius, qv3d, qc3d, qr3d, qi3d, qs3d, qg3d, qndrop3d
-      REAL, DIMENSION(ims:ime,kms:kme,jms:jme), INTENT(IN) :: re_cloud, re_ice, re_snow
+      REAL, DIMENSION(ims:ime,kms:kme,jms:jme), INTENT(IN), TARGET :: re_cloud, re_ice, re_snow
       INTEGER, INTENT(IN) :: has_reqc, has_reqi, has_reqs
       REAL, DIMENSION(ims:ime,kms:kme,jms:jme), OPTIONAL, INTENT(IN) :: f_ice_phy, f_rain_phy
       LOGICAL, OPTIONAL, INTENT(IN) :: f_qv, f_qc, f_qr, f_qi, f_qs, f_qg, f_qndrop
@@ -171,6 +179,39 @@ CONTAINS
       a%lwdnb = opt2(lwdnb); a%lwdnbc = opt2(lwdnbc); a%lwdnbcln = opt2(lwdnbcln)
       a%lwupflx = optf(lwupflx); a%lwupflxc = optf(lwupflxc); a%lwupflxcln = optf(lwupflxcln)
       a%lwdnflx = optf(lwdnflx); a%lwdnflxc = optf(lwdnflxc); a%lwdnflxcln = optf(lwdnflxcln)
+
+      ! clouds (icloud /= 0): a hydrometeor array is handed over only when it is PRESENT and its F_Q* flag is set,
+      ! which is exactly when the reference reads it (LW:11921-11990)
+      a%cldfra3d = opt3(cldfra3d)
+      a%qc3d = c_null_ptr; a%qr3d = c_null_ptr; a%qi3d = c_null_ptr; a%qs3d = c_null_ptr; a%qndrop3d = c_null_ptr
+      IF (PRESENT(f_qc) .AND. PRESENT(qc3d)) THEN
+         IF (f_qc) a%qc3d = c_loc(qc3d)
+      END IF
+      IF (PRESENT(f_qr) .AND. PRESENT(qr3d)) THEN
+         IF (f_qr) a%qr3d = c_loc(qr3d)
+      END IF
+      IF (PRESENT(f_qi) .AND. PRESENT(qi3d)) THEN
+         IF (f_qi) a%qi3d = c_loc(qi3d)
+      END IF
+      IF (PRESENT(f_qs) .AND. PRESENT(qs3d)) THEN
+         IF (f_qs) a%qs3d = c_loc(qs3d)
+      END IF
+      IF (PRESENT(f_qndrop) .AND. PRESENT(qndrop3d)) THEN
+         IF (f_qndrop) a%qndrop3d = c_loc(qndrop3d)
+      END IF
+      a%re_cloud = c_loc(re_cloud); a%re_ice = c_loc(re_ice); a%re_snow = c_loc(re_snow)
+      a%xland = c_loc(xland); a%xice = c_loc(xice); a%snow = c_loc(snow)
+      a%has_reqc = has_reqc; a%has_reqi = has_reqi; a%has_reqs = has_reqs
+      a%warm_rain = MERGE(1, 0, warm_rain)
+      a%progn = 0
+      IF (PRESENT(progn)) a%progn = progn
+      a%is_cammgmp_used = MERGE(1, 0, is_cammgmp_used)
+      a%f_ice_phy = 0
+      IF (PRESENT(f_ice_phy) .AND. PRESENT(f_qc) .AND. PRESENT(f_qi) .AND. PRESENT(f_qs)) THEN
+         IF (f_qc .AND. .NOT. f_qi .AND. f_qs) a%f_ice_phy = 1
+      END IF
+      a%mp_physics = mp_physics
+      a%g = REAL(g, c_double)
 
       rc = rrtmg_hip_lwrad(a, err)
       IF (rc /= 0) CALL fatal_from_c(err)

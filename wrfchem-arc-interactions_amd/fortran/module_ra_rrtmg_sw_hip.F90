@@ -47,6 +47,14 @@ MODULE module_ra_rrtmg_sw
       TYPE(c_ptr) :: swvisdir, swvisdif, swnirdir, swnirdif
       TYPE(c_ptr) :: swddir, swddni, swddif
       TYPE(c_ptr) :: swupflx, swupflxc, swupflxcln, swdnflx, swdnflxc, swdnflxcln
+      TYPE(c_ptr) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
+      TYPE(c_ptr) :: re_cloud, re_ice, re_snow
+      TYPE(c_ptr) :: qndrop3d
+      TYPE(c_ptr) :: xland, xice, snow
+      INTEGER(c_int) :: has_reqc, has_reqi, has_reqs
+      INTEGER(c_int) :: warm_rain, progn
+      INTEGER(c_int) :: is_cammgmp_used, f_ice_phy, mp_physics
+      REAL(c_double) :: g
    END TYPE swrad_args
 
    INTERFACE
@@ -144,7 +152,7 @@ CONTAINS
       REAL, INTENT(IN) :: r, g
       REAL, DIMENSION(ims:ime,kms:kme,jms:jme), OPTIONAL, INTENT(IN), TARGET :: &
            cldfra3d, lradius, iradius, qv3d, qc3d, qr3d, qi3d, qs3d, qg3d, qndrop3d
-      REAL, DIMENSION(ims:ime,kms:kme,jms:jme), INTENT(IN) :: re_cloud, re_ice, re_snow
+      REAL, DIMENSION(ims:ime,kms:kme,jms:jme), INTENT(IN), TARGET :: re_cloud, re_ice, re_snow
       INTEGER, INTENT(IN) :: has_reqc, has_reqi, has_reqs
       REAL, DIMENSION(ims:ime,kms:kme,jms:jme), OPTIONAL, INTENT(IN) :: f_ice_phy, f_rain_phy
       LOGICAL, OPTIONAL, INTENT(IN) :: f_qv, f_qc, f_qr, f_qi, f_qs, f_qg, f_qndrop
@@ -208,6 +216,40 @@ CONTAINS
       a%swddir = c_loc(swddir); a%swddni = c_loc(swddni); a%swddif = c_loc(swddif)
       a%swupflx = optf(swupflx); a%swupflxc = optf(swupflxc); a%swupflxcln = optf(swupflxcln)
       a%swdnflx = optf(swdnflx); a%swdnflxc = optf(swdnflxc); a%swdnflxcln = optf(swdnflxcln)
+
+      ! clouds (icloud /= 0): a hydrometeor array is handed over only when it is PRESENT and its F_Q* flag is set,
+      ! which is exactly when the reference reads it (SW:10371-10435)
+      a%cldfra3d = opt3(cldfra3d)
+      a%qc3d = c_null_ptr; a%qr3d = c_null_ptr; a%qi3d = c_null_ptr; a%qs3d = c_null_ptr; a%qndrop3d = c_null_ptr
+      IF (PRESENT(f_qc) .AND. PRESENT(qc3d)) THEN
+         IF (f_qc) a%qc3d = c_loc(qc3d)
+      END IF
+      IF (PRESENT(f_qr) .AND. PRESENT(qr3d)) THEN
+         IF (f_qr) a%qr3d = c_loc(qr3d)
+      END IF
+      IF (PRESENT(f_qi) .AND. PRESENT(qi3d)) THEN
+         IF (f_qi) a%qi3d = c_loc(qi3d)
+      END IF
+      IF (PRESENT(f_qs) .AND. PRESENT(qs3d)) THEN
+         IF (f_qs) a%qs3d = c_loc(qs3d)
+      END IF
+      IF (PRESENT(f_qndrop) .AND. PRESENT(qndrop3d)) THEN
+         IF (f_qndrop) a%qndrop3d = c_loc(qndrop3d)
+      END IF
+      a%re_cloud = c_loc(re_cloud); a%re_ice = c_loc(re_ice); a%re_snow = c_loc(re_snow)
+      a%xland = c_loc(xland); a%xice = c_loc(xice); a%snow = c_loc(snow)
+      a%has_reqc = has_reqc; a%has_reqi = has_reqi; a%has_reqs = has_reqs
+      a%warm_rain = MERGE(1, 0, warm_rain)
+      a%progn = 0
+      IF (PRESENT(progn)) a%progn = progn
+      a%is_cammgmp_used = MERGE(1, 0, is_cammgmp_used)
+      ! the Ferrier-type split of snow into ice (SW:10438-10450) needs F_ICE_PHY with F_QC, F_QS and no F_QI
+      a%f_ice_phy = 0
+      IF (PRESENT(f_ice_phy) .AND. PRESENT(f_qc) .AND. PRESENT(f_qi) .AND. PRESENT(f_qs)) THEN
+         IF (f_qc .AND. .NOT. f_qi .AND. f_qs) a%f_ice_phy = 1
+      END IF
+      a%mp_physics = mp_physics
+      a%g = REAL(g, c_double)
 
       rc = rrtmg_hip_swrad(a, err)
       IF (rc /= 0) CALL fatal_from_c(err)
