@@ -1,0 +1,63 @@
+"""Domain statistics (misc_stats_library.ncl:405-458) and the forcing decomposition
+(RadDecomp_functions.py:147-266): host arithmetic on the CPU, the device statistics kernel on the GPU."""
+import numpy as np
+import pytest
+
+
+def test_domain_stats_host_definitions(wa):
+    f = wa.forcing
+    x = np.arange(1.0, 102.0)            # 101 values: percentile points fall on exact indices
+    s = f.domain_stats_host(x[::-1])
+    assert s["avg"] == 51.0 and s["min"] == 1.0 and s["max"] == 101.0 and s["N"] == 101
+    assert s["median"] == 51.0 and s["x25"] == 26.0 and s["x75"] == 76.0 and s["x05"] == 6.0 and s["x95"] == 96.0
+    assert s["stddev"] == pytest.approx(np.std(x, ddof=1)) and s["SE"] == pytest.approx(s["stddev"] / np.sqrt(101))
+    assert s["morans_i"] == -9999.0
+    # sorted[round(p/100 (N-1))] with halves rounded away from zero (NCL round(.,3)): N = 11, 25 % -> index 2.5 -> 3
+    assert f.domain_stats_host(np.arange(11.0))["x25"] == 3.0
+    assert f.domain_stats_host([])["N"] == 0.0
+
+
+def test_decomposition_arithmetic(wa):
+    f = wa.forcing
+    rng = np.random.default_rng(5)
+    mk = lambda: {n: {"avg": float(rng.normal(100, 20)), "SE": float(rng.uniform(0.1, 1.0))}
+                  for n in ("SWUPT", "SWUPTCLN", "LWUPT", "LWUPTC")}
+    base, base_na, alt, alt_na = mk(), mk(), mk(), mk()
+    d = f.decompose(base, base_na, alt, alt_na, "SE")
+    # Delta S (total SW change, ALT - BASE at TOA upward) = direct + indirect + semi-direct (RadDecomp_functions.py:181-190)
+    delta_s = alt["SWUPT"]["avg"] - base["SWUPT"]["avg"]
+    # the identity holds when the no-aerosol clean flux equals the no-aerosol total flux (SWUPTCLN_nA == SWUPT_nA)
+    base_na["SWUPTCLN"]["avg"] = base_na["SWUPT"]["avg"]
+    alt_na["SWUPTCLN"]["avg"] = alt_na["SWUPT"]["avg"]
+    d = f.decompose(base, base_na, alt, alt_na, "SE")
+    assert d["SW_DIRECT"][0] + d["SW_INDIRECT"][0] + d["SW_SEMIDIRECT"][0] == pytest.approx(delta_s)
+    assert d["SW_DIRECT"][1] == pytest.approx(np.sqrt(base["SWUPTCLN"]["SE"] ** 2 + base["SWUPT"]["SE"] ** 2 +
+                                                      alt["SWUPTCLN"]["SE"] ** 2 + alt["SWUPT"]["SE"] ** 2))
+    lw_cre = lambda s: s["LWUPTC"]["avg"] - s["LWUPT"]["avg"]
+    assert d["LW_INDIRECT"][0] + d["LW_SEMIDIRECT"][0] == pytest.approx(lw_cre(base) - lw_cre(alt))
+
+
+@pytest.mark.gpu
+def test_domain_stats_device_matches_host(hip_lib, wa):
+    import torch
+    f = wa.forcing
+    rng = np.random.default_rng(6)
+    nj, ni = 37, 53
+    a = rng.normal(250.0, 40.0, size=(nj, ni))
+    dims = dict(ims=1, ime=ni, jms=1, jme=nj, its=4, ite=50, jts=3, jte=30)
+    t = torch.from_numpy(a).cuda()
+    got = f.domain_stats(t, dims)
+    ref = f.domain_stats_host(a[2:30, 3:50])
+    for n in f.STAT_NAMES:
+        assert got[n] == pytest.approx(ref[n], rel=1e-12), n
+    mask = (rng.uniform(size=(nj, ni)) < 0.4).astype(np.uint8)
+    got = f.domain_stats(t, dims, mask=torch.from_numpy(mask).cuda())
+    ref = f.domain_stats_host(a[2:30, 3:50][mask[2:30, 3:50] != 0])
+    for n in f.STAT_NAMES:
+        assert got[n] == pytest.approx(ref[n], rel=1e-12), n
+    t32 = torch.from_numpy(a.astype(np.float32)).cuda()
+    got = f.domain_stats(t32, dims)
+    ref = f.domain_stats_host(a.astype(np.float32).astype(np.float64)[2:30, 3:50])
+    assert got["median"] == ref["median"] and got["avg"] == pytest.approx(ref["avg"], rel=1e-12)
+    empty = f.domain_stats(t, dims, mask=torch.zeros((nj, ni), dtype=torch.uint8, device="cuda"))
+    assert empty["N"] == 0.0 and empty["avg"] == 0.0

@@ -172,6 +172,9 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
+    // nothing requested at this wavelength (output group absent): no work
+    if (w < OPT_NSW ? !(a.tauaer[w] || a.extaer[w] || a.bscoef[w]) : !(a.tauaerlw[w - OPT_NSW] || a.extaerlw[w - OPT_NSW]))
+        return;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);

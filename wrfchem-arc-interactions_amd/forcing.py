@@ -1,0 +1,89 @@
+"""Domain statistics and the Ghan-style forcing decomposition of the reference's post-processing chain, on the
+device-resident output fields.
+
+* ``domain_stats``: calc_standard_stats of analysis_scripts/NCL_extraction_package/misc_stats_library.ncl:405-458
+  through ``rrtmg_hip_domain_stats`` (sort + fixed-order reductions on the GPU).
+* ``decompose``: the combinations of analysis_scripts/RadDecomp_analysis_package/RadDecomp_functions.py:147-266
+  (SW direct / indirect / semi-direct, LW indirect / semi-direct) from the statistics of four scenarios:
+  BASE, BASE without aerosol-radiation interaction (``_nA``), ALT (emission source removed) and ALT ``_nA``.
+  Errors combine in quadrature exactly as there (``error_type`` = "stddev", "SE", ...).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .engine import ERRLEN, _check, _ptr, load_library
+
+STAT_NAMES = ["avg", "stddev", "min", "max", "median", "x25", "x75", "x05", "x95", "SE", "morans_i", "SE_corr", "N"]
+
+
+def domain_stats(field, dims, mask=None, stream=None) -> dict:
+    """field: 2-D torch CUDA tensor (nj_m, ni_m); dims: ims..jte (k entries ignored); mask: optional uint8 CUDA
+    tensor of the same shape (nonzero = use).  Returns the 13 statistics of the reference as a dict of floats."""
+    import torch
+    lib = load_library()
+    lib.rrtmg_hip_domain_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 8 + [C.c_void_p, C.c_void_p,
+                                                                                             C.c_char_p]
+    p, is_dev, size = _ptr(field)
+    if not is_dev:
+        raise ValueError("domain_stats needs a device-resident field")
+    mp = None
+    if mask is not None:
+        if mask.dtype != torch.uint8 or not mask.is_cuda or not mask.is_contiguous() or mask.shape != field.shape:
+            raise ValueError("mask must be a contiguous uint8 CUDA tensor of the field's shape")
+        mp = mask.data_ptr()
+    out = torch.zeros(13, dtype=torch.float64, device=field.device)
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib.rrtmg_hip_domain_stats(p, mp, size, dims["ims"], dims["ime"], dims["jms"], dims["jme"], dims["its"],
+                                      dims["ite"], dims["jts"], dims["jte"], out.data_ptr(), s, err), err)
+    return dict(zip(STAT_NAMES, out.cpu().tolist()))
+
+
+def domain_stats_host(values) -> dict:
+    """The same statistics with numpy (for tests and for host-resident data)."""
+    x = np.sort(np.asarray(values, dtype=np.float64).ravel())
+    n = x.size
+    if n == 0:
+        return dict(zip(STAT_NAMES, [0.0] * 13))
+    sd = float(np.std(x, ddof=1)) if n > 1 else 0.0
+
+    def pick(p):
+        v = 0.01 * p * (n - 1)
+        return x[min(max(int(v + 0.5), 0), n - 1)]
+
+    return dict(zip(STAT_NAMES, [float(x.mean()), sd, float(x[0]), float(x[-1]), pick(50.), pick(25.), pick(75.),
+                                 pick(5.), pick(95.), sd / np.sqrt(n), -9999.0, -9999.0, float(n)]))
+
+
+def _q(*errs):
+    return float(np.sqrt(sum(e * e for e in errs)))
+
+
+def decompose(base: dict, base_na: dict, alt: dict, alt_na: dict, error_type: str = "SE") -> dict:
+    """Each argument maps a field name (SWUPT, SWUPTCLN, LWUPT, LWUPTC) to its statistics dict (``domain_stats``).
+    Returns {effect: (value, error)} for SW_DIRECT, SW_INDIRECT, SW_SEMIDIRECT, LW_INDIRECT, LW_SEMIDIRECT
+    (RadDecomp_functions.py:147-266; sign conventions and error propagation as there).  LW_INDIRECT follows the
+    formula in the reference's comment (:218-221); its code reads LWUPTC_nA for both terms (:224-227), which makes
+    the reference's own LW_INDIRECT identically zero."""
+    a, e = "avg", error_type
+    out = {}
+    # SW direct = (SWUPTCLN - SWUPT)_BASE - (SWUPTCLN - SWUPT)_ALT
+    out["SW_DIRECT"] = (base["SWUPTCLN"][a] - base["SWUPT"][a] - alt["SWUPTCLN"][a] + alt["SWUPT"][a],
+                        _q(base["SWUPTCLN"][e], base["SWUPT"][e], alt["SWUPTCLN"][e], alt["SWUPT"][e]))
+    # SW indirect = SWUPTCLN_ALT_nA - SWUPTCLN_BASE_nA
+    out["SW_INDIRECT"] = (alt_na["SWUPTCLN"][a] - base_na["SWUPTCLN"][a], _q(alt_na["SWUPTCLN"][e], base_na["SWUPTCLN"][e]))
+    # SW semi-direct = SWUPTCLN_ALT - SWUPTCLN_BASE - SWUPT_ALT_nA + SWUPT_BASE_nA
+    out["SW_SEMIDIRECT"] = (alt["SWUPTCLN"][a] - base["SWUPTCLN"][a] - alt_na["SWUPT"][a] + base_na["SWUPT"][a],
+                            _q(alt["SWUPTCLN"][e], base["SWUPTCLN"][e], alt_na["SWUPT"][e], base_na["SWUPT"][e]))
+    # LW indirect = (LWUPTC - LWUPT)_BASE_nA - (LWUPTC - LWUPT)_ALT_nA
+    out["LW_INDIRECT"] = (base_na["LWUPTC"][a] - base_na["LWUPT"][a] - alt_na["LWUPTC"][a] + alt_na["LWUPT"][a],
+                          _q(base_na["LWUPTC"][e], base_na["LWUPT"][e], alt_na["LWUPTC"][e], alt_na["LWUPT"][e]))
+    # LW semi-direct = (LWUPTC - LWUPT)_BASE - (LWUPTC - LWUPT)_ALT - LW indirect
+    out["LW_SEMIDIRECT"] = (base["LWUPTC"][a] - base["LWUPT"][a] - alt["LWUPTC"][a] + alt["LWUPT"][a]
+                            - base_na["LWUPTC"][a] + base_na["LWUPT"][a] + alt_na["LWUPTC"][a] - alt_na["LWUPT"][a],
+                            _q(base["LWUPTC"][e], base["LWUPT"][e], alt["LWUPTC"][e], alt["LWUPT"][e],
+                               base_na["LWUPTC"][e], base_na["LWUPT"][e], alt_na["LWUPTC"][e], alt_na["LWUPT"][e]))
+    return out
