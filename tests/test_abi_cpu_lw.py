@@ -28,7 +28,7 @@ def test_lw_packed_tables_equal_oracle_tables(hip_lib, wa, oracle_mod, lw_table_
             assert (info["band"], info["ig"], info["ng"]) == (ib, ig, ng)
 
             def col(off, nrow):
-                return K[off + np.arange(nrow) * ng]
+                return K[off + np.arange(nrow) * info["stride"]]
 
             def same(name, off):
                 nonlocal checked
@@ -63,14 +63,14 @@ def test_lw_packed_tables_equal_oracle_tables(hip_lib, wa, oracle_mod, lw_table_
     g3 = 22   # first g of band 3
     i3 = eng.lw_table_info(lw_table_file, g3)
     t = orc.table(3, "kam0")
-    np.testing.assert_array_equal(K[i3["mlo0"] + np.arange(9 * 19) * 16], t.reshape(16, 9 * 19)[0])
+    np.testing.assert_array_equal(K[i3["mlo0"] + np.arange(9 * 19) * i3["stride"]], t.reshape(16, 9 * 19)[0])
     t = orc.table(3, "kbm0")
-    np.testing.assert_array_equal(K[i3["mup0"] + np.arange(5 * 19) * 16], t.reshape(16, 5 * 19)[0])
+    np.testing.assert_array_equal(K[i3["mup0"] + np.arange(5 * 19) * i3["stride"]], t.reshape(16, 5 * 19)[0])
     g8 = 88
     i8 = eng.lw_table_info(lw_table_file, g8)
     for slot, name in (("mlo0", "kam0"), ("mlo1", "kam2"), ("mlo2", "kam1"), ("mup0", "kbm0"), ("mup1", "kbm1")):
         t = orc.table(8, name)
-        np.testing.assert_array_equal(K[i8[slot] + np.arange(19) * 8], t.reshape(8, 19)[0], err_msg=name)
+        np.testing.assert_array_equal(K[i8[slot] + np.arange(19) * i8["stride"]], t.reshape(8, 19)[0], err_msg=name)
     assert i8["halo_lo0"] == orc.table(8, "gv0")[0] and i8["halo_lo1"] == orc.table(8, "gv1")[0]
 
 

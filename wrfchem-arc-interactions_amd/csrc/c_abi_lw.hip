@@ -165,7 +165,7 @@ extern "C" int rrtmg_hip_lw_table_info(const char *data_path, int data_real_byte
     int f[24] = {d.band, d.ig, d.ng, d.off_self, d.off_for, d.lo.off_major, d.up.off_major, d.lo.off_frac, d.up.off_frac,
                  (int)d.lo.cfg, (int)d.up.cfg,
                  d.lo.minor[0].off, d.lo.minor[1].off, d.lo.minor[2].off, d.up.minor[0].off, d.up.minor[1].off,
-                 d.lo.minor[0].nsp, d.lo.minor[1].nsp, d.lo.minor[2].nsp, d.up.minor[0].nsp, d.up.minor[1].nsp, 0, 0, 0};
+                 d.lo.minor[0].nsp, d.lo.minor[1].nsp, d.lo.minor[2].nsp, d.up.minor[0].nsp, d.up.minor[1].nsp, d.stride, 0, 0};
     std::memcpy(fields, f, sizeof f);
     double df[8] = {d.lo.fracconst, d.up.fracconst, d.lo.halo_coef[0], d.lo.halo_coef[1], d.up.halo_coef[0],
                     d.up.halo_coef[1], d.up.postscale, d.delwave};

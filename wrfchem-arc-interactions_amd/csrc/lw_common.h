@@ -65,7 +65,8 @@ struct LwRegime {
 
 struct LwGDesc {
     LwRegime lo, up;
-    int32_t band, ig, ng, off_self, off_for, pad_;
+    int32_t band, ig, ng, off_self, off_for;
+    int32_t stride;    // row stride of every table of the band: ng rounded up to a multiple of 8 doubles
     double delwave;
 };
 

@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     const int g = gbeg + (active ? lane : gcnt - 1);
     const LwGDesc *gd = tb.gdesc + g;
     LaneL L;
-    L.ng = gd->ng; L.off_self = gd->off_self; L.off_for = gd->off_for;
+    L.ng = gd->stride; L.off_self = gd->off_self; L.off_for = gd->off_for;   // row stride (padded ng)
     double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
     {
         const LwRegime R = gd->lo;

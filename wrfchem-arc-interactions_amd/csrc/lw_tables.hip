@@ -84,25 +84,25 @@ Groups make_groups(int ib)
     }
     return g;
 }
-// src [16][nrow] -> dst [nrow][ng] (weighted)
-void reduce_rows(const std::vector<double> &src, int nrow, const Groups &g, double *dst)
+// src [16][nrow] -> dst [nrow][stride] (weighted)
+void reduce_rows(const std::vector<double> &src, int nrow, const Groups &g, int stride, double *dst)
 {
     for (int r = 0; r < nrow; ++r)
         for (int igc = 0; igc < g.ng; ++igc) {
             double s = 0.;
             for (int i = g.first[igc]; i < g.first[igc + 1]; ++i) s = s + src[(size_t)i * nrow + r] * g.rw[i];
-            dst[(size_t)r * g.ng + igc] = s;
+            dst[(size_t)r * stride + igc] = s;
         }
 }
-// src [nj][16] -> dst [nj][ng]
-void reduce_vec(const std::vector<double> &src, int nj, const Groups &g, bool weighted, double *dst)
+// src [nj][16] -> dst [nj][stride]
+void reduce_vec(const std::vector<double> &src, int nj, const Groups &g, bool weighted, int stride, double *dst)
 {
     for (int j = 0; j < nj; ++j)
         for (int igc = 0; igc < g.ng; ++igc) {
             double s = 0.;
             for (int i = g.first[igc]; i < g.first[igc + 1]; ++i)
                 s = weighted ? s + src[j * MG16 + i] * g.rw[i] : s + src[j * MG16 + i];
-            dst[j * g.ng + igc] = s;
+            dst[j * stride + igc] = s;
         }
 }
 
@@ -153,6 +153,9 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
         const int band = ib + 1;
         const Groups grp = make_groups(ib);
         const int ng = grp.ng;
+        // rows are padded to a multiple of 8 doubles and tables start on 64-byte lines: a wavefront's unit-stride read
+        // of one band's row then touches one or two cache lines instead of straddling three
+        const int ngs = (ng + 7) & ~7;
         const int nrowa = NSPA[ib] * 65, nrowb = HAS_KB[ib] ? (band == 16 ? 235 : NSPB[ib] * 235) : 0;
         if (c.p + 4 > c.end) { err = "RRTMG_LW_DATA: truncated"; return 1; }
         int32_t reclen; std::memcpy(&reclen, c.p, 4); c.p += 4;
@@ -191,17 +194,19 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
         auto put_rows = [&](const std::vector<double> &src, int nrow, int pad_rows) -> int {
             if (src.empty()) return 0;
             // one guard row in front: the > 0.875 stencil reads row-1 with zero weight at the first row
-            K.resize(K.size() + (size_t)ng, 0.0);
+            K.resize((K.size() + 7) & ~size_t(7), 0.0);
+            K.resize(K.size() + (size_t)ngs, 0.0);
             int off = (int)K.size();
-            K.resize(K.size() + (size_t)(nrow + pad_rows) * ng, 0.0);
-            reduce_rows(src, nrow, grp, &K[off]);
+            K.resize(K.size() + (size_t)(nrow + pad_rows) * ngs, 0.0);
+            reduce_rows(src, nrow, grp, ngs, &K[off]);
             return off;
         };
         auto put_vec = [&](const std::vector<double> &src, int nj, bool weighted) -> int {
             if (src.empty()) return 0;
+            K.resize((K.size() + 7) & ~size_t(7), 0.0);
             int off = (int)K.size();
-            K.resize(K.size() + (size_t)nj * ng, 0.0);
-            reduce_vec(src, nj, grp, weighted, &K[off]);
+            K.resize(K.size() + (size_t)nj * ngs, 0.0);
+            reduce_vec(src, nj, grp, weighted, ngs, &K[off]);
             return off;
         };
         const int offA = put_rows(kao, nrowa, 3), offB = put_rows(kbo, nrowb, 3);
@@ -211,8 +216,8 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
         for (int m = 0; m < 3; ++m) offMA[m] = put_rows(ma[m], man[m] * 19, 12);
         for (int m = 0; m < 2; ++m) offMB[m] = put_rows(mb[m], mbn[m] * 19, 12);
         std::vector<double> g0v(ng, 0.), g1v(ng, 0.);
-        if (!gv[0].empty()) reduce_vec(gv[0], 1, grp, true, g0v.data());
-        if (!gv[1].empty()) reduce_vec(gv[1], 1, grp, true, g1v.data());
+        if (!gv[0].empty()) reduce_vec(gv[0], 1, grp, true, ng, g0v.data());
+        if (!gv[1].empty()) reduce_vec(gv[1], 1, grp, true, ng, g1v.data());
 
         // post-hoc scaling of individual g-points: band 4 upper (LW:5687-5696), band 7 upper (LW:6323-6331)
         auto postscale = [&](int ig1) -> double {
@@ -223,7 +228,7 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
 
         for (int ig = 0; ig < ng; ++ig) {
             LwGDesc &d = out.gdesc[g0 + ig];
-            d.band = ib; d.ig = ig; d.ng = ng; d.off_self = offS + ig; d.off_for = offF + ig; d.delwave = DELWAVE[ib];
+            d.band = ib; d.ig = ig; d.ng = ng; d.stride = ngs; d.off_self = offS + ig; d.off_for = offF + ig; d.delwave = DELWAVE[ib];
             LwRegime &L = d.lo, &U = d.up;
             auto init = [&](LwRegime &R) {
                 R = LwRegime{};

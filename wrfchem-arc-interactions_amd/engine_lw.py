@@ -129,7 +129,7 @@ def lw_table_info(data_path, g, real_bytes=8):
     d = np.zeros(8)
     _check(lib.rrtmg_hip_lw_table_info(data_path.encode(), real_bytes, g, f.ctypes.data, d.ctypes.data, err), err)
     names = ["band", "ig", "ng", "off_self", "off_for", "off_major_lo", "off_major_up", "off_frac_lo", "off_frac_up",
-             "cfg_lo", "cfg_up", "mlo0", "mlo1", "mlo2", "mup0", "mup1", "nlo0", "nlo1", "nlo2", "nup0", "nup1"]
+             "cfg_lo", "cfg_up", "mlo0", "mlo1", "mlo2", "mup0", "mup1", "nlo0", "nlo1", "nlo2", "nup0", "nup1", "stride"]
     out = dict(zip(names, f.tolist()))
     out.update(dict(zip(["frac_lo", "frac_up", "halo_lo0", "halo_lo1", "halo_up0", "halo_up1", "postscale_up",
                          "delwave"], d.tolist())))
