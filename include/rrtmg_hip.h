@@ -62,7 +62,7 @@ typedef struct rrtmg_hip_swrad_args {
     double solcon;           /* SOLCON */
     int aer_ra_feedback;     /* 0/1 */
     int clean_atm_diag;      /* <=0: CLN outputs are 0 (SW:9473-9478) */
-    int icloud;              /* must be 0 this release (cloud-free path) */
+    int icloud;              /* 0: cloud-free; otherwise McICA clouds from the cloud arguments below */
     int o3input;             /* 2 = use o33d inside the model domain */
     /* inputs, 2-D */
     const void *xcoszen, *albedo, *tsk;
@@ -93,6 +93,10 @@ typedef struct rrtmg_hip_swrad_args {
     int warm_rain, progn;
     int is_cammgmp_used, f_ice_phy, mp_physics;            /* CAM-MG radii and the Ferrier/HWRF splits are refused */
     double g;                                              /* gravity the driver passes (G), m s-2 */
+    /* band-resolved aerosol input of aer_opt = 2 / 3 (Fortran pointers tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw,
+     * (ims:ime, kms:kme, jms:jme, 1:14), SW:10982-10991): NULL = not associated.  Where the WRF-Chem arrays
+     * qualify (aer_ra_feedback = 1, tauaer300 and tauaer999 > 1e-9) they override these, as in the reference. */
+    const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;
 } rrtmg_hip_swrad_args;
 
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);

@@ -135,7 +135,8 @@ class SwTileIn(C.Structure):
                 + [("icloud", C.c_int)]
                 + [(n, dp) for n in CLOUD3 + CLOUD2]
                 + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
-                + [("g", C.c_double), ("seed_real4", C.c_int)])
+                + [("g", C.c_double), ("seed_real4", C.c_int)]
+                + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw")])
 
 
 SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",

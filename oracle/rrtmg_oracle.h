@@ -129,6 +129,7 @@ typedef struct {
     int has_reqc, has_reqi, has_reqs, warm_rain, progn;
     double g;
     int seed_real4;
+    const double *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   /* (i,k,j,band), optional (SW:10982-10991) */
 } SwTileIn;
 
 typedef struct {

@@ -1324,6 +1324,16 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
                     for (int k = 0; k <= nk; ++k) {
                         tauaer[nb * nlay + k] = 0.; ssaaer[nb * nlay + k] = 1.; asmaer[nb * nlay + k] = 0.;
                     }
+                if (in->tauaer3d_sw) {   /* band-resolved input of aer_opt = 2/3, SW:10982-10991 */
+                    const size_t n3 = (size_t)ni * nkm * (in->jme - in->jms + 1);
+                    for (int nb = 0; nb < SW_NBND; ++nb)
+                        for (int k = 0; k < nk; ++k) {
+                            const size_t q4 = (size_t)nb * n3 + I3(i, in->kts + k, j);
+                            tauaer[nb * nlay + k] = in->tauaer3d_sw[q4];
+                            ssaaer[nb * nlay + k] = in->ssaaer3d_sw[q4];
+                            asmaer[nb * nlay + k] = in->asyaer3d_sw[q4];
+                        }
+                }
                 if (in->aer_ra_feedback == 1) {
                     for (int nb = 0; nb < SW_NBND; ++nb) {
                         double wavemid = 0.5 * (wavemin[nb] + wavemax[nb]);

@@ -214,6 +214,8 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         !(a->tauaer300 && a->tauaer400 && a->tauaer600 && a->tauaer999 && a->gaer300 && a->gaer400 && a->gaer600 &&
           a->gaer999 && a->waer300 && a->waer400 && a->waer600 && a->waer999))
         return fail(err, "Warning: missing fields required for aerosol radiation");   // SW:10287-10305
+    if (a->tauaer3d_sw && !(a->ssaaer3d_sw && a->asyaer3d_sw))
+        return fail(err, "rrtmg_hip_swrad: tauaer3d_sw needs ssaaer3d_sw and asyaer3d_sw");
     if (sw_lds_bytes(nk) > 160 * 1024) return fail(err, "rrtmg_hip_swrad: column does not fit LDS");
     HIPCHK(hipSetDevice(st.device));
 
@@ -268,6 +270,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         k.swddir = a->swddir; k.swddni = a->swddni; k.swddif = a->swddif;
         k.swupflx = a->swupflx; k.swupflxc = a->swupflxc; k.swupflxcln = a->swupflxcln;
         k.swdnflx = a->swdnflx; k.swdnflxc = a->swdnflxc; k.swdnflxcln = a->swdnflxcln;
+        k.tauaer3d_sw = a->tauaer3d_sw; k.ssaaer3d_sw = a->ssaaer3d_sw; k.asyaer3d_sw = a->asyaer3d_sw;
         if (a->icloud != 0) {
             k.cldfra3d = a->cldfra3d; k.qc3d = a->qc3d; k.qr3d = a->qr3d; k.qi3d = a->qi3d; k.qs3d = a->qs3d;
             k.re_cloud = a->has_reqc ? a->re_cloud : nullptr; k.re_ice = a->has_reqi ? a->re_ice : nullptr;
@@ -288,6 +291,12 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         if (a->aer_ra_feedback == 1) {
             IN3(tauaer300); IN3(tauaer400); IN3(tauaer600); IN3(tauaer999);
             IN3(gaer400); IN3(gaer600); IN3(waer400); IN3(waer600);
+        }
+        {
+            const size_t n4 = n3 * SW_NBND;
+            HIPCHK(stg.in(a->tauaer3d_sw, n4, stream, &k.tauaer3d_sw));
+            HIPCHK(stg.in(a->ssaaer3d_sw, n4, stream, &k.ssaaer3d_sw));
+            HIPCHK(stg.in(a->asyaer3d_sw, n4, stream, &k.asyaer3d_sw));
         }
         if (a->icloud != 0) {
             IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);

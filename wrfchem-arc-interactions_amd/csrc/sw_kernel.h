@@ -28,6 +28,7 @@ struct SwKernelArgs {
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
     double grav;
     const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
+    const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   // (i,k,j,band) band-resolved aerosol input, optional
     const uint32_t *jump;                // KISS jump-ahead table for this layer count: [SW_NGPT][KISS_JUMP_WORDS]
     const double *cldtab;                // cloud optics coefficients [CLD_NTAB][SW_NBND][CLD_STRIDE]
     SwDeviceTables tab;

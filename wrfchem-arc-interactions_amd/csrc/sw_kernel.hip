@@ -790,6 +790,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     for (int item = tid; item < SW_NBND * nlp; item += NTHREADS) {
         const int nb = item / nlp, k = item - nb * nlp;
         double tau = 0., ssa = 1., asy = 0.;
+        if (a.tauaer3d_sw && k < nk) {   // aer_opt = 2/3 input, SW:10982-10991
+            const size_t q4 = (size_t)nb * a.ni_m * a.nk_m * a.nj_m + base3 + (size_t)k * sk;
+            tau = ldr(a.tauaer3d_sw, q4, r4); ssa = ldr(a.ssaaer3d_sw, q4, r4); asy = ldr(a.asyaer3d_sw, q4, r4);
+        }
         if (a.aer_ra_feedback == 1 && k < nk) {
             const size_t q = base3 + (size_t)k * sk;
             const double t300 = ldr(a.tauaer300, q, r4), t999 = ldr(a.tauaer999, q, r4);

@@ -55,6 +55,7 @@ MODULE module_ra_rrtmg_sw
       INTEGER(c_int) :: warm_rain, progn
       INTEGER(c_int) :: is_cammgmp_used, f_ice_phy, mp_physics
       REAL(c_double) :: g
+      TYPE(c_ptr) :: tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw
    END TYPE swrad_args
 
    INTERFACE
@@ -188,8 +189,18 @@ CONTAINS
       a%o3input = 0
       IF (PRESENT(o3input)) a%o3input = o3input
 
-      IF (ASSOCIATED(tauaer3d_sw)) CALL wrf_error_fatal( &
-         'rrtmg_swrad (HIP): band-resolved aerosol input tauaer3d_sw (aer_opt=2/3) is not supported')
+      ! band-resolved aerosol input of aer_opt = 2/3 (SW:10982-10991): (ims:ime,kms:kme,jms:jme,1:nbndsw), contiguous
+      a%tauaer3d_sw = c_null_ptr; a%ssaaer3d_sw = c_null_ptr; a%asyaer3d_sw = c_null_ptr
+      IF (ASSOCIATED(tauaer3d_sw)) THEN
+         IF (.NOT. (ASSOCIATED(ssaaer3d_sw) .AND. ASSOCIATED(asyaer3d_sw))) CALL wrf_error_fatal( &
+            'rrtmg_swrad (HIP): tauaer3d_sw is associated but ssaaer3d_sw / asyaer3d_sw are not')
+         IF (SIZE(tauaer3d_sw,1) /= ime-ims+1 .OR. SIZE(tauaer3d_sw,2) /= kme-kms+1 .OR. &
+             SIZE(tauaer3d_sw,3) /= jme-jms+1 .OR. SIZE(tauaer3d_sw,4) /= 14 .OR. &
+             .NOT. IS_CONTIGUOUS(tauaer3d_sw) .OR. .NOT. IS_CONTIGUOUS(ssaaer3d_sw) .OR. &
+             .NOT. IS_CONTIGUOUS(asyaer3d_sw)) CALL wrf_error_fatal( &
+            'rrtmg_swrad (HIP): tauaer3d_sw must be a contiguous (ims:ime,kms:kme,jms:jme,14) array')
+         a%tauaer3d_sw = c_loc(tauaer3d_sw); a%ssaaer3d_sw = c_loc(ssaaer3d_sw); a%asyaer3d_sw = c_loc(asyaer3d_sw)
+      END IF
       IF (PRESENT(aer_opt)) THEN
          IF (aer_opt == 1) CALL wrf_error_fatal('rrtmg_swrad (HIP): aer_opt=1 (Tegen climatology) is not supported')
       END IF
