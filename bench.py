@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--night", type=float, default=0.0, help="fraction of night columns (0 for kernel timing)")
     ap.add_argument("--cpu-sample", type=int, default=6000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--clouds", type=float, default=0.0,
+                    help="fraction of columns with 1-3 cloud decks (McICA path; 0 = cloud-free headline workload)")
     args = ap.parse_args()
 
     import torch
@@ -178,11 +180,17 @@ def main():
     lw12 = ["lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
             "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
 
+    cld_flags, cld_in = dict(icloud=0), {}
+    if args.clouds > 0.0:
+        from tests.helpers import cloud_arrays
+        cld_flags = wa.synth_clouds.add_clouds(st, seed=20260007 + 1000 * rank, cloudy_fraction=args.clouds)
+        cld_in = {n: dev(v) for n, v in cloud_arrays(st, cld_flags).items()}
+
     def sw_call():
-        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **sw_in, **sw_out)
+        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **sw_in, **cld_in, **sw_out)
 
     def lw_call():
-        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **lw_in, **lw_out)
+        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **lw_in, **cld_in, **lw_out)
 
     def gather_sums():
         # the only exchange on the path: per-tile flux / forcing sums for the domain means
@@ -266,7 +274,9 @@ def main():
         what = "SW+LW" if do_lw else "RRTMG-SW"
         if do_opt:
             workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic columns per GPU, MOSAIC {args.nbin}-bin optical "
-                        "averaging + SW+LW aerosol+clean double-call, fp64, cloud-free (BASELINE configs[2])")
+                        "averaging + SW+LW aerosol+clean double-call, fp64, "
+                        + (f"McICA clouds in {100 * args.clouds:.0f} % of the columns" if args.clouds > 0 else "cloud-free")
+                        + " (BASELINE configs[2])")
         elif do_lw:
             workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, SW+LW aerosol+clean "
                         "double-call, fp64, cloud-free; aerosol optics supplied in the WRF-Chem compact form "
@@ -292,7 +302,7 @@ def main():
                          "step_algorithmic_GBs": ncol * (bpc + obpc) / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
                          "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.clouds <= 0.0:
             try:
                 if do_opt:   # the CPU leg runs the radiation on the optics the device produced
                     for n, t in list(sw_in.items()) + list(lw_in.items()):

@@ -987,15 +987,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     if (pass == 1 && a.clean <= 0) {
         // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
         for (int l = lane; l < nlev; l += 64) { flux[2 * l] = 0.; flux[2 * l + 1] = 0.; }
-    } else {
-        // waves 0,1: total sky with aerosol (call #1); waves 2,3: total sky without aerosol (call #2, SW:9439-9467)
-        run_pass(pass == 0, cmask, flux, pass == 0);
     }
-    if (col_cloudy) {
-        // a cloudy column also needs the clear-sky fluxes of call #1 (zbbcu / zbbcd, SW:8405-8416, 8590-8593):
-        // a third pass without cloud on the two aerosol waves; cloud-free columns reuse the total-sky result
-        __syncthreads();
-        if (pass == 0) run_pass(true, 0, c.fluxc + (size_t)wave * nlev * 2, false);
+    // Round 0 -- waves 0,1: total sky with aerosol (call #1); waves 2,3: total sky without aerosol (call #2,
+    // SW:9439-9467).  Round 1, cloudy columns only -- the clear-sky fluxes of call #1 (zbbcu / zbbcd, SW:8405-8416,
+    // 8590-8593): a pass without cloud on the two aerosol waves; cloud-free columns reuse the total-sky result.
+    // One call site inside the loop keeps a single copy of the pass in the instruction cache.
+    const int nround = col_cloudy ? 2 : 1;
+    for (int r = 0; r < nround; ++r) {
+        if (r == 1) __syncthreads();
+        const bool run = r == 0 ? !(pass == 1 && a.clean <= 0) : pass == 0;
+        if (run) run_pass(r == 0 ? pass == 0 : true, r == 0 ? cmask : 0, r == 0 ? flux : c.fluxc + (size_t)wave * nlev * 2,
+                          r == 0 && pass == 0);
     }
     if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
