@@ -444,8 +444,7 @@ __device__ __forceinline__ void cloud_optics(const double *T, const ColView &c, 
 // direct-beam transmittance (SW:8568-8578).  dbt_nodel: unscaled direct beam
 // (SW:8459-8469), only requested by the aerosol pass on its way down.
 // cloudy: this sub-column (lane) has cloud in layer k -- total-sky properties per SW:8505-8510, 8476-8486.
-template <bool NODEL>
-__device__ __forceinline__ void layer_rt(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
+__device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
                                          bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel,
                                          bool cloudy = false, int iceflag = 3, const double *cldtab = nullptr,
                                          int *bad = nullptr)
@@ -913,7 +912,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             }
             RT rt;
             double dummy;
-            layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy, (mask >> k) & 1, iceflag, a.cldtab, &bad);
+            layer_rt(false, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy, (mask >> k) & 1, iceflag, a.cldtab, &bad);
             // vrtqdr_sw, SW:7997-8015
             double zreflect = frcp(1. -rupd * rt.refd);
             double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
@@ -933,8 +932,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
                 const int k = b * BLK + j;
                 if (k < nlay) {
                     const bool cl = (mask >> k) & 1;
-                    if (want_sfc) layer_rt<true>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad);
-                    else { layer_rt<false>(tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad); dn[j] = 1.; }
+                    dn[j] = 1.;
+                    layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad);
                 } else {
                     rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
                 }
