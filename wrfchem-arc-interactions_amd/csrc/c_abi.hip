@@ -323,7 +323,22 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                       a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
         return fail(err, "rrtmg_hip_swrad: the twelve TOA/surface flux arrays must be passed together");
 
-    HIPCHK(sw_launch(k, ni_t * nj_t, stream));
+    k.ncol = ni_t * nj_t;
+    const int nblocks = sw_grid_blocks(k.ncol);
+    {
+        const size_t need = sw_scratch_doubles_per_block(k.nk) * (size_t)nblocks;
+        std::lock_guard<std::mutex> lock(st.jump_mutex);
+        SwState::Scratch &w = st.scratch[stream];
+        if (w.doubles < need) {
+            if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
+            void *p = nullptr;
+            HIPCHK(hipMalloc(&p, need * sizeof(double)));
+            w.p = static_cast<double *>(p);
+            w.doubles = need;
+        }
+        k.scratch = w.p;
+    }
+    HIPCHK(sw_launch(k, nblocks, stream));
 
     if (a->mem != 1) {
         for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
@@ -368,6 +383,8 @@ extern "C" int rrtmg_hip_finalize(void)
     if (st.dCld) (void)hipFree(st.dCld);
     for (auto &kv : st.dJump) if (kv.second) (void)hipFree(kv.second);
     st.dJump.clear();
+    for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    st.scratch.clear();
     st.dK = st.dExp = st.dG = st.dStatus = st.dCld = nullptr;
     st.ready = false;
     return 0;

@@ -28,6 +28,9 @@ struct SwState {
     void *dCld = nullptr;                  // cloud optics coefficient tables (sw_cloud_tables)
     std::map<int, void *> dJump;           // KISS jump tables by layer count
     std::mutex jump_mutex;
+    // layer scratch of the column kernel, one grow-only buffer per stream (guarded by jump_mutex)
+    struct Scratch { double *p = nullptr; size_t doubles = 0; };
+    std::map<void *, Scratch> scratch;
 };
 
 SwState &sw_state();

@@ -31,6 +31,8 @@ struct SwKernelArgs {
     const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   // (i,k,j,band) band-resolved aerosol input, optional
     const uint32_t *jump;                // KISS jump-ahead table for this layer count: [SW_NGPT][KISS_JUMP_WORDS]
     const double *cldtab;                // cloud optics coefficients [CLD_NTAB][SW_NBND][CLD_STRIDE]
+    double *scratch;                     // sw_grid_blocks() x sw_scratch_doubles_per_block() doubles
+    int ncol;                            // columns of the tile (the grid is persistent)
     SwDeviceTables tab;
 };
 
@@ -45,6 +47,8 @@ hipError_t sw_upload_retab();
 
 size_t sw_lds_bytes(int nk);
 hipError_t sw_upload_constants(hipStream_t stream);
-hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream);
+size_t sw_scratch_doubles_per_block(int nk);
+int sw_grid_blocks(int ncol);
+hipError_t sw_launch(const SwKernelArgs &a, int nblocks, hipStream_t stream);
 
 }  // namespace rrtmg

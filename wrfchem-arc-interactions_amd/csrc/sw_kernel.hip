@@ -36,6 +36,7 @@ namespace rrtmg {
 
 namespace {
 
+constexpr int SW_SCR_VALS = 6;     // ref, refd, tra, trad, dbt, dbt_nodel per (layer, lane)
 constexpr int BLK = 4;            // layers per recompute block
 constexpr int CHUNK = 56;         // g-points per wave (112 = 2 x 56)
 constexpr int NTHREADS = 256;
@@ -304,17 +305,21 @@ struct LaneG {   // per-lane (g-point) constants
 };
 
 // gaseous + Rayleigh optical depth of layer k for this lane's g-point: the
-// 14 taumolNN routines (SW:3293-4540) as one data-driven expression
-__device__ __forceinline__ void gas_optics(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
-                                           bool lower, double &taug, double &taur)
+// 14 taumolNN routines (SW:3293-4540) as one data-driven expression, in two steps so that the table reads of the
+// next layer are in flight while the current layer is worked on (gas_fetch issues them, gas_finish consumes them).
+struct GasPre {
+    double kv[8], s0, s1, f0, f1, r0, r1, fs, speccomb;
+};
+
+__device__ __forceinline__ void gas_fetch(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
+                                          bool lower, GasPre &p)
 {
     const GRegime &R = lower ? L.lo : L.up;
     const uint32_t cf = R.cfg;
     const int nlp = c.nlp;
-    const int spa = (cf >> CFG_SPA_SHIFT) & 7, spb = (cf >> CFG_SPB_SHIFT) & 7, spm = (cf >> CFG_SPM_SHIFT) & 7;
+    const int spa = (cf >> CFG_SPA_SHIFT) & 7, spb = (cf >> CFG_SPB_SHIFT) & 7;
     const int nsp = (cf >> CFG_NSP_SHIFT) & 15;
-    const double colA = c.col[spa * nlp + k], colB = c.col[spb * nlp + k], colM = c.col[spm * nlp + k];
-    const double colh2o = c.col[SP_H2O * nlp + k];
+    const double colA = c.col[spa * nlp + k], colB = c.col[spb * nlp + k];
     double speccomb = colA, fs = 0.;
     int jsi = 0;
     if (cf & CFG_BINARY) {
@@ -326,35 +331,54 @@ __device__ __forceinline__ void gas_optics(const SwDeviceTables &tb, const ColVi
         jsi = (int)specmult;
         fs = specmult - (double)jsi;
     }
-    const double f00 = c.fac00[k], f10 = c.fac10[k], f01 = c.fac01[k], f11 = c.fac11[k];
-    const double omf = 1. - fs;
+    p.fs = fs; p.speccomb = speccomb;
     const int ng = L.ng;
     const double *K0 = tb.K + R.off_major + (size_t)(c.rb0[k] * nsp + jsi) * ng;
     const double *K1 = tb.K + R.off_major + (size_t)(c.rb1[k] * nsp + jsi) * ng;
     const int dT = nsp * ng;
-    // SW:3342-3350 (8-point) / SW:3374-3378 (4-point: fs = 0, zero-weight terms are exact)
-    double S = (omf * f00) * K0[0] + (fs * f00) * K0[ng] + (omf * f10) * K0[dT] + (fs * f10) * K0[dT + ng] +
-               (omf * f01) * K1[0] + (fs * f01) * K1[ng] + (omf * f11) * K1[dT] + (fs * f11) * K1[dT + ng];
-    double major = (cf & CFG_MAJOR) ? (speccomb * R.mfac) * S : 0.;
-    // continua, SW:3351-3357
-    double cont = 0.;
+    p.kv[0] = K0[0]; p.kv[1] = K0[ng]; p.kv[2] = K0[dT]; p.kv[3] = K0[dT + ng];
+    p.kv[4] = K1[0]; p.kv[5] = K1[ng]; p.kv[6] = K1[dT]; p.kv[7] = K1[dT + ng];
+    p.s0 = p.s1 = p.f0 = p.f1 = 0.;
     if (cf & (CFG_SELF | CFG_FOR)) {
         const double *Sf = tb.K + L.off_self + (size_t)c.inds[k] * ng;
         const double *Ff = tb.K + L.off_for + (size_t)c.indf[k] * ng;
-        double s0 = Sf[0], s1 = Sf[ng], f0 = Ff[0], f1 = Ff[ng];
-        double selft = (cf & CFG_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
-        double fort = (cf & CFG_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
+        p.s0 = Sf[0]; p.s1 = Sf[ng]; p.f0 = Ff[0]; p.f1 = Ff[ng];
+    }
+    p.r0 = p.r1 = 0.;
+    if (cf & CFG_RAYL24) {   // SW:4130-4131
+        const double *Ra = tb.K + L.off_rayla + (size_t)jsi * ng;
+        p.r0 = Ra[0]; p.r1 = Ra[ng];
+    }
+}
+
+__device__ __forceinline__ void gas_finish(const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
+                                           bool lower, const GasPre &p, double &taug, double &taur)
+{
+    const GRegime &R = lower ? L.lo : L.up;
+    const uint32_t cf = R.cfg;
+    const int nlp = c.nlp;
+    const int spm = (cf >> CFG_SPM_SHIFT) & 7;
+    const double colM = c.col[spm * nlp + k];
+    const double colh2o = c.col[SP_H2O * nlp + k];
+    const double fs = p.fs;
+    const double f00 = c.fac00[k], f10 = c.fac10[k], f01 = c.fac01[k], f11 = c.fac11[k];
+    const double omf = 1. - fs;
+    // SW:3342-3350 (8-point) / SW:3374-3378 (4-point: fs = 0, zero-weight terms are exact)
+    double S = (omf * f00) * p.kv[0] + (fs * f00) * p.kv[1] + (omf * f10) * p.kv[2] + (fs * f10) * p.kv[3] +
+               (omf * f01) * p.kv[4] + (fs * f01) * p.kv[5] + (omf * f11) * p.kv[6] + (fs * f11) * p.kv[7];
+    double major = (cf & CFG_MAJOR) ? (p.speccomb * R.mfac) * S : 0.;
+    // continua, SW:3351-3357
+    double cont = 0.;
+    if (cf & (CFG_SELF | CFG_FOR)) {
+        double selft = (cf & CFG_SELF) ? c.selffac[k] * (p.s0 + c.selffrac[k] * (p.s1 - p.s0)) : 0.;
+        double fort = (cf & CFG_FOR) ? c.forfac[k] * (p.f0 + c.forfrac[k] * (p.f1 - p.f0)) : 0.;
         cont = colh2o * (selft + fort);
     }
     double t = major + colM * R.minorabs + cont;
     if (cf & CFG_O2CONT) t += 4.35e-4 * c.col[SP_O2 * nlp + k] / (350.0 * 2.0);   // SW:3933
     taug = t;
     double rayl = R.rayl;
-    if (cf & CFG_RAYL24) {   // SW:4130-4131
-        const double *Ra = tb.K + L.off_rayla + (size_t)jsi * ng;
-        double r0 = Ra[0], r1 = Ra[ng];
-        rayl = r0 + fs * (r1 - r0);
-    }
+    if (cf & CFG_RAYL24) rayl = p.r0 + fs * (p.r1 - p.r0);
     taur = c.colmol[k] * rayl;
 }
 
@@ -446,11 +470,11 @@ __device__ __forceinline__ void cloud_optics(const double *T, const ColView &c, 
 // cloudy: this sub-column (lane) has cloud in layer k -- total-sky properties per SW:8505-8510, 8476-8486.
 __device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
                                          bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel,
-                                         bool cloudy = false, int iceflag = 3, const double *cldtab = nullptr,
-                                         int *bad = nullptr)
+                                         const GasPre &gp, bool cloudy = false, int iceflag = 3,
+                                         const double *cldtab = nullptr, int *bad = nullptr)
 {
     double taug, taur;
-    gas_optics(tb, c, L, k, lower, taug, taur);
+    gas_finish(tb, c, L, k, lower, gp, taug, taur);
     const int ia = L.band * c.nlp + k;
     const double ta = aer_on ? c.taer[ia] : 0.0;   // clean call: ztauacln = 0 (SW:9346), omega/g unchanged
     const double wa = c.waer[ia], ga = c.gaer[ia];
@@ -484,11 +508,14 @@ __device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables 
 
 }  // namespace
 
-__global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelArgs a)
+// One column: vb = position of the column in the XCD-interleaved order, scr = this workgroup's slice of the
+// layer scratch (SW_SCR_VALS values per wave, layer and lane).
+__device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, double *lds, double *scr_block)
 {
-    extern __shared__ double lds[];
     const SwDeviceTables &tb = a.tab;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
     ColView c = carve(lds, nlp, nblk, nlev);
@@ -496,7 +523,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
     int col;
     {
-        const int b = blockIdx.x, nwg = gridDim.x;
+        const int b = vb, nwg = a.ncol;
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         col = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
@@ -898,6 +925,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
     const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
     double *ck = c.ckpt + (size_t)wave * nblk * 2 * 64;
+    double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * 64 + lane;
     int bad = 0;
 
     // One spcvmc_sw pass of this wave's 56 sub-columns: aer_on = with aerosol optical depth, mask = the
@@ -905,14 +933,27 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     auto run_pass = [&](const bool aer_on, const uint64_t mask, double *flux, const bool want_sfc) {
         // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
         double rup = alb, rupd = alb;
+        GasPre gp;
+        gas_fetch(tb, c, L, 0, 0 < laytrop, gp);
         for (int k = 0; k < nlay; ++k) {
+            GasPre gn;   // next layer's table reads go out before this layer's arithmetic
+            {
+                const int kn = k + 1 < nlay ? k + 1 : k;
+                gas_fetch(tb, c, L, kn, kn < laytrop, gn);
+            }
             if ((k & (BLK - 1)) == 0) {
                 ck[((k / BLK) * 2 + 0) * 64 + lane] = rup;
                 ck[((k / BLK) * 2 + 1) * 64 + lane] = rupd;
             }
             RT rt;
-            double dummy;
-            layer_rt(false, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dummy, (mask >> k) & 1, iceflag, a.cldtab, &bad);
+            double dnl = 1.;
+            layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dnl, gp, (mask >> k) & 1, iceflag, a.cldtab, &bad);
+            gp = gn;
+            {   // keep the layer's two-stream result for the way down
+                double *s = scr + (size_t)k * SW_SCR_VALS * 64;
+                s[0] = rt.ref; s[64] = rt.refd; s[128] = rt.tra; s[192] = rt.trad; s[256] = rt.dbt;
+                if (want_sfc) s[320] = dnl;
+            }
             // vrtqdr_sw, SW:7997-8015
             double zreflect = frcp(1. -rupd * rt.refd);
             double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
@@ -931,9 +972,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
             for (int j = 0; j < BLK; ++j) {
                 const int k = b * BLK + j;
                 if (k < nlay) {
-                    const bool cl = (mask >> k) & 1;
-                    dn[j] = 1.;
-                    layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt[j], dn[j], cl, iceflag, a.cldtab, &bad);
+                    const double *s = scr + (size_t)k * SW_SCR_VALS * 64;
+                    rt[j].ref = s[0]; rt[j].refd = s[64]; rt[j].tra = s[128]; rt[j].trad = s[192]; rt[j].dbt = s[256];
+                    dn[j] = want_sfc ? s[320] : 1.;
                 } else {
                     rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
                 }
@@ -1054,6 +1095,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelAr
     }
 }
 
+// Persistent workgroups: each walks the columns blockIdx.x, blockIdx.x + gridDim.x, ... so that the layer scratch
+// is one slice per resident workgroup, whatever the tile size.
+__global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelArgs a)
+{
+    extern __shared__ double lds[];
+    double *scr = a.scratch + (size_t)blockIdx.x * (4 * (size_t)(a.nk + 1) * SW_SCR_VALS * 64);
+    for (int vb = blockIdx.x; vb < a.ncol; vb += gridDim.x) {
+        sw_column(a, vb, lds, scr);
+        __syncthreads();
+    }
+}
+
+size_t sw_scratch_doubles_per_block(int nk) { return 4 * (size_t)(nk + 1) * SW_SCR_VALS * 64; }
+
+int sw_grid_blocks(int ncol)
+{
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int g = 2 * ncu;   // __launch_bounds__(NTHREADS, 2), LDS for two workgroups per CU
+    return ncol < g ? ncol : g;
+}
+
 // ---------------------------------------------------------------------------
 size_t sw_lds_bytes(int nk)
 {
@@ -1110,7 +1173,7 @@ hipError_t sw_upload_retab()
     return hipMemcpyToSymbol(HIP_SYMBOL(c_retab), CLD_RETAB, sizeof(double) * 95);
 }
 
-hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream)
+hipError_t sw_launch(const SwKernelArgs &a, int nblocks, hipStream_t stream)
 {
     const size_t lds = sw_lds_bytes(a.nk);
     static size_t attr_bytes = 0;   // grow-only opt-in for > 64 KB of dynamic LDS
@@ -1120,7 +1183,7 @@ hipError_t sw_launch(const SwKernelArgs &a, int ncol, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_bytes = lds;
     }
-    hipLaunchKernelGGL(sw_column_kernel, dim3(ncol), dim3(NTHREADS), lds, stream, a);
+    hipLaunchKernelGGL(sw_column_kernel, dim3(nblocks), dim3(NTHREADS), lds, stream, a);
     return hipGetLastError();
 }
 
