@@ -60,6 +60,17 @@ def test_host_pointer_mode_equals_device_mode(eng, wa):
         np.testing.assert_array_equal(a[n], b[n], err_msg=n)
 
 
+def test_scratch_cap_splits_the_tile_into_launches(eng, wa, monkeypatch):
+    """RRTMG_HIP_SW_SCRATCH_MB bounds the layer scratch: a tile larger than the cap is worked off in several
+    launches (here 8 columns each) and gives the same bits as a single launch."""
+    st = wa.synth.make_wrf_state(7, 5, 40, seed=20260155, night_fraction=0.2)
+    one = run_hip_swrad(eng, st, device=True)
+    monkeypatch.setenv("RRTMG_HIP_SW_SCRATCH_MB", "1")
+    many = run_hip_swrad(eng, st, device=True)
+    for n in one:
+        np.testing.assert_array_equal(one[n], many[n], err_msg=n)
+
+
 def test_clean_diag_off_gives_zero_cln(eng, sw_oracle, wa):
     st = wa.synth.make_wrf_state(4, 2, 40, seed=20260112)
     got = run_hip_swrad(eng, st, clean=0)

@@ -323,22 +323,37 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                       a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
         return fail(err, "rrtmg_hip_swrad: the twelve TOA/surface flux arrays must be passed together");
 
-    k.ncol = ni_t * nj_t;
-    const int nblocks = sw_grid_blocks(k.ncol);
+    // scratch of this stream: as many columns per launch as RRTMG_HIP_SW_SCRATCH_MB (default 16384) holds
     {
-        const size_t need = sw_scratch_doubles_per_block(k.nk) * (size_t)nblocks;
-        std::lock_guard<std::mutex> lock(st.jump_mutex);
-        SwState::Scratch &w = st.scratch[stream];
-        if (w.doubles < need) {
-            if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
-            void *p = nullptr;
-            HIPCHK(hipMalloc(&p, need * sizeof(double)));
-            w.p = static_cast<double *>(p);
-            w.doubles = need;
+        const int ncol_all = ni_t * nj_t;
+        size_t mb = 16384;
+        if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
+            const long v = std::atol(e);
+            if (v > 0) mb = (size_t)v;
         }
-        k.scratch = w.p;
+        const size_t percol = sw_scratch_doubles_per_column(k.nk);
+        size_t cols = (mb << 20) / (percol * sizeof(double));
+        if (cols < 8) cols = 8;
+        const int cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
+        {
+            std::lock_guard<std::mutex> lock(st.jump_mutex);
+            SwState::Scratch &w = st.scratch[stream];
+            if (w.doubles < percol * (size_t)cap_cols) {
+                if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
+                void *p = nullptr;
+                HIPCHK(hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double)));
+                w.p = static_cast<double *>(p);
+                w.doubles = percol * (size_t)cap_cols;
+            }
+            k.scratch = w.p;
+        }
+        k.scratch_stride = percol;
+        for (int c0 = 0; c0 < ncol_all; c0 += cap_cols) {
+            k.col0 = c0;
+            k.ncol = ncol_all - c0 < cap_cols ? ncol_all - c0 : cap_cols;
+            HIPCHK(sw_launch(k, stream));
+        }
     }
-    HIPCHK(sw_launch(k, nblocks, stream));
 
     if (a->mem != 1) {
         for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));

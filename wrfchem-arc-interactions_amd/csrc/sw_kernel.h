@@ -31,8 +31,9 @@ struct SwKernelArgs {
     const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   // (i,k,j,band) band-resolved aerosol input, optional
     const uint32_t *jump;                // KISS jump-ahead table for this layer count: [SW_NGPT][KISS_JUMP_WORDS]
     const double *cldtab;                // cloud optics coefficients [CLD_NTAB][SW_NBND][CLD_STRIDE]
-    double *scratch;                     // sw_grid_blocks() x sw_scratch_doubles_per_block() doubles
-    int ncol;                            // columns of the tile (the grid is persistent)
+    double *scratch;                     // ncol x scratch_stride doubles
+    size_t scratch_stride;               // sw_scratch_doubles_per_column(nk)
+    int col0, ncol;                      // this launch covers columns col0 .. col0+ncol-1 of the tile
     SwDeviceTables tab;
 };
 
@@ -47,8 +48,7 @@ hipError_t sw_upload_retab();
 
 size_t sw_lds_bytes(int nk);
 hipError_t sw_upload_constants(hipStream_t stream);
-size_t sw_scratch_doubles_per_block(int nk);
-int sw_grid_blocks(int ncol);
-hipError_t sw_launch(const SwKernelArgs &a, int nblocks, hipStream_t stream);
+size_t sw_scratch_doubles_per_column(int nk);
+hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream);
 
 }  // namespace rrtmg

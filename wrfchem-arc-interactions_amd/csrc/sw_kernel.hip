@@ -16,11 +16,15 @@
 //   * main phase: lanes = g-points.  Wave w handles g-chunk (w&1) of pass
 //     (w>>1): pass 0 = with aerosol, pass 1 = clean sky.  Gas optics are
 //     evaluated by one data-driven formula (per-g descriptor) so the 14 bands
-//     never diverge.  The vertical adding recurrence is sequential in k per
-//     lane; to avoid a per-lane, per-level fp64 store of the whole profile
-//     (43 KB per wave), the upward sweep keeps only every 4th level in LDS
-//     and the downward sweep recomputes the layer reflectances block by block
-//     (register-resident, statically indexed).
+//     never diverge; its table reads are issued one layer ahead.  The vertical
+//     adding recurrence is sequential in k per lane.  The upward sweep writes
+//     each layer's two-stream result (5-6 doubles per lane) and every 4th level
+//     of the recurrence to the column's scratch slice in HBM (coalesced 512-B
+//     rows, 590 KB per column at 41 layers); the downward sweep reads them back
+//     block by block instead of evaluating the layers a second time.  That
+//     trades 37 GB of streaming per 40 000 columns for 45 % of the fp64
+//     instructions and frees the LDS the checkpoints took, so three workgroups
+//     fit on a CU (measured: 15.5 -> 12.0 ms).
 //   * per-level spectral sums (SW:8629-8634) are wave reductions; the two
 //     chunk waves of a pass meet in LDS; the epilogue (lanes = levels) forms
 //     net fluxes, heating rates and writes the WRF arrays.
@@ -37,7 +41,7 @@ namespace rrtmg {
 namespace {
 
 constexpr int SW_SCR_VALS = 6;     // ref, refd, tra, trad, dbt, dbt_nodel per (layer, lane)
-constexpr int BLK = 4;            // layers per recompute block
+constexpr int BLK = 4;            // levels between checkpoints of the upward sweep = layers per block on the way down
 constexpr int CHUNK = 56;         // g-points per wave (112 = 2 x 56)
 constexpr int NTHREADS = 256;
 
@@ -266,7 +270,6 @@ struct ColView {
     double *colmol, *pdp;
     double *taer, *waer, *gaer;   // [14][nlp]
     int *rb0, *rb1, *inds, *indf, *jp;   // row bases (0-based), continuum rows, jp
-    double *ckpt;       // [4 waves][nck][2][64]
     double *flux;       // [4 waves][nlev][2]
     double *sfc;        // [4 waves][8] surface-only sums
     double *fluxc;      // [2 waves][nlev][2] clear-sky (aerosol) fluxes of a cloudy column
@@ -287,7 +290,6 @@ __device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nle
     v.col = p; p += SP_COUNT * nlp;
     v.colmol = p; p += nlp; v.pdp = p; p += nlp;
     v.taer = p; p += SW_NBND * nlp; v.waer = p; p += SW_NBND * nlp; v.gaer = p; p += SW_NBND * nlp;
-    v.ckpt = p; p += 4 * nck * 2 * 64;
     v.flux = p; p += 4 * nlev * 2;
     v.sfc = p; p += 4 * 8;
     v.fluxc = p; p += 2 * nlev * 2;
@@ -513,9 +515,7 @@ __device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables 
 __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, double *lds, double *scr_block)
 {
     const SwDeviceTables &tb = a.tab;
-    int tid_ = threadIdx.x;
-    asm volatile("" : "+v"(tid_));
-    const int tid = tid_, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
     ColView c = carve(lds, nlp, nblk, nlev);
@@ -523,9 +523,9 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
     int col;
     {
-        const int b = vb, nwg = a.ncol;
+        const int b = vb, nwg = a.ncol;   // columns of this launch (a chunk of the tile)
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        col = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        col = a.col0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int it = col % a.ni_t, jt = col / a.ni_t;            // position inside the tile
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt);
@@ -924,7 +924,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     const double adjflux = 1.0 * (a.solcon / 1.36822e+03);   // adjes = 1, dyofyr = 0 (SW:10623-10626, 9735-9739)
     const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
     const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
-    double *ck = c.ckpt + (size_t)wave * nblk * 2 * 64;
+    double *ck = scr_block + (size_t)4 * nlay * SW_SCR_VALS * 64 + (size_t)wave * nblk * 2 * 64;
     double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * 64 + lane;
     int bad = 0;
 
@@ -961,7 +961,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             rup = nrup; rupd = nrupd;
         }
 
-        // ---- downward sweep by blocks: recompute the block's layers, then descend ----
+        // ---- downward sweep by blocks: read the block's layers back, rebuild its upward reflectances, descend ----
         double tdn = 1., rdnd = 0., tdbt = 1., tdbt_nodel = 1.;
         for (int b = nblk - 1; b >= 0; --b) {
             RT rt[BLK];
@@ -1095,26 +1095,19 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     }
 }
 
-// Persistent workgroups: each walks the columns blockIdx.x, blockIdx.x + gridDim.x, ... so that the layer scratch
-// is one slice per resident workgroup, whatever the tile size.
-__global__ void __launch_bounds__(NTHREADS, 2) sw_column_kernel(const SwKernelArgs a)
+// One workgroup per column of the launch; its scratch slice: the layers' two-stream results [4 waves][nlay][6][64]
+// and the upward sweep's checkpoints [4 waves][nblk][2][64].
+__global__ void __launch_bounds__(NTHREADS, 3) sw_column_kernel(const SwKernelArgs a)
 {
     extern __shared__ double lds[];
-    double *scr = a.scratch + (size_t)blockIdx.x * (4 * (size_t)(a.nk + 1) * SW_SCR_VALS * 64);
-    for (int vb = blockIdx.x; vb < a.ncol; vb += gridDim.x) {
-        sw_column(a, vb, lds, scr);
-        __syncthreads();
-    }
+    double *scr = a.scratch + (size_t)blockIdx.x * a.scratch_stride;
+    sw_column(a, blockIdx.x, lds, scr);
 }
 
-size_t sw_scratch_doubles_per_block(int nk) { return 4 * (size_t)(nk + 1) * SW_SCR_VALS * 64; }
-
-int sw_grid_blocks(int ncol)
+size_t sw_scratch_doubles_per_column(int nk)
 {
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int g = 2 * ncu;   // __launch_bounds__(NTHREADS, 2), LDS for two workgroups per CU
-    return ncol < g ? ncol : g;
+    const size_t nlay = nk + 1, nblk = (nlay + BLK - 1) / BLK;
+    return 4 * nlay * SW_SCR_VALS * 64 + 4 * nblk * 2 * 64;
 }
 
 // ---------------------------------------------------------------------------
@@ -1122,7 +1115,7 @@ size_t sw_lds_bytes(int nk)
 {
     const int nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
-    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)4 * nblk * 2 * 64 + (size_t)6 * nlev * 2 + 32;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)6 * nlev * 2 + 32;
     size_t ni = (size_t)nlp * 8 + 1 + 4;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
@@ -1173,7 +1166,7 @@ hipError_t sw_upload_retab()
     return hipMemcpyToSymbol(HIP_SYMBOL(c_retab), CLD_RETAB, sizeof(double) * 95);
 }
 
-hipError_t sw_launch(const SwKernelArgs &a, int nblocks, hipStream_t stream)
+hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream)
 {
     const size_t lds = sw_lds_bytes(a.nk);
     static size_t attr_bytes = 0;   // grow-only opt-in for > 64 KB of dynamic LDS
@@ -1183,7 +1176,7 @@ hipError_t sw_launch(const SwKernelArgs &a, int nblocks, hipStream_t stream)
         if (e != hipSuccess) return e;
         attr_bytes = lds;
     }
-    hipLaunchKernelGGL(sw_column_kernel, dim3(nblocks), dim3(NTHREADS), lds, stream, a);
+    hipLaunchKernelGGL(sw_column_kernel, dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
     return hipGetLastError();
 }
 
