@@ -323,10 +323,10 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                       a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
         return fail(err, "rrtmg_hip_swrad: the twelve TOA/surface flux arrays must be passed together");
 
-    // scratch of this stream: as many columns per launch as RRTMG_HIP_SW_SCRATCH_MB (default 16384) holds
+    // scratch of this stream: as many columns per launch as RRTMG_HIP_SW_SCRATCH_MB (default 32768) holds
     {
         const int ncol_all = ni_t * nj_t;
-        size_t mb = 16384;
+        size_t mb = 32768;
         if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;
