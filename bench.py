@@ -40,10 +40,15 @@ def algorithmic_bytes_per_column(nk, mode, real_bytes=8):
     return (sw + (lw if mode != "sw" else 0)) * real_bytes, sw * real_bytes, lw * real_bytes
 
 
-def optics_bytes_per_column(nk, nbin, real_bytes=8):
+def optics_bytes_per_column(nk, nbin, real_bytes=8, part="all"):
     """Optical averaging: reads 10 tracers per section + alt + dz8w per cell, writes tau/omega/g at 4 wavelengths
-    and 16 longwave optical depths per cell."""
-    return (10 * nbin + 2 + 12 + 16) * nk * real_bytes
+    (optics_kernel) and 16 longwave optical depths (optics_lw_kernel) per cell; each kernel reads the tracers."""
+    rd = 10 * nbin + 2
+    if part == "sw":
+        return (rd + 12) * nk * real_bytes
+    if part == "lw":
+        return (rd + 16) * nk * real_bytes
+    return (rd + 12 + 16) * nk * real_bytes
 
 
 def cpu_optics_seconds_per_column(wa, st, ms, ncol_sample):
@@ -249,16 +254,31 @@ def main():
     sw_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))   # HIP events on the launch stream
     lw_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if do_lw else 0.0
     opt_ms = float(np.mean([e[3].elapsed_time(e[0]) for e in events])) if do_opt else 0.0
+    opt_part_ms = {}
+    if do_opt:
+        # the stage is two kernels (shortwave wavelengths, longwave band pairs): time each one on its own, outside
+        # the timed region, by asking for one output group only
+        for part, outs in (("sw", {n: t for n, t in opt_out.items() if not n.startswith("tauaerlw")}),
+                           ("lw", {n: t for n, t in opt_out.items() if n.startswith("tauaerlw")})):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **outs)
+            e0.record()
+            for _ in range(3):
+                wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **outs)
+            e1.record()
+            torch.cuda.synchronize()
+            opt_part_ms[part] = e0.elapsed_time(e1) / 3
 
     if rank == 0:
         value = world * ncol * args.steps / elapsed
         bpc, bpc_sw, bpc_lw = algorithmic_bytes_per_column(args.nk, args.mode)
-        # dominant kernel by measured duration (the LW pair counts as lw_gas_kernel + lw_rt_kernel: the events
-        # bracket both, so the SW or the optics kernel is reported unless LW as a whole is longer)
+        # dominant kernel by measured duration: the SW column kernel or one of the two optics kernels (the two
+        # LW kernels are shorter than the SW kernel; the events bracket them together)
         obpc = optics_bytes_per_column(args.nk, args.nbin) if do_opt else 0
         cand = [("sw_column_kernel", sw_ms, bpc_sw)]
         if do_opt:
-            cand.append(("optics_kernel", opt_ms, obpc))
+            cand.append(("optics_kernel", opt_part_ms["sw"], optics_bytes_per_column(args.nk, args.nbin, part="sw")))
+            cand.append(("optics_lw_kernel", opt_part_ms["lw"], optics_bytes_per_column(args.nk, args.nbin, part="lw")))
         dom_name, dom_ms, dom_bpc = max(cand, key=lambda c: c[1])
         achieved = ncol * dom_bpc / (dom_ms * 1e-3) / 1e9
         traffic = None
@@ -298,7 +318,8 @@ def main():
                          "algorithmic_bytes_per_column": dom_bpc,
                          "sw_kernel_ms": sw_ms, "sw_algorithmic_bytes_per_column": bpc_sw,
                          "lw_kernel_ms": lw_ms, "lw_algorithmic_bytes_per_column": bpc_lw if do_lw else 0,
-                         "optics_kernel_ms": opt_ms, "optics_algorithmic_bytes_per_column": obpc,
+                         "optics_stage_ms": opt_ms, "optics_kernel_ms": opt_part_ms.get("sw", 0.0),
+                         "optics_lw_kernel_ms": opt_part_ms.get("lw", 0.0), "optics_algorithmic_bytes_per_column": obpc,
                          "step_algorithmic_GBs": ncol * (bpc + obpc) / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
                          "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
         }

@@ -29,6 +29,9 @@ namespace {
 constexpr int OPT_THREADS = 128;
 
 __constant__ OpticsTables c_opt;
+// weights of the asymmetry sum, functions of the (wave-uniform) term number only:
+// c_gw[0][n] = (2n+1)/(n(n+1)), c_gw[1][n] = (n-1)(n+1)/n
+__constant__ double c_gw[2][OPT_NMIE + 2];
 
 struct cplx { double re, im; };
 
@@ -82,6 +85,8 @@ struct MieAcc {
     cplx an1, bn1, xb;
 };
 
+// FULL = false: only the extinction and scattering sums (longwave bands use absorption alone)
+template <bool FULL>
 __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
 {
     const double en = (double)n;
@@ -90,24 +95,32 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
     const cplx xi = {psi, -chi}, xi1 = {A.psi1, -A.chi1};
     cplx t = cmul(D, minv);
     t.re += en * xinv;
-    const cplx an = cdiv(cplx{t.re * psi - A.psi1, t.im * psi}, csub(cmul(t, xi), xi1));
+    const cplx na = {t.re * psi - A.psi1, t.im * psi}, da = csub(cmul(t, xi), xi1);
     t = cmul(m, D);
     t.re += en * xinv;
-    const cplx bn = cdiv(cplx{t.re * psi - A.psi1, t.im * psi}, csub(cmul(t, xi), xi1));
+    const cplx nb = {t.re * psi - A.psi1, t.im * psi}, db = csub(cmul(t, xi), xi1);
+    // a_n = na/da, b_n = nb/db with one reciprocal: 1/|da|^2 = |db|^2 / (|da|^2 |db|^2)
+    const double ma = da.re * da.re + da.im * da.im, mb = db.re * db.re + db.im * db.im;
+    const double r = frcp(ma * mb);
+    const double ra = r * mb, rb = r * ma;
+    const cplx an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+    const cplx bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
     const double w2 = 2. * en + 1.;
     A.qs += w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
     A.qe += w2 * (an.re + bn.re);
-    A.gs += (w2 * frcp(en * (en + 1.))) * (an.re * bn.re + an.im * bn.im);
-    if (n > 1)
-        A.gs += ((en - 1.) * (en + 1.) * frcp(en)) *
-                (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
-    A.xb.re += A.sgn * w2 * (an.re - bn.re);
-    A.xb.im += A.sgn * w2 * (an.im - bn.im);
-    A.sgn = -A.sgn;
+    if (FULL) {
+        A.gs += c_gw[0][n] * (an.re * bn.re + an.im * bn.im);
+        if (n > 1)
+            A.gs += c_gw[1][n] * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+        A.xb.re += A.sgn * w2 * (an.re - bn.re);
+        A.xb.im += A.sgn * w2 * (an.im - bn.im);
+        A.sgn = -A.sgn;
+        A.an1 = an; A.bn1 = bn;
+    }
     A.psi0 = A.psi1; A.psi1 = psi; A.chi0 = A.chi1; A.chi1 = chi;
-    A.an1 = an; A.bn1 = bn;
 }
 
+template <bool FULL>
 __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS [OPT_NCK][OPT_THREADS], this thread's column */,
                            double &qext, double &qsca, double &gasy, double &qback)
 {
@@ -151,29 +164,149 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
 #pragma unroll
         for (int i = 0; i < OPT_MB; ++i) {
             const int n = j * OPT_MB + i + 1;
-            if (n <= nstop) mie_term(A, n, dd[i], m, minv, xinv);
+            if (n <= nstop) mie_term<FULL>(A, n, dd[i], m, minv, xinv);
         }
     }
     const double x2inv = xinv * xinv;
     qsca = 2. * x2inv * A.qs;
     qext = 2. * x2inv * A.qe;
-    gasy = A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
-    qback = x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im);
+    gasy = FULL && A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
+    qback = FULL ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
 }
 
-__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) optics_kernel(const OpticsKernelArgs a)
+// Two longwave evaluations of one particle (neighbouring bands) side by side.  The recurrences of D_n are serial
+// chains of ~10 dependent fp64 operations per step and the longwave series are short, so a single evaluation
+// leaves the SIMD waiting on its own results; two independent chains in one instruction stream fill those gaps.
+// Both start the downward recurrence at the larger of their two start orders (a higher start is only more
+// accurate), use register blocks of OPT_MB2 terms and the two halves of the thread's checkpoint column
+// (OPT_NCK/2 checkpoints each: nstop <= OPT_MB2*OPT_NCK/2 = 64, the caller checks).  Extinction and scattering only.
+constexpr int OPT_MB2 = 8, OPT_NCK2 = OPT_NCK / 2;
+
+struct MieSetup {
+    cplx yinv, minv;
+    double xinv;
+    int nstop, nmx;
+};
+__device__ __forceinline__ MieSetup mie_setup(double x, cplx m)
 {
-    // the OPT_NWAVE blocks of one cell group run back-to-back on one XCD (blockIdx & 7)
+    MieSetup s;
+    const cplx y = {x * m.re, x * m.im};
+    const double ymod = sqrt(y.re * y.re + y.im * y.im);
+    const double xstop = x + 4. * cbrt(x) + 2.;
+    s.nstop = (int)xstop;
+    const double base = fmax(xstop, ymod);
+    s.nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;   // as in mie_sphere
+    s.yinv = crecip(y);
+    s.minv = crecip(m);
+    s.xinv = frcp(x);
+    return s;
+}
+
+__device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2, const MieSetup &s1, const MieSetup &s2,
+                                         double2 *ck, double &qext1, double &qsca1, double &qext2, double &qsca2)
+{
+    const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
+    const int nck = (nstopm + OPT_MB2 - 1) / OPT_MB2, ntop = nck * OPT_MB2;
+    const int nmx = s1.nmx > s2.nmx ? s1.nmx : s2.nmx;
+    cplx d1 = {0., 0.}, d2 = {0., 0.};
+    for (int n = nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), both particles
+        const double en = (double)n;
+        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+        d1 = csub(ny1, crecip(cadd(d1, ny1)));
+        d2 = csub(ny2, crecip(cadd(d2, ny2)));
+        const int n1 = n - 1;
+        if (n1 <= ntop && (n1 & (OPT_MB2 - 1)) == 0) {
+            ck[(size_t)(n1 / OPT_MB2 - 1) * OPT_THREADS] = make_double2(d1.re, d1.im);
+            ck[(size_t)(OPT_NCK2 + n1 / OPT_MB2 - 1) * OPT_THREADS] = make_double2(d2.re, d2.im);
+        }
+        if (n1 <= OPT_MB2) break;
+    }
+    MieAcc A1, A2;
+    sincos(x1, &A1.psi1, &A1.psi0);
+    sincos(x2, &A2.psi1, &A2.psi0);
+    A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
+    A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
+    for (int j = 0; j < nck; ++j) {
+        cplx dd1[OPT_MB2], dd2[OPT_MB2];
+        const double2 c1 = ck[(size_t)j * OPT_THREADS], c2 = ck[(size_t)(OPT_NCK2 + j) * OPT_THREADS];
+        dd1[OPT_MB2 - 1] = {c1.x, c1.y};
+        dd2[OPT_MB2 - 1] = {c2.x, c2.y};
+#pragma unroll
+        for (int i = OPT_MB2 - 1; i >= 1; --i) {
+            const double en = (double)(j * OPT_MB2 + i + 1);
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            dd1[i - 1] = csub(ny1, crecip(cadd(dd1[i], ny1)));
+            dd2[i - 1] = csub(ny2, crecip(cadd(dd2[i], ny2)));
+        }
+#pragma unroll
+        for (int i = 0; i < OPT_MB2; ++i) {
+            const int n = j * OPT_MB2 + i + 1;
+            if (n <= s1.nstop) mie_term<false>(A1, n, dd1[i], m1, s1.minv, s1.xinv);
+            if (n <= s2.nstop) mie_term<false>(A2, n, dd2[i], m2, s2.minv, s2.xinv);
+        }
+    }
+    const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
+    qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
+    qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
+}
+
+// refractive index of the internal mixture at wavelength slot w (volume average, or Maxwell-Garnett with BC inclusions)
+__device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mix, int w)
+{
+    cplx m;
+    double sr = 0., si = 0.;
+#pragma unroll
+    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+        if (mix == 1 && sp == OS_BC) continue;
+        sr += vol[sp] * c_opt.refr[sp][w];
+        si += vol[sp] * c_opt.refi[sp][w];
+    }
+    if (mix == 0) {
+        const double vi = frcp(vwet);
+        m = {sr * vi, si * vi};
+    } else {
+        const double vbc = vol[OS_BC], vmat = vwet - vbc;
+        const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
+        if (!(vmat > 1.e-30 * vwet)) {
+            m = mbc;
+        } else {
+            const double vi = frcp(vmat);
+            const cplx mm = {sr * vi, si * vi};
+            if (!(vbc > 0.)) {
+                m = mm;
+            } else {   // Maxwell-Garnett: e = em (ei + 2em + 2f(ei-em)) / (ei + 2em - f(ei-em))
+                const double f = vbc * frcp(vwet);
+                const cplx em = cmul(mm, mm), ei = cmul(mbc, mbc);
+                const cplx de = csub(ei, em);
+                const cplx base = {ei.re + 2. * em.re, ei.im + 2. * em.im};
+                const cplx nume = {base.re + 2. * f * de.re, base.im + 2. * f * de.im};
+                const cplx deno = {base.re - f * de.re, base.im - f * de.im};
+                m = csqrt_pos(cmul(em, cdiv(nume, deno)));
+            }
+        }
+    }
+    return m;
+}
+
+// LW = false: one shortwave wavelength per workgroup (4 per cell group); LW = true: one pair of longwave bands
+// (8 per cell group).  Two kernels so that each path gets its own register allocation.
+template <bool LW>
+__device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *s_ck)
+{
+    // the workgroups of one cell group run back-to-back on one XCD (blockIdx & 7)
+    constexpr int NW = LW ? OPT_NLW / 2 : OPT_NSW;
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
-    const int gl = s / OPT_NWAVE, w = s - gl * OPT_NWAVE;
-    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
+    const int gl = s / NW, slot = s - gl * NW;
+    constexpr bool lw = LW;
+    const int w = lw ? OPT_NSW + 2 * slot : slot, w2 = w + 1;   // w2: second band of a longwave pair
     double2 *ck = s_ck + threadIdx.x;
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
     // nothing requested at this wavelength (output group absent): no work
-    if (w < OPT_NSW ? !(a.tauaer[w] || a.extaer[w] || a.bscoef[w]) : !(a.tauaerlw[w - OPT_NSW] || a.extaerlw[w - OPT_NSW]))
+    if (!lw ? !(a.tauaer[w] || a.extaer[w] || a.bscoef[w])
+            : !(a.tauaerlw[w - OPT_NSW] || a.extaerlw[w - OPT_NSW] || a.tauaerlw[w2 - OPT_NSW] || a.extaerlw[w2 - OPT_NSW]))
         return;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
@@ -182,10 +315,11 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
     const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
     const int r4 = a.real4;
     const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
-    const double lam = c_opt.wavelength_um[w];
+    const double lam = c_opt.wavelength_um[w], lam2 = c_opt.wavelength_um[lw ? w2 : w];
     const double pi = 3.14159265358979323846;
 
     double ext = 0., sca = 0., gsca = 0., bsc = 0.;   // 1/cm (bsc: 1/(cm sr))
+    double ext2 = 0., sca2 = 0.;                      // second band of a longwave pair
     for (int ib = 0; ib < a.nbin; ++ib) {
         double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
         double vdry = 0.;
@@ -210,53 +344,35 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
             num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
         }
         const double dwet = ddry * cbrt(vwet * frcp(vdry));
-        // refractive index of the internal mixture
-        cplx m;
-        {
-            double sr = 0., si = 0.;
-#pragma unroll
-            for (int sp = 0; sp < OPT_NSPEC; ++sp) {
-                if (a.mix == 1 && sp == OS_BC) continue;
-                sr += vol[sp] * c_opt.refr[sp][w];
-                si += vol[sp] * c_opt.refi[sp][w];
-            }
-            if (a.mix == 0) {
-                const double vi = frcp(vwet);
-                m = {sr * vi, si * vi};
-            } else {
-                const double vbc = vol[OS_BC], vmat = vwet - vbc;
-                const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
-                if (!(vmat > 1.e-30 * vwet)) {
-                    m = mbc;
-                } else {
-                    const double vi = frcp(vmat);
-                    const cplx mm = {sr * vi, si * vi};
-                    if (!(vbc > 0.)) {
-                        m = mm;
-                    } else {   // Maxwell-Garnett: e = em (ei + 2em + 2f(ei-em)) / (ei + 2em - f(ei-em))
-                        const double f = vbc * frcp(vwet);
-                        const cplx em = cmul(mm, mm), ei = cmul(mbc, mbc);
-                        const cplx de = csub(ei, em);
-                        const cplx base = {ei.re + 2. * em.re, ei.im + 2. * em.im};
-                        const cplx nume = {base.re + 2. * f * de.re, base.im + 2. * f * de.im};
-                        const cplx deno = {base.re - f * de.re, base.im - f * de.im};
-                        m = csqrt_pos(cmul(em, cdiv(nume, deno)));
-                    }
-                }
-            }
-        }
+        const cplx m = mix_index(vol, vwet, a.mix, w);
         double x = pi * dwet * frcp(lam);
         x = x > OPT_XMAX ? OPT_XMAX : x;
-        double qe, qs, g, qb;
-        mie_sphere(x, m, ck, qe, qs, g, qb);
+        double qe, qs, g = 0., qb = 0., qe2 = 0., qs2 = 0.;
+        if (!lw) {
+            mie_sphere<true>(x, m, ck, qe, qs, g, qb);
+        } else {
+            const cplx mb = mix_index(vol, vwet, a.mix, w2);
+            double xb = pi * dwet * frcp(lam2);
+            xb = xb > OPT_XMAX ? OPT_XMAX : xb;
+            const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
+            if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
+                mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
+            } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
+                double g0, b0;
+                mie_sphere<false>(x, m, ck, qe, qs, g0, b0);
+                mie_sphere<false>(xb, mb, ck, qe2, qs2, g0, b0);
+            }
+        }
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
         ext += cross * qe;
         sca += cross * qs;
         gsca += cross * qs * g;
         bsc += cross * qb * (0.25 / pi);
+        ext2 += cross * qe2;
+        sca2 += cross * qs2;
     }
-    if (w < OPT_NSW) {
+    if (!lw) {
         if (a.tauaer[w]) {
             str(a.tauaer[w], q, r4, ext * 100. * dz);
             str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
@@ -266,16 +382,38 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
         if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
     } else {
         const int ib = w - OPT_NSW;
-        const double ab = fmax(ext - sca, 0.);
+        const double ab = fmax(ext - sca, 0.), ab2 = fmax(ext2 - sca2, 0.);
         if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
         if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
+        if (a.tauaerlw[ib + 1]) str(a.tauaerlw[ib + 1], q, r4, ab2 * 100. * dz);
+        if (a.extaerlw[ib + 1]) str(a.extaerlw[ib + 1], q, r4, ab2 * 1.e5);
     }
+}
+
+__global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
+    optics_body<false>(a, s_ck);
+}
+
+__global__ void __launch_bounds__(OPT_THREADS) optics_lw_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
+    optics_body<true>(a, s_ck);
 }
 
 }  // namespace
 
 hipError_t optics_upload_tables(const OpticsTables &t)
 {
+    static double gw[2][OPT_NMIE + 2];
+    for (int n = 1; n < OPT_NMIE + 2; ++n) {
+        const double en = (double)n;
+        gw[0][n] = (2. * en + 1.) / (en * (en + 1.));
+        gw[1][n] = (en - 1.) * (en + 1.) / en;
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gw), gw, sizeof gw);
+    if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_opt), &t, sizeof(OpticsTables));
 }
 
@@ -285,9 +423,14 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream)
     if (ncell <= 0) return hipSuccess;
     const long groups = (ncell + OPT_THREADS - 1) / OPT_THREADS;
     const long groups8 = (groups + 7) / 8;
-    const long blocks = groups8 * 8 * OPT_NWAVE;
-    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
+    const long blocks = groups8 * 8 * OPT_NSW, blocks_lw = groups8 * 8 * (OPT_NLW / 2);
+    if (blocks_lw > 0x7fffffffL) return hipErrorInvalidValue;
+    // skip a kernel none of whose outputs were asked for
+    bool any_sw = false, any_lw = false;
+    for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
+    for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
+    if (any_sw) hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
+    if (any_lw) hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 
