@@ -134,6 +134,8 @@ struct LCol {   // LDS image of the column
     double *taua;      // [16][nl]
     double *secdiff, *plankbnd;   // [16]
     double *wrk;       // [2][nl] scratch for the column sums
+    double *pfr;       // [2][nl]+2 Planck-table fractions (layer, level above; surface level, boundary)
+    int *pix;          // [2][nl]+2 Planck-table indices, same order
     double *flux;      // [3 waves][4][nl+1]: down clean, down total, up clean, up total
     int *rb0, *rb1, *inds, *indf, *indm;
     int nl;
@@ -153,8 +155,10 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
     c.mul = p; p += LS_COUNT * nl;
     c.rat = p; p += LR_COUNT * 2 * nl;
     c.wrk = p; p += 2 * nl;
+    c.pfr = p; p += 2 * nl + 2;
     int *q = reinterpret_cast<int *>(p);
     c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
+    c.pix = q; q += 2 * nl + 2;
     double *r = rec;
     c.planklay = r; r += LW_NBND * nl;
     c.planklev = r; r += LW_NBND * (nl + 1);
@@ -560,13 +564,9 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         int indlev = (int)(tz_t - 159.);
         indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
         const double tlevfrac = tz_t - 159. - (double)indlev;
-        for (int ib = 0; ib < LW_NBND; ++ib) {
-            const double *P = tb.totplnk + ib * 181;
-            double dbdtlev = P[indlev] - P[indlev - 1];
-            double dbdtlay = P[indlay] - P[indlay - 1];
-            c.planklay[ib * nl + k] = P[indlay - 1] + tlayfrac * dbdtlay;
-            c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + tlevfrac * dbdtlev;
-        }
+        // the 16-band table lookups are done by all threads after the barrier (LW:3600-3644)
+        c.pix[k] = indlay; c.pfr[k] = tlayfrac;
+        c.pix[nl + k] = indlev; c.pfr[nl + k] = tlevfrac;
         if (k == 0) {
             const double tz0 = tlev_at(a, base3, sk, 0, nk, nl);
             int indbound = (int)(tbound - 159.);
@@ -575,13 +575,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             int indlev0 = (int)(tz0 - 159.);
             indlev0 = indlev0 < 1 ? 1 : (indlev0 > 180 ? 180 : indlev0);
             const double t0frac = tz0 - 159. - (double)indlev0;
-            for (int ib = 0; ib < LW_NBND; ++ib) {
-                const double *P = tb.totplnk + ib * 181;
-                double dbdtlev = P[indbound] - P[indbound - 1];
-                c.plankbnd[ib] = semiss * (P[indbound - 1] + tbndfrac * dbdtlev);
-                dbdtlev = P[indlev0] - P[indlev0 - 1];
-                c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + t0frac * dbdtlev;
-            }
+            c.pix[2 * nl] = indlev0; c.pfr[2 * nl] = t0frac;
+            c.pix[2 * nl + 1] = indbound; c.pfr[2 * nl + 1] = tbndfrac;
             c.pz[0] = plev_b;
         }
         c.pz[k + 1] = plev_t;
@@ -827,25 +822,42 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     if (tid == 0) s_laytrop = 0;
     __syncthreads();
     if (nlower) atomicAdd(&s_laytrop, nlower);
-    __syncthreads();
-    const int ltrop = s_laytrop;
-    if (tid == 0) {
-        // precipitable water -> diffusivity angle per band, LW:11307-11309 and LW:3142-3150
+    // Planck functions of the layers and of the levels above them in the 16 bands: (band, layer) items over all
+    // threads; the surface level and the boundary by the first 16 threads
+    for (int item = tid; item < LW_NBND * nl; item += LW_THREADS) {
+        const int ib = item / nl, k = item - ib * nl;
+        const double *P = tb.totplnk + ib * 181;
+        const int indlay = c.pix[k], indlev = c.pix[nl + k];
+        const double dbdtlev = P[indlev] - P[indlev - 1];
+        const double dbdtlay = P[indlay] - P[indlay - 1];
+        c.planklay[ib * nl + k] = P[indlay - 1] + c.pfr[k] * dbdtlay;
+        c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + c.pfr[nl + k] * dbdtlev;
+    }
+    if (tid < LW_NBND) {
+        const int ib = tid;
+        const double *P = tb.totplnk + ib * 181;
+        const int indlev0 = c.pix[2 * nl], indbound = c.pix[2 * nl + 1];
+        double dbdtlev = P[indbound] - P[indbound - 1];
+        c.plankbnd[ib] = semiss * (P[indbound - 1] + c.pfr[2 * nl + 1] * dbdtlev);
+        dbdtlev = P[indlev0] - P[indlev0 - 1];
+        c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + c.pfr[2 * nl] * dbdtlev;
+        // precipitable water -> diffusivity angle of this band, LW:11307-11309 and LW:3142-3150 (every one of the
+        // 16 threads forms the column sums in the reference's order)
         double amttl = 0.0, wvttl = 0.0;
         for (int k = 0; k < nl; ++k) { amttl = amttl + c.wrk[k]; wvttl = wvttl + c.wrk[nl + k]; }
         const double amd = 28.9660, amw = 18.0160, grav = 9.8066;
         const double wvsh = (amw * wvttl) / (amd * amttl);
         const double pwvcm = wvsh * (1.e3 * c.pz[0]) / (1.e2 * grav);
-        for (int ib = 0; ib < LW_NBND; ++ib) {
-            double sd = 1.66;
-            if (!(ib == 0 || ib == 3 || ib >= 9)) {
-                sd = c_a0[ib] + c_a1[ib] * exp(c_a2[ib] * pwvcm);
-                if (sd > 1.80) sd = 1.80;
-                if (sd < 1.50) sd = 1.50;
-            }
-            c.secdiff[ib] = sd;
+        double sd = 1.66;
+        if (!(ib == 0 || ib == 3 || ib >= 9)) {
+            sd = c_a0[ib] + c_a1[ib] * exp(c_a2[ib] * pwvcm);
+            if (sd > 1.80) sd = 1.80;
+            if (sd < 1.50) sd = 1.50;
         }
+        c.secdiff[ib] = sd;
     }
+    __syncthreads();
+    const int ltrop = s_laytrop;
     if (a.aer_ra_feedback == 1 && tid >= 64 && tid < 64 + LW_NBND) {
         // negative column aerosol optical depth is fatal, LW:12607-12615
         const int nb = tid - 64;
@@ -1110,8 +1122,8 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
 // ---------------------------------------------------------------------------
 size_t lw_gas_lds_bytes(int nl)
 {
-    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2) + (nl + 1);
-    size_t ni = (size_t)nl * 5;
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 2) + 2 + (nl + 1);
+    size_t ni = (size_t)nl * 7 + 2;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)
