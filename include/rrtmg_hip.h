@@ -136,6 +136,36 @@ int rrtmg_hip_tile_sums(const void *const *fields12, int real_bytes, int ims, in
 int rrtmg_hip_domain_stats(const void *field2d, const unsigned char *mask2d, int real_bytes, int ims, int ime, int jms,
                            int jme, int its, int ite, int jts, int jte, double *out13_dev, void *stream, char *err);
 
+/* ---------------------- driver-side neighbours ---------------------- */
+
+/* Tile of two-dimensional (i,j) arrays in WRF memory order; mem / stream as in rrtmg_hip_swrad_args. */
+typedef struct {
+    int ims, ime, jms, jme, its, ite, jts, jte;
+    int real_bytes;          /* 4 or 8: REAL size of every array of the call */
+    int mem;                 /* 0 host pointers (staged, synchronous), 1 device pointers (enqueued on stream) */
+    void *stream;
+} rrtmg_hip_tile2d;
+
+/* Energy buckets, module_radiation_driver.F:2308-2381: acc[f] += flux[f] * dtaccum for up to 16 field pairs
+ * (the driver's order: LW upt,uptc,dnt,dntc,upb,upbc,dnb,dnbc then the same for SW; NULL pairs are skipped). */
+int rrtmg_hip_accumulate_fluxes(const rrtmg_hip_tile2d *dims, double dtaccum, const void *const *flux16,
+                                void *const *acc16, char *err);
+
+/* swint_opt = 1, after a radiation step: update_swinterp_parameters, module_radiation_driver.F:2668-2749. */
+typedef struct {
+    const void *coszen, *coszen_loc, *swddir, *swdown;
+    void *swddir_ref, *bb, *Bx, *swdown_ref, *gg, *Gx, *coszen_ref;
+} rrtmg_hip_swinterp_update_args;
+int rrtmg_hip_update_swinterp_parameters(const rrtmg_hip_tile2d *dims, const rrtmg_hip_swinterp_update_args *args,
+                                         char *err);
+
+/* swint_opt = 1, every model step: interp_sw_radiation, module_radiation_driver.F:2751-2795. */
+typedef struct {
+    const void *coszen_ref, *coszen_loc, *swddir_ref, *bb, *Bx, *swdown_ref, *gg, *Gx, *albedo;
+    void *swdown, *swddir, *swddni, *swddif, *gsw;
+} rrtmg_hip_swinterp_apply_args;
+int rrtmg_hip_interp_sw_radiation(const rrtmg_hip_tile2d *dims, const rrtmg_hip_swinterp_apply_args *args, char *err);
+
 /* ------------------------------- longwave -------------------------------- */
 
 /* Read RRTMG_LW_DATA (record field order of lw_kgb01..16, LW:13021-14387),

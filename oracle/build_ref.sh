@@ -31,4 +31,15 @@ $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_sw.F90" sw_inner.o lw_inner
 if [ -f "$HERE/ref_harness_lw.F90" ]; then
   $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_lw.F90" lw_inner.o -o ref_lw -module-dir "$OUT"
 fi
+# swint_opt routines of the radiation driver: two self-contained subroutines (DRV:2668-2795), wrapped into a module
+# on the fly (the driver module itself USEs most of WRF)
+DRV="$REF/module_radiation_driver.F"
+DRV_BEG=2668; DRV_END=2795
+sed -n "${DRV_BEG}p" "$DRV" | grep -qi 'subroutine update_swinterp_parameters' || { echo "driver line range moved" >&2; exit 1; }
+sed -n "${DRV_END}p" "$DRV" | grep -qi 'end subroutine interp_sw_radiation' || { echo "driver line range moved" >&2; exit 1; }
+if [ -f "$HERE/ref_harness_swinterp.F90" ]; then
+  { echo "module swinterp_ref"; echo "contains"; sed -n "${DRV_BEG},${DRV_END}p" "$DRV"; echo "end module swinterp_ref"; } \
+    | $FC $FFLAGS -c -x f95-cpp-input - -o swinterp_inner.o -module-dir "$OUT"
+  $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_swinterp.F90" swinterp_inner.o -o ref_swinterp -module-dir "$OUT"
+fi
 echo "build_ref: built $(ls $OUT/ref_* | tr '\n' ' ')"
