@@ -97,6 +97,11 @@ typedef struct rrtmg_hip_swrad_args {
      * (ims:ime, kms:kme, jms:jme, 1:14), SW:10982-10991): NULL = not associated.  Where the WRF-Chem arrays
      * qualify (aer_ra_feedback = 1, tauaer300 and tauaer999 > 1e-9) they override these, as in the reference. */
     const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;
+    /* aer_opt = 1 (SW:9201-9205, 11083-11100): optical depth at 0.55 um of the six ECMWF aerosol types,
+     * aerod(ims:ime, kms:kme, jms:jme, 1:6); rrtmg_sw then runs with iaer = 6 and every other aerosol input is
+     * ignored (SW:9313-9340).  NULL = aer_opt /= 1.  The clean call uses zero aerosol optical depth (the
+     * reference leaves ztauacln unset on this route). */
+    const void *aerod;
 } rrtmg_hip_swrad_args;
 
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);

@@ -136,7 +136,7 @@ class SwTileIn(C.Structure):
                 + [(n, dp) for n in CLOUD3 + CLOUD2]
                 + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
                 + [("g", C.c_double), ("seed_real4", C.c_int)]
-                + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw")])
+                + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw", "aerod")])
 
 
 SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",
@@ -148,6 +148,17 @@ SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",
 
 class SwTileOut(C.Structure):
     _fields_ = [(n, dp) for n in SW_TILE_OUT]
+
+
+def ecaer_bands(ecaer):
+    """iaer = 6 (SW:9313-9340): ecaer (6, nlay) -> tauaer, ssaaer, asmaer (14, nlay)."""
+    e = np.ascontiguousarray(ecaer, dtype=np.float64)
+    nlay = e.shape[1]
+    out = [np.zeros((14, nlay)) for _ in range(3)]
+    l = lib()
+    l.sw_oracle_ecaer_bands.argtypes = [C.c_int, dp, dp, dp, dp]
+    l.sw_oracle_ecaer_bands(nlay, _p(e), *[_p(o) for o in out])
+    return out
 
 
 def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedback, clean_atm_diag, outputs: dict,

@@ -33,7 +33,7 @@ program ref_sw
   use mcica_subcol_gen_sw, only : mcica_subcol_sw
   implicit none
   character(len=512) :: ftab, fcol, fout, fdump, fmode
-  logical :: clouds
+  logical :: clouds, ecmwf
   integer(kind=im) :: irng, permuteseed, iflags(3)
   real(kind=rb), allocatable :: cldfrac(:,:), clwp(:,:), ciwp(:,:), cswp(:,:), rel(:,:), rei(:,:), res(:,:)
   real(kind=rb), allocatable :: taucld(:,:,:), ssacld(:,:,:), asmcld(:,:,:), fsfcld(:,:,:)
@@ -64,10 +64,11 @@ program ref_sw
   fdump = ''
   if (nargs >= 4) call get_command_argument(4, fdump)
   if (trim(fdump) == '-') fdump = ''
-  clouds = .false.
+  clouds = .false.; ecmwf = .false.
   if (nargs >= 5) then
      call get_command_argument(5, fmode)
      clouds = trim(fmode) == 'clouds'
+     ecmwf = trim(fmode) == 'ecaer'      ! aer_opt = 1: six ECMWF aerosol types, iaer = 6
   end if
 
   call read_tables(trim(ftab))
@@ -111,6 +112,11 @@ program ref_sw
      read(21) buf; tauaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
      read(21) buf; ssaaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
      read(21) buf; asmaer(1,:,:) = reshape(buf, (/nlay, nbndsw/))
+     if (ecmwf) then
+        deallocate(buf); allocate(buf(nlay*naerec))
+        read(21) buf; ecaer(1,:,:) = reshape(buf, (/nlay, naerec/))
+        deallocate(buf); allocate(buf(nlay*nbndsw))
+     end if
      if (clouds) then
         read(21) cldfrac(1,:), clwp(1,:), ciwp(1,:), cswp(1,:), rel(1,:), rei(1,:), res(1,:)
         read(21) iflags
@@ -130,7 +136,7 @@ program ref_sw
              inflgsw, iceflgsw, liqflgsw, cldfmcl, taucmcl, ssacmcl, asmcmcl, fsfcmcl, &
              ciwpmcl, clwpmcl, cswpmcl, reicmcl, relqmcl, resnmcl, &
              tauaer, ssaaer, asmaer, ecaer, &
-             swuflx, swdflx, swhr, swuflxc, swdflxc, swhrc, swuflxcln, swdflxcln, 0, &
+             swuflx, swdflx, swhr, swuflxc, swdflxc, swhrc, swuflxcln, swdflxcln, merge(1, 0, ecmwf), &
              sibvisdir, sibvisdif, sibnirdir, sibnirdif, swdkdir, swdkdif, iclean)
      end do
      write(22) swuflx(1,:), swdflx(1,:), swhr(1,:), swuflxc(1,:), swdflxc(1,:), swhrc(1,:)

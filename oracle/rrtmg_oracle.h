@@ -130,7 +130,12 @@ typedef struct {
     double g;
     int seed_real4;
     const double *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   /* (i,k,j,band), optional (SW:10982-10991) */
+    const double *aerod;                                     /* (i,k,j,6), optional: aer_opt = 1 (SW:11083-11100) */
 } SwTileIn;
+
+/* iaer = 6: band optical properties of the mixture of the six ECMWF aerosol types, SW:9313-9340.
+ * ecaer[type][layer] (optical depth at 0.55 um) -> tau, ssa, asy [band][layer]. */
+void sw_oracle_ecaer_bands(int nlay, const double *ecaer, double *tau, double *ssa, double *asy);
 
 typedef struct {
     double *rthratensw;                                      /* 3-D, INOUT */

@@ -1371,6 +1371,15 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
                     }
                     if (rc) break;
                 }
+                if (in->aerod) {   /* aer_opt = 1: rrtmg_sw runs with iaer = 6 and ignores tauaer/ssaaer/asmaer */
+                    double ecaer[6 * MAXLAY];
+                    const size_t n3 = (size_t)ni * nkm * (in->jme - in->jms + 1);
+                    for (int na = 0; na < 6; ++na) {
+                        for (int k = 0; k < nk; ++k) ecaer[na * nlay + k] = in->aerod[(size_t)na * n3 + I3(i, in->kts + k, j)];
+                        ecaer[na * nlay + nk] = 0.;   /* SW:11096 */
+                    }
+                    sw_oracle_ecaer_bands(nlay, ecaer, tauaer, ssaaer, asmaer);
+                }
                 SwColumnIn ci = {nlay, play, plev, tlay, tlev, in->tsk[I2(i, j)], h2ovmr, o3vmr, co2vmr, ch4vmr,
                                  n2ovmr, o2vmr, alb, alb, alb, alb, coszrs, 1.0, in->solcon, 0,
                                  tauaer, ssaaer, asmaer, in->clean_atm_diag};
@@ -1451,4 +1460,26 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
 #undef I3
 #undef I3F
 #undef I2
+}
+
+/* iaer = 6 (aer_opt = 1): mixture of the six ECMWF aerosol types, SW:9313-9340, with the tables of swaerpr
+ * (SW:4932-5017, sw_aer_tables.h).  Downstream the result takes the place of the iaer = 10 inputs
+ * (ztaua, zomga, zasya).  The reference leaves the clean-sky optical depth (ztauacln) unset on this route;
+ * the restatement and the engine use zero. */
+#include "sw_aer_tables.h"
+void sw_oracle_ecaer_bands(int nlay, const double *ecaer, double *tau, double *ssa, double *asy)
+{
+    for (int i = 0; i < nlay; ++i)
+        for (int ib = 0; ib < 14; ++ib) {
+            double t = 0., o = 0., g = 0.;
+            for (int ia = 0; ia < 6; ++ia) {
+                const double e = ecaer[ia * nlay + i];
+                t = t + SWAER_RSRTAUA[ib][ia] * e;
+                o = o + SWAER_RSRTAUA[ib][ia] * e * SWAER_RSRPIZA[ib][ia];
+                g = g + SWAER_RSRTAUA[ib][ia] * e * SWAER_RSRPIZA[ib][ia] * SWAER_RSRASYA[ib][ia];
+            }
+            if (o != 0.) g = g / o;
+            if (t != 0.) o = o / t;
+            tau[ib * nlay + i] = t; ssa[ib * nlay + i] = o; asy[ib * nlay + i] = g;
+        }
 }

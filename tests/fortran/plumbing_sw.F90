@@ -4,7 +4,8 @@
 PROGRAM plumbing_sw
    USE module_ra_rrtmg_sw, ONLY : rrtmg_swrad, rrtmg_swinit
    IMPLICIT NONE
-   INTEGER :: ni, nj, nk, clean, icloud
+   INTEGER :: ni, nj, nk, clean, icloud, aeropt
+   REAL, ALLOCATABLE, DIMENSION(:,:,:,:) :: aerod
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
    INTEGER :: ids,ide,jds,jde,kds,kde, ims,ime,jms,jme,kms,kme, its,ite,jts,jte,kts,kte
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: t3d,t8w,p3d,p8w,pi3d,rho3d,dz8w,qv3d,rthratensw, re_c,re_i,re_s
@@ -19,7 +20,9 @@ PROGRAM plumbing_sw
    CALL get_command_argument(2, fout)
    OPEN(11, file=TRIM(fin), access='stream', form='unformatted', status='old')
    READ(11) ni, nj, nk, clean
-   icloud = clean / 10            ! header word: clean_atm_diag + 10*icloud
+   aeropt = clean / 100           ! header word: clean_atm_diag + 10*icloud + 100*aer_opt
+   clean = MOD(clean, 100)
+   icloud = clean / 10
    clean = MOD(clean, 10)
    ids=1; ide=ni+1; jds=1; jde=nj+1; kds=1; kde=nk+1
    ims=1; ime=ni; jms=1; jme=nj; kms=1; kme=nk+1
@@ -47,6 +50,9 @@ PROGRAM plumbing_sw
    ALLOCATE(qi3d(ims:ime,kms:kme,jms:jme), qs3d(ims:ime,kms:kme,jms:jme))
    cldfra3d = 0.; qc3d = 0.; qr3d = 0.; qi3d = 0.; qs3d = 0.
    IF (icloud /= 0) READ(11) cldfra3d, qc3d, qr3d, qi3d, qs3d
+   ALLOCATE(aerod(ims:ime,kms:kme,jms:jme,6))
+   aerod = 0.
+   IF (aeropt == 1) READ(11) aerod
    CLOSE(11)
    rho3d = 1.; dz8w = 100.; xlat = 0.; xlong = 0.; xland = 1.; xice = 0.; snow = 0.
    re_c = 0.; re_i = 0.; re_s = 0.
@@ -74,7 +80,7 @@ PROGRAM plumbing_sw
         CLDFRA3D=cldfra3d, QC3D=qc3d, QR3D=qr3d, QI3D=qi3d, QS3D=qs3d, &
         F_QV=.TRUE., F_QC=.TRUE., F_QR=.TRUE., F_QI=.TRUE., F_QS=.TRUE., F_QG=.FALSE., &
         XLAND=xland, XICE=xice, SNOW=snow,                            &
-        QV3D=qv3d, NO_SRC=1, sf_surface_physics=2,                    &
+        QV3D=qv3d, AER_OPT=aeropt, AEROD=aerod, NO_SRC=6, sf_surface_physics=2, &
         TAUAER300=tauaer300, TAUAER400=tauaer400,                     &
         TAUAER600=tauaer600, TAUAER999=tauaer999,                     &
         GAER300=gaer300, GAER400=gaer400, GAER600=gaer600, GAER999=gaer999, &

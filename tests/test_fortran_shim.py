@@ -87,3 +87,28 @@ def test_shim_plumbing_4x4x40(hip_lib, sw_oracle, wa, tmp_path, fflags, dt, rtol
     compare_sw(got, ref, rtol, 1e-9 if dt == "<f8" else 2e-6, names=names)
     night = st.a2["xcoszen"] <= 0
     assert (got["gsw"][night] == SENTINEL).all()
+
+
+@pytest.mark.gpu
+def test_shim_aer_opt_1(hip_lib, sw_oracle, wa, tmp_path):
+    """aer_opt = 1 through the Fortran interface: aerod(ims:ime,kms:kme,jms:jme,1:6) replaces the other aerosol
+    inputs (iaer = 6)."""
+    from helpers import AER, IN2, IN3, alloc_outputs, dims_of
+    from oracle import oracle as orc
+    from test_sw_aerod_gpu import _aerod
+    exe = build_driver(hip_lib, "-O1 -fdefault-real-8")
+    st = wa.synth.make_wrf_state(4, 4, 40, seed=20260000, night_fraction=0.2)
+    wa.synth.write_sw_data(str(tmp_path / "RRTMG_SW_DATA_DBL"), seed=20260001, real_bytes=8)
+    aerod = _aerod(st, 20260731)
+    write_state(tmp_path / "in.bin", st, 101, "<f8")
+    with open(tmp_path / "in.bin", "ab") as f:
+        f.write(np.ascontiguousarray(aerod, dtype="<f8").tobytes())
+    r = subprocess.run([exe, "in.bin", "out.bin"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = read_out(tmp_path / "out.bin", st, "<f8")
+    arrays = {n: st.a2[n] for n in IN2}
+    arrays.update({n: st.a3[n] for n in IN3 + AER})   # passed with aer_ra_feedback = 1, ignored on this route
+    arrays["aerod"] = aerod
+    ref = alloc_outputs(st)
+    orc.swrad_tile(sw_oracle, dims_of(st), arrays, 1370.0, 1, 1, ref)
+    compare_sw(got, ref, 1e-9, 1e-9, names=[n for n in got if n in ref])

@@ -17,6 +17,28 @@ def test_sw_column_solver_matches_reference_bitwise(sw_oracle, oracle_mod, name)
         np.testing.assert_array_equal(out[n], g["ref_" + n], err_msg=n)
 
 
+def test_sw_ecmwf_aerosol_types_match_reference_bitwise(sw_oracle, oracle_mod):
+    """aer_opt = 1 / iaer = 6 (SW:9313-9340): the reference mixes the six aerosol types itself; the restatement
+    forms the band properties (sw_oracle_ecaer_bands) and hands them to the same solver."""
+    g = np.load(os.path.join(GOLD, "sw_cols_k40_ecaer.npz"))
+    cols = {k[3:]: g[k] for k in g.files if k.startswith("in_")}
+    ecaer = cols.pop("ecaer")
+    bands = [oracle_mod.ecaer_bands(e) for e in ecaer]
+    for i, n in enumerate(("tauaer", "ssaaer", "asmaer")):
+        cols[n] = np.stack([b[i] for b in bands])
+    out = sw_oracle.rrtmg_sw(cols, clean=0)
+    for n in oracle_mod.SW_COL_OUT:
+        if not n.endswith("cln"):   # the clean call is off in this fixture (see tools/make_golden_ecaer.py)
+            np.testing.assert_array_equal(out[n], g["ref_" + n], err_msg=n)
+    has = ecaer.sum(axis=(1, 2)) > 0
+    assert has.any() and (~has).any()
+    # the input matters: columns with aerosol differ from the aerosol-free solution of the same state
+    cols0 = dict(cols, tauaer=np.zeros_like(cols["tauaer"]))
+    out0 = sw_oracle.rrtmg_sw(cols0, clean=0)
+    assert np.abs(out0["swuflx"][has, -1] - out["swuflx"][has, -1]).min() > 1e-4
+    np.testing.assert_array_equal(out0["swuflx"][~has], out["swuflx"][~has])
+
+
 def test_sw_reference_fixture_physics(sw_oracle):
     """sanity of the fixture itself: invariants the reference relies on."""
     g = np.load(os.path.join(GOLD, "sw_cols_k40.npz"))

@@ -271,6 +271,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         k.swupflx = a->swupflx; k.swupflxc = a->swupflxc; k.swupflxcln = a->swupflxcln;
         k.swdnflx = a->swdnflx; k.swdnflxc = a->swdnflxc; k.swdnflxcln = a->swdnflxcln;
         k.tauaer3d_sw = a->tauaer3d_sw; k.ssaaer3d_sw = a->ssaaer3d_sw; k.asyaer3d_sw = a->asyaer3d_sw;
+        k.aerod = a->aerod;
         if (a->icloud != 0) {
             k.cldfra3d = a->cldfra3d; k.qc3d = a->qc3d; k.qr3d = a->qr3d; k.qi3d = a->qi3d; k.qs3d = a->qs3d;
             k.re_cloud = a->has_reqc ? a->re_cloud : nullptr; k.re_ice = a->has_reqi ? a->re_ice : nullptr;
@@ -297,6 +298,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             HIPCHK(stg.in(a->tauaer3d_sw, n4, stream, &k.tauaer3d_sw));
             HIPCHK(stg.in(a->ssaaer3d_sw, n4, stream, &k.ssaaer3d_sw));
             HIPCHK(stg.in(a->asyaer3d_sw, n4, stream, &k.asyaer3d_sw));
+            HIPCHK(stg.in(a->aerod, n3 * 6, stream, &k.aerod));
         }
         if (a->icloud != 0) {
             IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);

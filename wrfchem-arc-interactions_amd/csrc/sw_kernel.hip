@@ -34,6 +34,7 @@
 #include "rrtmg_common.h"
 #include "sw_kernel.h"
 #include "cld_retab.h"
+#include "sw_aer_tables.h"
 #include "mcica_device.h"
 
 namespace rrtmg {
@@ -386,6 +387,8 @@ __device__ __forceinline__ void gas_finish(const SwDeviceTables &tb, const ColVi
 
 // ice effective radius versus temperature (retab, LW:11424-11442), uploaded by sw_upload_retab()
 __constant__ double c_retab[95];
+// rsrtaua, rsrpiza, rsrasya of the ECMWF aerosol types (swaerpr, SW:4932-5017), [quantity][band][type]
+__constant__ double c_swaer[3][SW_NBND][6];
 
 // Cloud optical properties of one cloudy sub-column layer: cldprmc_sw, SW:2062-2388, for inflag >= 2, liqflag = 1,
 // iceflag = 3, 4 or 5 (what RRTMG_SWRAD can select, SW:10514-10604).  Table indices and interpolation fractions
@@ -853,6 +856,26 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
         }
     }
     __syncthreads();
+    if (a.aerod) {
+        // aer_opt = 1: the six ECMWF aerosol types replace every other aerosol input (iaer = 6, SW:9313-9340);
+        // no aerosol in the extra layer (SW:11096)
+        for (int item = tid; item < SW_NBND * nlp; item += NTHREADS) {
+            const int nb = item / nlp, k = item - nb * nlp;
+            double tau = 0., ssa = 0., asy = 0.;
+            if (k < nk) {
+                for (int ia = 0; ia < 6; ++ia) {
+                    const double ec = ldr(a.aerod, (size_t)ia * a.ni_m * a.nk_m * a.nj_m + base3 + (size_t)k * sk, r4);
+                    tau = tau + c_swaer[0][nb][ia] * ec;
+                    ssa = ssa + c_swaer[0][nb][ia] * ec * c_swaer[1][nb][ia];
+                    asy = asy + c_swaer[0][nb][ia] * ec * c_swaer[1][nb][ia] * c_swaer[2][nb][ia];
+                }
+                if (ssa != 0.) asy = asy / ssa;
+                if (tau != 0.) ssa = ssa / tau;
+            }
+            c.taer[item] = tau; c.waer[item] = ssa; c.gaer[item] = asy;
+        }
+        __syncthreads();
+    }
 
     // ======================= main phase: lanes = g-points =======================
     const int chunk = wave & 1, pass = wave >> 1;
@@ -1163,6 +1186,12 @@ hipError_t sw_upload_constants(hipStream_t)
 
 hipError_t sw_upload_retab()
 {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_swaer), SWAER_RSRTAUA, sizeof(double) * SW_NBND * 6, 0);
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_swaer), SWAER_RSRPIZA, sizeof(double) * SW_NBND * 6, sizeof(double) * SW_NBND * 6);
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_swaer), SWAER_RSRASYA, sizeof(double) * SW_NBND * 6, 2 * sizeof(double) * SW_NBND * 6);
+    if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_retab), CLD_RETAB, sizeof(double) * 95);
 }
 

@@ -56,6 +56,7 @@ MODULE module_ra_rrtmg_sw
       INTEGER(c_int) :: is_cammgmp_used, f_ice_phy, mp_physics
       REAL(c_double) :: g
       TYPE(c_ptr) :: tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw
+      TYPE(c_ptr) :: aerod
    END TYPE swrad_args
 
    INTERFACE
@@ -164,7 +165,7 @@ CONTAINS
       REAL, DIMENSION(ims:ime,kms:kme,jms:jme), OPTIONAL, INTENT(IN), TARGET :: o33d
       INTEGER, OPTIONAL, INTENT(IN) :: o3input
       INTEGER, INTENT(IN) :: no_src
-      REAL, DIMENSION(ims:ime,kms:kme,jms:jme,1:no_src), OPTIONAL, INTENT(IN) :: aerod
+      REAL, DIMENSION(ims:ime,kms:kme,jms:jme,1:no_src), OPTIONAL, INTENT(IN), TARGET :: aerod
       INTEGER, OPTIONAL, INTENT(IN) :: aer_opt
       REAL, DIMENSION(ims:ime,jms:jme), OPTIONAL, INTENT(INOUT), TARGET :: &
            swupt, swuptc, swuptcln, swdnt, swdntc, swdntcln, swupb, swupbc, swupbcln, swdnb, swdnbc, swdnbcln
@@ -201,8 +202,14 @@ CONTAINS
             'rrtmg_swrad (HIP): tauaer3d_sw must be a contiguous (ims:ime,kms:kme,jms:jme,14) array')
          a%tauaer3d_sw = c_loc(tauaer3d_sw); a%ssaaer3d_sw = c_loc(ssaaer3d_sw); a%asyaer3d_sw = c_loc(asyaer3d_sw)
       END IF
+      ! aer_opt = 1: optical depth of the six ECMWF aerosol types (SW:11083-11100), rrtmg_sw then runs with iaer = 6
+      a%aerod = c_null_ptr
       IF (PRESENT(aer_opt)) THEN
-         IF (aer_opt == 1) CALL wrf_error_fatal('rrtmg_swrad (HIP): aer_opt=1 (Tegen climatology) is not supported')
+         IF (aer_opt == 1) THEN
+            IF (.NOT. PRESENT(aerod)) CALL wrf_error_fatal('rrtmg_swrad (HIP): aer_opt=1 needs aerod')
+            IF (no_src < 6) CALL wrf_error_fatal('rrtmg_swrad (HIP): aer_opt=1 needs six aerosol types in aerod')
+            a%aerod = c_loc(aerod)
+         END IF
       END IF
       IF (sf_surface_physics == 8) CALL wrf_error_fatal('rrtmg_swrad (HIP): SSiB spectral albedo is not supported')
       IF (.NOT. PRESENT(qv3d)) CALL wrf_error_fatal('rrtmg_swrad (HIP): qv3d is required')
