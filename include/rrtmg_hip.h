@@ -136,8 +136,8 @@ int rrtmg_hip_tile_sums(const void *const *fields12, int real_bytes, int ims, in
 /* Domain statistics of one 2-D device field over the tile (optionally masked, mask2d nonzero = use; memory shape):
  * what calc_standard_stats of the reference's post-processing forms on the host
  * (analysis_scripts/NCL_extraction_package/misc_stats_library.ncl:405-458).  out13 (device):
- * avg, stddev (N-1), min, max, median, 25th, 75th, 5th, 95th percentile, standard error, -9999 (Moran's I, not
- * computed), -9999 (corrected SE), N.  Percentile p = sorted[round(p/100 (N-1))].  Synchronises `stream`. */
+ * avg, stddev (N-1), min, max, median, 25th, 75th, 5th, 95th percentile, standard error, Moran's I (neighbour /
+ * Manhattan weights, :196-370), corrected SE = SE * I, N.  Percentile p = sorted[round(p/100 (N-1))].  Synchronises `stream`. */
 int rrtmg_hip_domain_stats(const void *field2d, const unsigned char *mask2d, int real_bytes, int ims, int ime, int jms,
                            int jme, int its, int ite, int jts, int jte, double *out13_dev, void *stream, char *err);
 

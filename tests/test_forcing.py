@@ -17,6 +17,24 @@ def test_domain_stats_host_definitions(wa):
     assert f.domain_stats_host([])["N"] == 0.0
 
 
+def test_morans_i_host_known_answers(wa):
+    """Moran's I as calc_morans_i_2D forms it (neighbour + manhattan weights): a checkerboard is perfectly
+    anti-correlated with its four neighbours, smooth fields are positively correlated, white noise is near zero;
+    the weight sum counts every ordered pair of 4-neighbours."""
+    f = wa.forcing
+    jj, ii = np.mgrid[0:12, 0:16]
+    n = 12 * 16
+    board = ((ii + jj) % 2).astype(float)
+    # I = sum_pairs d_a d_b / (W sd^2) with sd the sample (N-1) deviation: -(N-1)/N for the checkerboard
+    assert f.morans_i_host(board) == pytest.approx(-(n - 1) / n, rel=1e-12)
+    assert f.morans_i_host(ii + 0.5 * jj) > 0.9
+    rng = np.random.default_rng(2)
+    assert abs(f.morans_i_host(rng.normal(size=(60, 70)))) < 0.05
+    assert f.morans_i_host(np.ones((5, 5))) == 0.0
+    s = f.domain_stats_host(board, field2d=board)
+    assert s["morans_i"] == pytest.approx(-(n - 1) / n) and s["SE_corr"] == pytest.approx(s["SE"] * s["morans_i"])
+
+
 def test_decomposition_arithmetic(wa):
     f = wa.forcing
     rng = np.random.default_rng(5)
@@ -47,14 +65,20 @@ def test_domain_stats_device_matches_host(hip_lib, wa):
     dims = dict(ims=1, ime=ni, jms=1, jme=nj, its=4, ite=50, jts=3, jte=30)
     t = torch.from_numpy(a).cuda()
     got = f.domain_stats(t, dims)
-    ref = f.domain_stats_host(a[2:30, 3:50])
+    ref = f.domain_stats_host(a[2:30, 3:50], field2d=a[2:30, 3:50])
     for n in f.STAT_NAMES:
-        assert got[n] == pytest.approx(ref[n], rel=1e-12), n
+        # Moran's I is a sum of cancelling products added in a different order: looser
+        assert got[n] == pytest.approx(ref[n], rel=1e-9 if n in ("morans_i", "SE_corr") else 1e-12, abs=1e-13), n
     mask = (rng.uniform(size=(nj, ni)) < 0.4).astype(np.uint8)
     got = f.domain_stats(t, dims, mask=torch.from_numpy(mask).cuda())
-    ref = f.domain_stats_host(a[2:30, 3:50][mask[2:30, 3:50] != 0])
+    ref = f.domain_stats_host(a[2:30, 3:50][mask[2:30, 3:50] != 0], field2d=a[2:30, 3:50], mask=mask[2:30, 3:50])
     for n in f.STAT_NAMES:
-        assert got[n] == pytest.approx(ref[n], rel=1e-12), n
+        # Moran's I is a sum of cancelling products added in a different order: looser
+        assert got[n] == pytest.approx(ref[n], rel=1e-9 if n in ("morans_i", "SE_corr") else 1e-12, abs=1e-13), n
+    # a smooth field: strongly autocorrelated
+    sm = np.add.outer(np.sin(np.arange(nj) / 6.0), np.cos(np.arange(ni) / 9.0))
+    got = f.domain_stats(torch.from_numpy(sm).cuda(), dims)
+    assert got["morans_i"] == pytest.approx(f.morans_i_host(sm[2:30, 3:50]), rel=1e-11) and got["morans_i"] > 0.9
     t32 = torch.from_numpy(a.astype(np.float32)).cuda()
     got = f.domain_stats(t32, dims)
     ref = f.domain_stats_host(a.astype(np.float32).astype(np.float64)[2:30, 3:50])

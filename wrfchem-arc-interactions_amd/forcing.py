@@ -42,8 +42,38 @@ def domain_stats(field, dims, mask=None, stream=None) -> dict:
     return dict(zip(STAT_NAMES, out.cpu().tolist()))
 
 
-def domain_stats_host(values) -> dict:
-    """The same statistics with numpy (for tests and for host-resident data)."""
+def morans_i_host(field2d, mask=None) -> float:
+    """Moran's I the way calc_morans_i_2D forms it with the options of calc_standard_stats (neighbour, manhattan;
+    misc_stats_library.ncl:196-370): flattened field, the eight displacements, weight 1 at Manhattan distance 1;
+    masked cells are missing (their products drop out, their weights stay)."""
+    x = np.asarray(field2d, dtype=np.float64)
+    nj, ni = x.shape
+    ok = np.ones(x.shape, bool) if mask is None else np.asarray(mask) != 0
+    if not ok.any():
+        return 0.0
+    vals = x[ok]
+    sd = float(np.std(vals, ddof=1)) if vals.size > 1 else 0.0
+    if sd == 0.0:
+        return 0.0
+    d = np.where(ok, x - vals.mean(), 0.0).ravel()
+    okf = ok.ravel()
+    N = ni * nj
+    n = np.arange(N)
+    ii, jj = n % ni, n // ni
+    au = w = 0.0
+    for m in (1, ni - 1, ni, ni + 1, N - ni - 1, N - ni, N - ni + 1, N - 1):
+        if m == 0:
+            continue
+        n1 = (n + m) % N
+        near = (np.abs(ii - ii[n1]) + np.abs(jj - jj[n1])) == 1
+        w += float(near.sum())
+        au += float((d * d[n1])[near & okf & okf[n1]].sum())
+    return au / (w * sd * sd) if w > 0 else 0.0
+
+
+def domain_stats_host(values, field2d=None, mask=None) -> dict:
+    """The same statistics with numpy (for tests and for host-resident data).  Moran's I needs the 2-D field
+    (field2d, optional mask); without it the two slots carry the reference's -9999 marker."""
     x = np.sort(np.asarray(values, dtype=np.float64).ravel())
     n = x.size
     if n == 0:
@@ -54,8 +84,10 @@ def domain_stats_host(values) -> dict:
         v = 0.01 * p * (n - 1)
         return x[min(max(int(v + 0.5), 0), n - 1)]
 
+    se = sd / np.sqrt(n)
+    mi = morans_i_host(field2d, mask) if field2d is not None else -9999.0
     return dict(zip(STAT_NAMES, [float(x.mean()), sd, float(x[0]), float(x[-1]), pick(50.), pick(25.), pick(75.),
-                                 pick(5.), pick(95.), sd / np.sqrt(n), -9999.0, -9999.0, float(n)]))
+                                 pick(5.), pick(95.), se, mi, se * mi if field2d is not None else -9999.0, float(n)]))
 
 
 def _q(*errs):
