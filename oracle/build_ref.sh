@@ -42,4 +42,17 @@ if [ -f "$HERE/ref_harness_swinterp.F90" ]; then
     | $FC $FFLAGS -c -x f95-cpp-input - -o swinterp_inner.o -module-dir "$OUT"
   $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_swinterp.F90" swinterp_inner.o -o ref_swinterp -module-dir "$OUT"
 fi
+# helper routines of the LW wrapper module that need nothing from WRF: retab, INIRAD/O3DATA, relcalc/reicalc
+LWF="$REF/module_ra_rrtmg_lw.F"
+sed -n "11424p" "$LWF" | grep -qi 'real retab(95)' || { echo "retab line range moved" >&2; exit 1; }
+sed -n "12704p" "$LWF" | grep -qi 'SUBROUTINE INIRAD' || { echo "INIRAD line range moved" >&2; exit 1; }
+sed -n "12840p" "$LWF" | grep -qi 'END SUBROUTINE O3DATA' || { echo "O3DATA line range moved" >&2; exit 1; }
+sed -n "14403p" "$LWF" | grep -qi 'subroutine relcalc' || { echo "relcalc line range moved" >&2; exit 1; }
+sed -n "14491p" "$LWF" | grep -qi 'end subroutine reicalc' || { echo "reicalc line range moved" >&2; exit 1; }
+if [ -f "$HERE/ref_harness_wrapper.F90" ]; then
+  { echo "module wrapper_ref"; sed -n "11424,11444p" "$LWF"; echo "contains"; sed -n "12704,12840p" "$LWF";
+    sed -n "14403,14491p" "$LWF"; echo "end module wrapper_ref"; } \
+    | $FC $FFLAGS -c -x f95-cpp-input - -o wrapper_inner.o -module-dir "$OUT"
+  $FC -fdefault-real-8 -O2 -I"$OUT" "$HERE/ref_harness_wrapper.F90" wrapper_inner.o -o ref_wrapper -module-dir "$OUT"
+fi
 echo "build_ref: built $(ls $OUT/ref_* | tr '\n' ' ')"

@@ -87,6 +87,9 @@ typedef struct {
 int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, double *ciwp, double *cswp,
                        double *rel, double *rei, double *res, int *flags3);
 
+double oracle_relcalc(double t, double landm, double icefrac, double snowh);   /* LW:14403-14462 */
+double oracle_reicalc(double t);                                               /* LW:14464-14491 */
+
 /* McICA generator and cloud optics (rrtmg_sw_cloud_oracle.c) */
 int oracle_mcica(int nsub, int nlay, const double *play, const double *cldfrac, int change_seed, int real4,
                  double *cldfmc);

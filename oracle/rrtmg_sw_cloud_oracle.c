@@ -211,6 +211,27 @@ int sw_oracle_cldprmc(int nlay, int inflag, int iceflag, int liqflag, const doub
  * --------------------------------------------------------------------------------------------------------- */
 #include "cld_retab.h"
 
+/* relcalc, LW:14403-14462: liquid effective radius (um) from temperature and surface type.  Pinned bitwise on the
+ * reference routine (oracle/_ref/ref_wrapper, tests/golden/wrapper_helpers.npz). */
+double oracle_relcalc(double t, double landm, double icefrac, double snowh)
+{
+    const double tmelt = 273.16, rliqocean = 14.0, rliqice = 14.0, rliqland = 8.0;
+    double rel = rliqland + (rliqocean - rliqland) * fmin(1.0, fmax(0.0, (tmelt - t) * 0.05));
+    rel = rel + (rliqocean - rel) * fmin(1.0, fmax(0.0, snowh * 10.));
+    rel = rel + (rliqocean - rel) * fmin(1.0, fmax(0.0, 1.0 - landm));
+    rel = rel + (rliqice - rel) * fmin(1.0, fmax(0.0, icefrac));
+    return rel;
+}
+
+/* reicalc, LW:14464-14491: ice effective radius (um) from the retab table (LW:11424-11442).  Pinned likewise. */
+double oracle_reicalc(double t)
+{
+    int index = (int)(t - 179.);
+    index = index < 1 ? 1 : (index > 94 ? 94 : index);
+    const double corr = t - (double)(int)t;
+    return CLD_RETAB[index - 1] * (1. - corr) + CLD_RETAB[index] * corr;
+}
+
 int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, double *ciwp, double *cswp,
                        double *rel, double *rei, double *res, int *flags3)
 {
@@ -296,22 +317,10 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
                 reliq = fmax(reliq, 4.);
                 reliq = fmin(reliq, 20.);
             }
-        } else {               /* relcalc, LW:14403-14462 */
-            const double tmelt = 273.16, rliqocean = 14.0, rliqice = 14.0, rliqland = 8.0;
-            const double tr = w->t_rad ? w->t_rad[k] : w->t[k];
-            reliq = rliqland + (rliqocean - rliqland) * fmin(1.0, fmax(0.0, (tmelt - tr) * 0.05));
-            reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, snowh * 10.));
-            reliq = reliq + (rliqocean - reliq) * fmin(1.0, fmax(0.0, 1.0 - landm));
-            reliq = reliq + (rliqice - reliq) * fmin(1.0, fmax(0.0, icefrac));
+        } else {
+            reliq = oracle_relcalc(w->t_rad ? w->t_rad[k] : w->t[k], landm, icefrac, snowh);
         }
-        double reice;
-        {                      /* reicalc, LW:14464-14491 */
-            const double tr = w->t_rad ? w->t_rad[k] : w->t[k];
-            int index = (int)(tr - 179.);
-            index = index < 1 ? 1 : (index > 94 ? 94 : index);
-            double corr = tr - (double)(int)tr;
-            reice = CLD_RETAB[index - 1] * (1. - corr) + CLD_RETAB[index] * corr;
-        }
+        double reice = oracle_reicalc(w->t_rad ? w->t_rad[k] : w->t[k]);
         if (inflg >= 3) reliq = recloud1d[k];
         if (iceflg >= 4) reice = reice1d[k];
         if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
