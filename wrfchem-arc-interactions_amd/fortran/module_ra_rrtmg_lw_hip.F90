@@ -21,6 +21,26 @@ MODULE module_ra_rrtmg_lw
    IMPLICIT NONE
    PRIVATE
    PUBLIC :: rrtmg_lwrad, rrtmg_lwinit
+   PUBLIC :: inirad, o3data, relcalc, reicalc, retab
+
+   ! ice effective radius (um) versus temperature, 180..274 K (numeric table of the reference, LW:11424-11442)
+   REAL, SAVE :: retab(95) = (/ &
+         5.92779, 6.26422, 6.61973, 6.99539, 7.39234, 7.81177,  &
+         8.25496, 8.72323, 9.21800, 9.74075, 10.2930, 10.8765,  &
+         11.4929, 12.1440, 12.8317, 13.5581, 14.2319, 15.0351,  &
+         15.8799, 16.7674, 17.6986, 18.6744, 19.6955, 20.7623,  &
+         21.8757, 23.0364, 24.2452, 25.5034, 26.8125, 27.7895,  &
+         28.6450, 29.4167, 30.1088, 30.7306, 31.2943, 31.8151,  &
+         32.3077, 32.7870, 33.2657, 33.7540, 34.2601, 34.7892,  &
+         35.3442, 35.9255, 36.5316, 37.1602, 37.8078, 38.4720,  &
+         39.1508, 39.8442, 40.5552, 41.2912, 42.0635, 42.8876,  &
+         43.7863, 44.7853, 45.9170, 47.2165, 48.7221, 50.4710,  &
+         52.4980, 54.8315, 57.4898, 60.4785, 63.7898, 65.5604,  &
+         71.2885, 75.4113, 79.7368, 84.2351, 88.8833, 93.6658,  &
+         98.5739, 103.603, 108.752, 114.025, 119.424, 124.954,  &
+         130.630, 136.457, 142.446, 148.608, 154.956, 161.503,  &
+         168.262, 175.248, 182.473, 189.952, 197.699, 205.728,  &
+         214.055, 222.694, 231.661, 240.971, 250.639 /)
 
    INTEGER, PARAMETER :: errlen = 256
 
@@ -255,5 +275,111 @@ CONTAINS
                              REAL(p_top, c_double), INT(kme, c_int), rrtmg_hip_pick_device(), err)
       IF (rc /= 0) CALL fatal_from_c(err)
    END SUBROUTINE rrtmg_lwinit
+
+!------------------------------------------------------------------
+!  Host-side helpers other radiation schemes import from this module (the reference's module_ra_rrtmg_sw does,
+!  SW:9894): ozone climatology INIRAD / O3DATA (LW:12704-12840), effective radii relcalc / reicalc (LW:14403-14491)
+!  and the table retab (LW:11424-11442).  Plain Fortran on the host -- their callers are CPU code -- checked bit for
+!  bit against the reference routines (tests/test_fortran_lw_helpers.py, tests/golden/wrapper_helpers.npz).
+!------------------------------------------------------------------
+   SUBROUTINE inirad(o3prof, plev, kts, kte)
+      INTEGER, INTENT(IN) :: kts, kte
+      REAL, DIMENSION(kts:kte+1), INTENT(INOUT) :: o3prof
+      REAL, DIMENSION(kts:kte+2), INTENT(IN) :: plev
+      o3prof(kts:kte+1) = 0.
+      CALL o3data(o3prof, plev, kts, kte)
+   END SUBROUTINE inirad
+
+   SUBROUTINE o3data(o3prof, plev, kts, kte)
+      INTEGER, INTENT(IN) :: kts, kte
+      REAL, DIMENSION(kts:kte+1), INTENT(INOUT) :: o3prof
+      REAL, DIMENSION(kts:kte+2), INTENT(IN) :: plev
+      ! summer / winter mixing-ratio profiles and their pressure levels (mb), 31 levels
+      REAL, PARAMETER :: o3sum(31) = (/ &
+         5.297E-8, 5.852E-8, 6.579E-8, 7.505E-8, 8.577E-8, 9.895E-8,  &
+         1.175E-7, 1.399E-7, 1.677E-7, 2.003E-7, 2.571E-7, 3.325E-7,  &
+         4.438E-7, 6.255E-7, 8.168E-7, 1.036E-6, 1.366E-6, 1.855E-6,  &
+         2.514E-6, 3.240E-6, 4.033E-6, 4.854E-6, 5.517E-6, 6.089E-6,  &
+         6.689E-6, 1.106E-5, 1.462E-5, 1.321E-5, 9.856E-6, 5.960E-6,  &
+         5.960E-6 /)
+      REAL, PARAMETER :: ppsum(31) = (/ &
+         955.890, 850.532, 754.599, 667.742, 589.841, 519.421,  &
+         455.480, 398.085, 347.171, 301.735, 261.310, 225.360,  &
+         193.419, 165.490, 141.032, 120.125, 102.689, 87.829,  &
+         75.123, 64.306, 55.086, 47.209, 40.535, 34.795,  &
+         29.865, 19.122, 9.277, 4.660, 2.421, 1.294,  &
+         0.647 /)
+      REAL, PARAMETER :: o3win(31) = (/ &
+         4.629E-8, 4.686E-8, 5.017E-8, 5.613E-8, 6.871E-8, 8.751E-8,  &
+         1.138E-7, 1.516E-7, 2.161E-7, 3.264E-7, 4.968E-7, 7.338E-7,  &
+         1.017E-6, 1.308E-6, 1.625E-6, 2.011E-6, 2.516E-6, 3.130E-6,  &
+         3.840E-6, 4.703E-6, 5.486E-6, 6.289E-6, 6.993E-6, 7.494E-6,  &
+         8.197E-6, 9.632E-6, 1.113E-5, 1.146E-5, 9.389E-6, 6.135E-6,  &
+         6.135E-6 /)
+      REAL, PARAMETER :: ppwin(31) = (/ &
+         955.747, 841.783, 740.199, 649.538, 568.404, 495.815,  &
+         431.069, 373.464, 322.354, 277.190, 237.635, 203.433,  &
+         174.070, 148.949, 127.408, 108.915, 93.114, 79.551,  &
+         67.940, 58.072, 49.593, 42.318, 36.138, 30.907,  &
+         26.362, 16.423, 7.583, 3.620, 1.807, 0.938,  &
+         0.469 /)
+      REAL :: o3ann(31), ppwrkh(32), pb1, pb2, pt1, pt2
+      INTEGER :: k, jj
+      ! annual mean on the summer pressure levels
+      o3ann(1) = 0.5 * (o3sum(1) + o3win(1))
+      DO k = 2, 31
+         o3ann(k) = o3win(k-1) + (o3win(k) - o3win(k-1)) / (ppwin(k) - ppwin(k-1)) * (ppsum(k) - ppwin(k-1))
+      END DO
+      DO k = 2, 31
+         o3ann(k) = 0.5 * (o3ann(k) + o3sum(k))
+      END DO
+      ! half levels of the climatology, then the pressure-weighted mean over each model layer
+      ppwrkh(1) = 1100.
+      DO k = 2, 31
+         ppwrkh(k) = (ppsum(k) + ppsum(k-1)) / 2.
+      END DO
+      ppwrkh(32) = 0.
+      DO k = kts, kte + 1
+         DO jj = 1, 31
+            pb1 = plev(k) - ppwrkh(jj);     IF (-pb1 >= 0.) pb1 = 0.
+            pb2 = plev(k) - ppwrkh(jj+1);   IF (-pb2 >= 0.) pb2 = 0.
+            pt1 = plev(k+1) - ppwrkh(jj);   IF (-pt1 >= 0.) pt1 = 0.
+            pt2 = plev(k+1) - ppwrkh(jj+1); IF (-pt2 >= 0.) pt2 = 0.
+            o3prof(k) = o3prof(k) + (pb2 - pb1 - pt2 + pt1) * o3ann(jj)
+         END DO
+         o3prof(k) = o3prof(k) / (plev(k) - plev(k+1))
+      END DO
+   END SUBROUTINE o3data
+
+   SUBROUTINE relcalc(ncol, pcols, pver, t, landfrac, landm, icefrac, rel, snowh)
+      INTEGER, INTENT(IN) :: ncol, pcols, pver
+      REAL, INTENT(IN) :: landfrac(pcols), icefrac(pcols), snowh(pcols), landm(pcols), t(pcols,pver)
+      REAL, INTENT(OUT) :: rel(pcols,pver)
+      REAL, PARAMETER :: tmelt = 273.16, rliqocean = 14.0, rliqice = 14.0, rliqland = 8.0
+      INTEGER :: i, k
+      DO k = 1, pver
+         DO i = 1, ncol
+            rel(i,k) = rliqland + (rliqocean - rliqland) * MIN(1.0, MAX(0.0, (tmelt - t(i,k)) * 0.05))
+            rel(i,k) = rel(i,k) + (rliqocean - rel(i,k)) * MIN(1.0, MAX(0.0, snowh(i) * 10.))
+            rel(i,k) = rel(i,k) + (rliqocean - rel(i,k)) * MIN(1.0, MAX(0.0, 1.0 - landm(i)))
+            rel(i,k) = rel(i,k) + (rliqice - rel(i,k)) * MIN(1.0, MAX(0.0, icefrac(i)))
+         END DO
+      END DO
+   END SUBROUTINE relcalc
+
+   SUBROUTINE reicalc(ncol, pcols, pver, t, re)
+      INTEGER, INTENT(IN) :: ncol, pcols, pver
+      REAL, INTENT(IN) :: t(pcols,pver)
+      REAL, INTENT(OUT) :: re(pcols,pver)
+      REAL :: corr
+      INTEGER :: i, k, ix
+      DO k = 1, pver
+         DO i = 1, ncol
+            ix = MIN(MAX(INT(t(i,k) - 179.), 1), 94)
+            corr = t(i,k) - INT(t(i,k))
+            re(i,k) = retab(ix) * (1. - corr) + retab(ix+1) * corr
+         END DO
+      END DO
+   END SUBROUTINE reicalc
 
 END MODULE module_ra_rrtmg_lw
