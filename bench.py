@@ -296,7 +296,9 @@ def main():
             workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic columns per GPU, MOSAIC {args.nbin}-bin optical "
                         "averaging + SW+LW aerosol+clean double-call, fp64, "
                         + (f"McICA clouds in {100 * args.clouds:.0f} % of the columns" if args.clouds > 0 else "cloud-free")
-                        + " (BASELINE configs[2])")
+                        + (" (BASELINE configs[2])" if (args.ni, args.nj, args.nk, args.nbin) == (200, 200, 40, 4) else
+                           " (the domain and optics of BASELINE configs[3] on one GPU)"
+                           if (args.ni, args.nj, args.nk, args.nbin) == (500, 500, 50, 8) else ""))
         elif do_lw:
             workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, SW+LW aerosol+clean "
                         "double-call, fp64, cloud-free; aerosol optics supplied in the WRF-Chem compact form "
