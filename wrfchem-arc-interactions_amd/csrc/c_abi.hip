@@ -336,16 +336,27 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         const size_t percol = sw_scratch_doubles_per_column(k.nk);
         size_t cols = (mb << 20) / (percol * sizeof(double));
         if (cols < 8) cols = 8;
-        const int cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
+        int cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
         {
             std::lock_guard<std::mutex> lock(st.jump_mutex);
             SwState::Scratch &w = st.scratch[stream];
+            if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
             if (w.doubles < percol * (size_t)cap_cols) {
                 if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
+                // when the device cannot spare that much, halve the batch until it fits (down to 8 columns)
                 void *p = nullptr;
-                HIPCHK(hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double)));
+                hipError_t e = hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double));
+                while (e == hipErrorOutOfMemory && cap_cols > 8) {
+                    (void)hipGetLastError();
+                    cap_cols = cap_cols / 2 < 8 ? 8 : cap_cols / 2;
+                    w.limit = percol * (size_t)cap_cols;
+                    e = hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double));
+                }
+                HIPCHK(e);
                 w.p = static_cast<double *>(p);
                 w.doubles = percol * (size_t)cap_cols;
+            } else if (w.doubles / percol < (size_t)cap_cols) {
+                cap_cols = (int)(w.doubles / percol);
             }
             k.scratch = w.p;
         }

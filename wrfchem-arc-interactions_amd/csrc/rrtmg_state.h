@@ -29,7 +29,7 @@ struct SwState {
     std::map<int, void *> dJump;           // KISS jump tables by layer count
     std::mutex jump_mutex;
     // layer scratch of the column kernel, one grow-only buffer per stream (guarded by jump_mutex)
-    struct Scratch { double *p = nullptr; size_t doubles = 0; };
+    struct Scratch { double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */ };
     std::map<void *, Scratch> scratch;
 };
 
