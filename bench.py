@@ -97,6 +97,37 @@ def cpu_baseline(tab_sw, tab_lw, st, ncol_sample, mode):
             "sample": f"{n} columns through the C restatement of rrtmg_sw only (gcc -O2), {secs:.2f} s"}
 
 
+def flux_rmse(tab_sw, tab_lw, st, sw_out, lw_out, nrows, mode):
+    """The second half of the metric: root-mean-square difference between the device's fluxes / heating rates and
+    the CPU restatement of the reference (bit-exact with the reference solvers on the golden fixtures) over the
+    first `nrows` rows of the tile.  Part of the CPU-baseline leg (the only place bench.py touches oracle/)."""
+    from oracle import oracle as orc, oracle_lw
+    from tests.helpers import run_oracle_swrad
+    from tests.helpers_lw import run_oracle_lwrad
+    tile = dict(jts=1, jte=nrows)
+    res = {"columns": nrows * st.ni, "against": "oracle/ (C restatement, pinned bit for bit on the reference solvers)"}
+
+    def rms(got, ref, names, rows3=False):
+        d = []
+        for n in names:
+            g = got[n].cpu().numpy()
+            d.append((g[:nrows] - ref[n][:nrows]).ravel() if not rows3 else (g[:nrows, :st.nk] - ref[n][:nrows, :st.nk]).ravel())
+        d = np.concatenate(d)
+        return float(np.sqrt(np.mean(d * d))), float(np.abs(d).max())
+
+    ref = run_oracle_swrad(orc.SwOracle(tab_sw), st, tile=tile, profiles=False)
+    sw2 = [n for n in ref if n.startswith(("swup", "swdn")) and ref[n].ndim == 2]
+    res["sw_flux_rmse_Wm2"], res["sw_flux_maxabs_Wm2"] = rms(sw_out, ref, sw2)
+    res["sw_heating_rmse_K_per_day"] = rms(sw_out, ref, ["rthratensw"], rows3=True)[0] * 86400.0
+    if mode != "sw":
+        nlay = oracle_lw.nlayers(st.nk + 1, P_TOP)
+        refl = run_oracle_lwrad(oracle_lw.LwOracle(tab_lw), st, nlay, tile=tile, profiles=False)
+        lw2 = [n for n in refl if n.startswith(("lwup", "lwdn")) and refl[n].ndim == 2]
+        res["lw_flux_rmse_Wm2"], res["lw_flux_maxabs_Wm2"] = rms(lw_out, refl, lw2)
+        res["lw_heating_rmse_K_per_day"] = rms(lw_out, refl, ["rthratenlw"], rows3=True)[0] * 86400.0
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +369,7 @@ def main():
                     cb["sample"] += (f"; optical averaging: {n_opt} columns through the C port of the engine's own "
                                      f"specification (no reference arithmetic exists), {spc_opt * n_opt:.2f} s, 1 thread")
                 line["cpu_baseline"] = cb
+                line["flux_rmse"] = flux_rmse(tab, tabl, st, sw_out, lw_out, max(1, min(st.nj, 400 // st.ni)), args.mode)
             except Exception as e:   # never let the baseline leg kill the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "reference",
                                         "sample": f"failed: {e!r}"}
