@@ -81,21 +81,26 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
     else reinterpret_cast<double *>(p)[idx] = v;
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+// One step of a wave reduction in the VALU (data-parallel primitive, no LDS round trip): v + v moved by `ctrl`;
+// rows not selected by row_mask receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int mlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    const int mhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(mhi, mlo);
 }
-
-// sums of two values over the wave in one butterfly: lane 0 ends with sum(a), lane 32 with sum(b)
-__device__ __forceinline__ double wave_sum2(double a, double b, int lane)
+// sum over the 64 lanes, valid in lane 63: pairs inside quads, quads inside half rows, half rows, rows
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror, row_bcast15, row_bcast31)
+__device__ __forceinline__ double wave_sum_l63(double v)
 {
-    const bool hi = lane & 32;
-    double send = hi ? a : b, keep = hi ? b : a;
-    double v = keep + __shfl_xor(send, 32, 64);
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = dpp_add<0xB1, 0xF>(v);
+    v = dpp_add<0x4E, 0xF>(v);
+    v = dpp_add<0x141, 0xF>(v);
+    v = dpp_add<0x140, 0xF>(v);
+    v = dpp_add<0x142, 0xA>(v);
+    v = dpp_add<0x143, 0xC>(v);
     return v;
 }
 
@@ -125,7 +130,7 @@ __device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze
     double tblind = fdiv(ze1, tb.bpade + ze1);
     int itind = (int)(10000.0 * tblind + 0.5);
     itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
-    double tv = tb.exp_tbl[itind];
+    double tv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.exp_tbl) + (uint32_t)itind * 8u);
     double sv = 1. - ze1 + 0.5 * ze1 * ze1;
     return ze1 <= 0.06 ? sv : tv;
 }
@@ -336,21 +341,23 @@ __device__ __forceinline__ void gas_fetch(const SwDeviceTables &tb, const ColVie
     }
     p.fs = fs; p.speccomb = speccomb;
     const int ng = L.ng;
-    const double *K0 = tb.K + R.off_major + (size_t)(c.rb0[k] * nsp + jsi) * ng;
-    const double *K1 = tb.K + R.off_major + (size_t)(c.rb1[k] * nsp + jsi) * ng;
-    const int dT = nsp * ng;
-    p.kv[0] = K0[0]; p.kv[1] = K0[ng]; p.kv[2] = K0[dT]; p.kv[3] = K0[dT + ng];
-    p.kv[4] = K1[0]; p.kv[5] = K1[ng]; p.kv[6] = K1[dT]; p.kv[7] = K1[dT + ng];
+    // element offsets fit 32 bits (the table is < 1 MB): uniform base + 32-bit lane offset, no 64-bit address math
+    auto at = [&](uint32_t e) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.K) + e * 8u); };
+    const uint32_t K0 = (uint32_t)R.off_major + (uint32_t)(c.rb0[k] * nsp + jsi) * (uint32_t)ng;
+    const uint32_t K1 = (uint32_t)R.off_major + (uint32_t)(c.rb1[k] * nsp + jsi) * (uint32_t)ng;
+    const uint32_t dT = (uint32_t)(nsp * ng);
+    p.kv[0] = at(K0); p.kv[1] = at(K0 + ng); p.kv[2] = at(K0 + dT); p.kv[3] = at(K0 + dT + ng);
+    p.kv[4] = at(K1); p.kv[5] = at(K1 + ng); p.kv[6] = at(K1 + dT); p.kv[7] = at(K1 + dT + ng);
     p.s0 = p.s1 = p.f0 = p.f1 = 0.;
     if (cf & (CFG_SELF | CFG_FOR)) {
-        const double *Sf = tb.K + L.off_self + (size_t)c.inds[k] * ng;
-        const double *Ff = tb.K + L.off_for + (size_t)c.indf[k] * ng;
-        p.s0 = Sf[0]; p.s1 = Sf[ng]; p.f0 = Ff[0]; p.f1 = Ff[ng];
+        const uint32_t Sf = (uint32_t)L.off_self + (uint32_t)c.inds[k] * (uint32_t)ng;
+        const uint32_t Ff = (uint32_t)L.off_for + (uint32_t)c.indf[k] * (uint32_t)ng;
+        p.s0 = at(Sf); p.s1 = at(Sf + ng); p.f0 = at(Ff); p.f1 = at(Ff + ng);
     }
     p.r0 = p.r1 = 0.;
     if (cf & CFG_RAYL24) {   // SW:4130-4131
-        const double *Ra = tb.K + L.off_rayla + (size_t)jsi * ng;
-        p.r0 = Ra[0]; p.r1 = Ra[ng];
+        const uint32_t Ra = (uint32_t)L.off_rayla + (uint32_t)jsi * (uint32_t)ng;
+        p.r0 = at(Ra); p.r1 = at(Ra + ng);
     }
 }
 
@@ -1013,9 +1020,9 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     double zreflect = frcp(1. -rdnd * rud[j + 1]);
                     double fu = (tdbt * ru[j + 1] + (tdn - tdbt) * rud[j + 1]) * zreflect;
                     double fd = tdbt + (tdn - tdbt + tdbt * ru[j + 1] * rdnd) * zreflect;
-                    double s2 = wave_sum2(zincflx * fu, zincflx * fd, lane);
-                    if (lane == 0) flux[2 * l] = s2;
-                    if (lane == 32) flux[2 * l + 1] = s2;
+                    // two independent reductions (their steps interleave); lane 63 holds both sums
+                    const double su = wave_sum_l63(zincflx * fu), sd = wave_sum_l63(zincflx * fd);
+                    if (lane == 63) { flux[2 * l] = su; flux[2 * l + 1] = sd; }
                 }
                 // through layer k, SW:8026-8034 and SW:8578
                 double zreflect = frcp(1. -rt[j].refd * rdnd);
@@ -1030,15 +1037,15 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             double zreflect = frcp(1. -rdnd * alb);
             double fu = (tdbt * alb + (tdn - tdbt) * alb) * zreflect;
             double fd = tdbt + (tdn - tdbt + tdbt * alb * rdnd) * zreflect;
-            double su = wave_sum(zincflx * fu), sd = wave_sum(zincflx * fd);
-            if (lane == 0) { flux[0] = su; flux[1] = sd; }
+            double su = wave_sum_l63(zincflx * fu), sd = wave_sum_l63(zincflx * fd);
+            if (lane == 63) { flux[0] = su; flux[1] = sd; }
             if (want_sfc) {
                 // surface-only direct / UV-visible / near-IR sums of the total-sky call (SW:8633-8647 at ikl = 1)
                 const double uv = gd.uvband ? zincflx : 0., ni = gd.uvband ? 0. : zincflx;
-                double dirbb = wave_sum(zincflx * tdbt_nodel);
-                double uvfd = wave_sum(uv * fd), uvdir = wave_sum(uv * tdbt_nodel);
-                double nifd = wave_sum(ni * fd), nidir = wave_sum(ni * tdbt_nodel);
-                if (lane == 0) {
+                double dirbb = wave_sum_l63(zincflx * tdbt_nodel);
+                double uvfd = wave_sum_l63(uv * fd), uvdir = wave_sum_l63(uv * tdbt_nodel);
+                double nifd = wave_sum_l63(ni * fd), nidir = wave_sum_l63(ni * tdbt_nodel);
+                if (lane == 63) {
                     double *s = c.sfc + wave * 8;
                     s[0] = dirbb; s[1] = uvfd; s[2] = uvdir; s[3] = nifd; s[4] = nidir;
                 }
