@@ -102,6 +102,9 @@ typedef struct rrtmg_hip_swrad_args {
      * ignored (SW:9313-9340).  NULL = aer_opt /= 1.  The clean call uses zero aerosol optical depth (the
      * reference leaves ztauacln unset on this route). */
     const void *aerod;
+    /* SSiB land surface (sf_surface_physics = 8, SW:10692-10703): spectral albedos (2-D) used where xland < 1.5;
+     * the four together or none.  NULL = the broadband albedo everywhere.  xland is then read whatever icloud. */
+    const void *alswvisdir, *alswvisdif, *alswnirdir, *alswnirdif;
 } rrtmg_hip_swrad_args;
 
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);

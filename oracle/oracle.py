@@ -136,7 +136,8 @@ class SwTileIn(C.Structure):
                 + [(n, dp) for n in CLOUD3 + CLOUD2]
                 + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
                 + [("g", C.c_double), ("seed_real4", C.c_int)]
-                + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw", "aerod")])
+                + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw", "aerod",
+                                     "alswvisdir", "alswvisdif", "alswnirdir", "alswnirdif")])
 
 
 SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",

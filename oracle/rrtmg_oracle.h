@@ -134,6 +134,7 @@ typedef struct {
     int seed_real4;
     const double *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   /* (i,k,j,band), optional (SW:10982-10991) */
     const double *aerod;                                     /* (i,k,j,6), optional: aer_opt = 1 (SW:11083-11100) */
+    const double *alswvisdir, *alswvisdif, *alswnirdir, *alswnirdif;   /* SSiB albedos (2-D), optional (SW:10692-10703) */
 } SwTileIn;
 
 /* iaer = 6: band optical properties of the mixture of the six ECMWF aerosol types, SW:9313-9340.

@@ -1380,8 +1380,14 @@ int sw_oracle_swrad_tile(const SwTables *t, const SwTileIn *in, SwTileOut *out, 
                     }
                     sw_oracle_ecaer_bands(nlay, ecaer, tauaer, ssaaer, asmaer);
                 }
+                /* SSiB land surface: spectral albedos where xland < 1.5, SW:10692-10703 */
+                double asdir = alb, asdif = alb, aldir = alb, aldif = alb;
+                if (in->alswvisdir && in->xland[I2(i, j)] < 1.5) {
+                    asdir = in->alswvisdir[I2(i, j)]; asdif = in->alswvisdif[I2(i, j)];
+                    aldir = in->alswnirdir[I2(i, j)]; aldif = in->alswnirdif[I2(i, j)];
+                }
                 SwColumnIn ci = {nlay, play, plev, tlay, tlev, in->tsk[I2(i, j)], h2ovmr, o3vmr, co2vmr, ch4vmr,
-                                 n2ovmr, o2vmr, alb, alb, alb, alb, coszrs, 1.0, in->solcon, 0,
+                                 n2ovmr, o2vmr, asdir, asdif, aldir, aldif, coszrs, 1.0, in->solcon, 0,
                                  tauaer, ssaaer, asmaer, in->clean_atm_diag};
                 double cst[7][MAXLAY], cin[9][MAXLAY];
                 if (in->icloud != 0) {

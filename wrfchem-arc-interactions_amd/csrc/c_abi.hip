@@ -214,6 +214,9 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         !(a->tauaer300 && a->tauaer400 && a->tauaer600 && a->tauaer999 && a->gaer300 && a->gaer400 && a->gaer600 &&
           a->gaer999 && a->waer300 && a->waer400 && a->waer600 && a->waer999))
         return fail(err, "Warning: missing fields required for aerosol radiation");   // SW:10287-10305
+    if ((a->alswvisdir || a->alswvisdif || a->alswnirdir || a->alswnirdif) &&
+        !(a->alswvisdir && a->alswvisdif && a->alswnirdir && a->alswnirdif && a->xland))
+        return fail(err, "rrtmg_hip_swrad: the four SSiB albedos and xland must be passed together");
     if (a->tauaer3d_sw && !(a->ssaaer3d_sw && a->asyaer3d_sw))
         return fail(err, "rrtmg_hip_swrad: tauaer3d_sw needs ssaaer3d_sw and asyaer3d_sw");
     if (sw_lds_bytes(nk) > 160 * 1024) return fail(err, "rrtmg_hip_swrad: column does not fit LDS");
@@ -272,6 +275,10 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         k.swdnflx = a->swdnflx; k.swdnflxc = a->swdnflxc; k.swdnflxcln = a->swdnflxcln;
         k.tauaer3d_sw = a->tauaer3d_sw; k.ssaaer3d_sw = a->ssaaer3d_sw; k.asyaer3d_sw = a->asyaer3d_sw;
         k.aerod = a->aerod;
+        if (a->alswvisdir) {
+            k.alswvisdir = a->alswvisdir; k.alswvisdif = a->alswvisdif; k.alswnirdir = a->alswnirdir;
+            k.alswnirdif = a->alswnirdif; k.xland = a->xland;
+        }
         if (a->icloud != 0) {
             k.cldfra3d = a->cldfra3d; k.qc3d = a->qc3d; k.qr3d = a->qr3d; k.qi3d = a->qi3d; k.qs3d = a->qs3d;
             k.re_cloud = a->has_reqc ? a->re_cloud : nullptr; k.re_ice = a->has_reqi ? a->re_ice : nullptr;
@@ -299,6 +306,10 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             HIPCHK(stg.in(a->ssaaer3d_sw, n4, stream, &k.ssaaer3d_sw));
             HIPCHK(stg.in(a->asyaer3d_sw, n4, stream, &k.asyaer3d_sw));
             HIPCHK(stg.in(a->aerod, n3 * 6, stream, &k.aerod));
+        }
+        if (a->alswvisdir) {
+            IN2(alswvisdir); IN2(alswvisdif); IN2(alswnirdir); IN2(alswnirdif);
+            if (a->icloud == 0) IN2(xland);
         }
         if (a->icloud != 0) {
             IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);

@@ -30,6 +30,7 @@ struct SwKernelArgs {
     const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
     const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   // (i,k,j,band) band-resolved aerosol input, optional
     const void *aerod;                   // (i,k,j,6) ECMWF aerosol types, aer_opt = 1 / iaer = 6, optional
+    const void *alswvisdir, *alswvisdif, *alswnirdir, *alswnirdif;   // SSiB spectral albedos (2-D), optional
     const uint32_t *jump;                // KISS jump-ahead table for this layer count: [SW_NGPT][KISS_JUMP_WORDS]
     const double *cldtab;                // cloud optics coefficients [CLD_NTAB][SW_NBND][CLD_STRIDE]
     double *scratch;                     // ncol x scratch_stride doubles

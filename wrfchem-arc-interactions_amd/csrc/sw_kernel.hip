@@ -953,7 +953,13 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     }
     const double adjflux = 1.0 * (a.solcon / 1.36822e+03);   // adjes = 1, dyofyr = 0 (SW:10623-10626, 9735-9739)
     const double zincflx = active ? adjflux * sfluxzen * prmu0 : 0.;   // SW:8363
-    const double alb = ldr(a.albedo, i2, r4);                   // asdir = asdif = aldir = aldif (SW:10699-10702)
+    // surface albedo of this lane's band, direct and diffuse: the broadband value (SW:10699-10702) or, over SSiB
+    // land, the UV/visible pair in bands 25-28 and the near-IR pair elsewhere (SW:10692-10697, 9266-9277)
+    double albp = ldr(a.albedo, i2, r4), albd = albp;
+    if (a.alswvisdir && ldr(a.xland, i2, r4) < 1.5) {
+        albp = gd.uvband ? ldr(a.alswvisdir, i2, r4) : ldr(a.alswnirdir, i2, r4);
+        albd = gd.uvband ? ldr(a.alswvisdif, i2, r4) : ldr(a.alswnirdif, i2, r4);
+    }
     double *ck = scr_block + (size_t)4 * nlay * SW_SCR_VALS * 64 + (size_t)wave * nblk * 2 * 64;
     double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * 64 + lane;
     int bad = 0;
@@ -962,7 +968,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     // sub-column's cloudy layers (0: clear sky).  Fluxes per level go to flux[2l], flux[2l+1].
     auto run_pass = [&](const bool aer_on, const uint64_t mask, double *flux, const bool want_sfc) {
         // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
-        double rup = alb, rupd = alb;
+        double rup = albp, rupd = albd;
         GasPre gp;
         gas_fetch(tb, c, L, 0, 0 < laytrop, gp);
         for (int k = 0; k < nlay; ++k) {
@@ -1034,9 +1040,9 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             }
         }
         {   // surface level
-            double zreflect = frcp(1. -rdnd * alb);
-            double fu = (tdbt * alb + (tdn - tdbt) * alb) * zreflect;
-            double fd = tdbt + (tdn - tdbt + tdbt * alb * rdnd) * zreflect;
+            double zreflect = frcp(1. -rdnd * albd);
+            double fu = (tdbt * albp + (tdn - tdbt) * albd) * zreflect;
+            double fd = tdbt + (tdn - tdbt + tdbt * albp * rdnd) * zreflect;
             double su = wave_sum_l63(zincflx * fu), sd = wave_sum_l63(zincflx * fd);
             if (lane == 63) { flux[0] = su; flux[1] = sd; }
             if (want_sfc) {

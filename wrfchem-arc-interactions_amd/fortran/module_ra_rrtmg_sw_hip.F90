@@ -57,6 +57,7 @@ MODULE module_ra_rrtmg_sw
       REAL(c_double) :: g
       TYPE(c_ptr) :: tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw
       TYPE(c_ptr) :: aerod
+      TYPE(c_ptr) :: alswvisdir, alswvisdif, alswnirdir, alswnirdif
    END TYPE swrad_args
 
    INTERFACE
@@ -211,7 +212,14 @@ CONTAINS
             a%aerod = c_loc(aerod)
          END IF
       END IF
-      IF (sf_surface_physics == 8) CALL wrf_error_fatal('rrtmg_swrad (HIP): SSiB spectral albedo is not supported')
+      ! SSiB land surface: spectral albedos where xland < 1.5 (SW:10692-10703)
+      a%alswvisdir = c_null_ptr; a%alswvisdif = c_null_ptr; a%alswnirdir = c_null_ptr; a%alswnirdif = c_null_ptr
+      IF (sf_surface_physics == 8) THEN
+         IF (.NOT. (PRESENT(alswvisdir) .AND. PRESENT(alswvisdif) .AND. PRESENT(alswnirdir) .AND. PRESENT(alswnirdif))) &
+            CALL wrf_error_fatal('rrtmg_swrad (HIP): sf_surface_physics=8 needs alswvisdir, alswvisdif, alswnirdir, alswnirdif')
+         a%alswvisdir = c_loc(alswvisdir); a%alswvisdif = c_loc(alswvisdif)
+         a%alswnirdir = c_loc(alswnirdir); a%alswnirdif = c_loc(alswnirdif)
+      END IF
       IF (.NOT. PRESENT(qv3d)) CALL wrf_error_fatal('rrtmg_swrad (HIP): qv3d is required')
 
       a%xcoszen = c_loc(xcoszen); a%albedo = c_loc(albedo); a%tsk = c_loc(tsk)
