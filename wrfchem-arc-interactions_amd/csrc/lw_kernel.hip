@@ -233,14 +233,13 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         }
         if (!binary) { wm1 = 0.; w0 = 1.; w1 = 0.; w2 = 0.; jsi = 0; speccomb = colA; }
         const double *Kp = tb.K + R.off_major + (size_t)(rb[m] * nsp + jsi) * ng;
-        double s;
-        if (__any(wm1 != 0. || w2 != 0.)) {   // some lane of the wave sits on a 3-point edge stencil
-            s = (wm1 * fT[m]) * Kp[-ng] + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * Kp[2 * ng] +
-                (wm1 * fT1[m]) * Kp[ts - ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] +
-                (w2 * fT1[m]) * Kp[ts + 2 * ng];
-        } else {                              // same value: the skipped terms are exact zeros
-            s = (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng];
-        }
+        // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
+        // their weights are exact zeros and the products drop out
+        double em0 = 0., em1 = 0., ep0 = 0., ep1 = 0.;
+        if (wm1 != 0.) { em0 = Kp[-ng]; em1 = Kp[ts - ng]; }
+        if (w2 != 0.) { ep0 = Kp[2 * ng]; ep1 = Kp[ts + 2 * ng]; }
+        double s = (wm1 * fT[m]) * em0 + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * ep0 +
+                   (wm1 * fT1[m]) * em1 + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] + (w2 * fT1[m]) * ep1;
         maj[m] = s;
         sc[m] = speccomb;
     }
