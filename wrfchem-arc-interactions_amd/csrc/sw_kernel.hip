@@ -139,72 +139,6 @@ struct RT {
     double ref, refd, tra, trad, dbt;
 };
 
-// reftra_sw, PIFM (kmodts = 2), SW:2526-2699, for one layer
-__device__ __forceinline__ void reftra(const SwDeviceTables &tb, double zto1, double zw, double zg, double prmuz,
-                                       RT &o)
-{
-    const double eps = 1.e-08, zwcrit = 0.9999995;
-    double zg3 = 3. * zg;
-    double zgamma1 = (8. - zw * (5. + zg3)) * 0.25;
-    double zgamma2 = 3. * (zw * (1. - zg)) * 0.25;
-    double zgamma3 = (2. - zg3 * prmuz) * 0.25;
-    double zgamma4 = 1. - zgamma3;
-    double zq = zg / (1. - zg);
-    double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
-    double zwo = zw / denom;
-    if (zwo >= zwcrit) {
-        // conservative scattering, SW:2560-2600
-        double za = zgamma1 * prmuz;
-        double za1 = za - zgamma3;
-        double zgt = zgamma1 * zto1;
-        double ze1 = fmin(zto1 / prmuz, 500.);
-        double ze2 = exp_lookup(tb, ze1);
-        double r = (zgt - za1 * (1. - ze2)) / (1. + zgt);
-        double rd = zgt / (1. + zgt);
-        bool one = (ze2 == 1.0);
-        o.ref = one ? 0.0 : r;
-        o.tra = one ? 1.0 : 1. - r;
-        o.refd = one ? 0.0 : rd;
-        o.trad = one ? 1.0 : 1. - rd;
-    } else {
-        double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
-        double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
-        double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
-        double zrp = zrk * prmuz;
-        double zrp1 = 1. + zrp;
-        double zrm1 = 1. - zrp;
-        double zrk2 = 2. * zrk;
-        double zrpp = 1. - zrp * zrp;
-        double zrkg = zrk + zgamma1;
-        double zr1 = zrm1 * (za2 + zrk * zgamma3);
-        double zr2 = zrp1 * (za2 - zrk * zgamma3);
-        double zr3 = zrk2 * (zgamma3 - za2 * prmuz);
-        double zr4 = zrpp * zrkg;
-        double zr5 = zrpp * (zrk - zgamma1);
-        double zt1 = zrp1 * (za1 + zrk * zgamma4);
-        double zt2 = zrm1 * (za1 - zrk * zgamma4);
-        double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-        double zbeta = (zgamma1 - zrk) / zrkg;
-        double ze1 = fmin(zrk * zto1, 500.);
-        double ze2 = fmin(zto1 / prmuz, 500.);
-        double zem1 = exp_lookup(tb, ze1);
-        double zep1 = 1. / zem1;
-        double zem2 = exp_lookup(tb, ze2);
-        double zep2 = 1. / zem2;
-        double zdenr = zr4 * zep1 + zr5 * zem1;
-        double zdent = zr4 * zep1 + zr5 * zem1;
-        bool small = (zdenr >= -eps && zdenr <= eps);
-        double r = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
-        double t = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
-        o.ref = small ? eps : r;
-        o.tra = small ? zem2 : t;
-        double zemm = zem1 * zem1;
-        double zdend = 1. / ((1. - zbeta * zemm) * zrkg);
-        o.refd = zgamma2 * (1. - zemm) * zdend;
-        o.trad = zrk2 * zem1 * zdend;
-    }
-}
-
 // reftra_sw (SW:2526-2699) with the divisions folded: the reference forms zep1 = 1/zem1 and
 // zep2 = 1/zem2 and divides by zdenr = zr4*zep1 + zr5*zem1 (= zdent); multiplying numerators and
 // denominator by zem1 gives the same ratios over D = zr4 + zr5*zem1^2 with one reciprocal, and
