@@ -91,3 +91,39 @@ def test_lw_cloud_refusals_and_fatal_sizes(hip_lib, wa, lw_table_file):
     st.a3["qi3d"][:, 5, :] = 1.0e-4
     with pytest.raises(wa.engine.WrfFatal, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
         run_hip_lwrad(eng, st, cloud=cloud)
+
+
+def test_cloudy_lw_full_size_properties_200x200x40(hip_lib, wa, lw_table_file):
+    """BASELINE size with cloud in a fifth of the columns: the clear-sky fluxes of a cloudy run are the total-sky
+    fluxes of the same state run without cloud, cloud-free columns are untouched by icloud (bitwise), cloud reduces
+    the outgoing longwave, and a permutation of the columns permutes the results."""
+    eng, _ = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(200, 200, 40, seed=20260440)
+    base = run_hip_lwrad(eng, st, profiles=False)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260441, cloudy_fraction=0.2)
+    got = run_hip_lwrad(eng, st, cloud=cloud, profiles=False)
+    cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
+    clear = ~cloudy
+    assert cloudy.sum() > 4000
+    for n in got:
+        if got[n].ndim == 2:
+            assert np.isfinite(got[n]).all(), n
+    # to rounding, not bitwise: in a layer where some sub-column is cloudy rtrnmc evaluates the clear stream through
+    # the cloudy-layer regime arithmetic (LW:3216-3282), which rounds differently from the cloud-free branch
+    for c, t in (("lwuptc", "lwupt"), ("lwdnbc", "lwdnb"), ("lwupbc", "lwupb")):
+        np.testing.assert_allclose(got[c], base[t], rtol=1e-13, atol=0, err_msg=c)
+        np.testing.assert_array_equal(got[c][clear], base[t][clear], err_msg=c)
+    for n in ("lwupt", "lwdnb", "lwuptcln", "glw", "olr"):
+        np.testing.assert_array_equal(got[n][clear], base[n][clear], err_msg=n)
+    assert (got["lwcf"][clear] == 0).all()
+    # cloud tops are colder than the surface, cloud bases warmer than the clear sky above (in most columns: McICA
+    # samples one cloud state per g-point)
+    assert (got["lwupt"][cloudy] <= got["lwuptc"][cloudy]).mean() > 0.9
+    assert (got["lwdnb"][cloudy] >= got["lwdnbc"][cloudy]).mean() > 0.9
+    perm = np.random.default_rng(0).permutation(st.ni)
+    for d in (st.a2, st.a3):
+        for n in d:
+            d[n] = np.ascontiguousarray(d[n][..., perm])
+    got2 = run_hip_lwrad(eng, st, cloud=cloud, profiles=False)
+    for n in ("lwupt", "lwdnb", "lwuptcln", "lwcf"):
+        np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)

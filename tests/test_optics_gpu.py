@@ -111,3 +111,40 @@ def test_optics_feed_the_radiation(hip_lib, wa, sw_table_file, sw_oracle):
     assert compare_sw(hip, orc, 1e-8, 1e-8) < 1e-7
     forcing = hip["swuptcln"] - hip["swupt"]
     assert np.abs(forcing).max() > 0.1
+
+
+def test_optics_full_size_properties_200x200x40(hip_lib, wa):
+    """BASELINE configs[2] size: size-independent properties instead of the (slow) oracle -- physical bounds, exact
+    linearity in the particle number (masses and numbers doubled: every diameter, size parameter and refractive index
+    is unchanged, so tau doubles exactly and omega, g stay bitwise the same), and invariance under a permutation of
+    the columns."""
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(200, 200, 40, seed=20260360)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260361)
+    got = run_hip_optics(wa, st, ms)
+    mask = tile_mask(st, ms.alt.shape)
+    for n, g in got.items():
+        v = g[mask]
+        assert np.isfinite(v).all(), n
+        assert (v >= 0).all(), n
+        if n.startswith(("waer", "gaer")):
+            assert (v <= 1.0).all(), n
+    assert got["tauaer1"][mask].max() > 1e-4 and got["tauaerlw8"][mask].max() > 1e-6
+    # shortwave extinction falls from 300 to 999 nm on average (sub-micron particles dominate), absorption does not vanish
+    assert got["tauaer1"][mask].mean() > got["tauaer4"][mask].mean()
+    ms2 = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260361)
+    ms2.chem = ms2.chem * 2.0
+    got2 = run_hip_optics(wa, st, ms2)
+    for n in got:
+        if n.startswith(("waer", "gaer")):
+            np.testing.assert_array_equal(got2[n][mask], got[n][mask], err_msg=n)
+        else:   # optical depths, extinction and backscatter coefficients
+            np.testing.assert_array_equal(got2[n][mask], 2.0 * got[n][mask], err_msg=n)
+    perm = np.random.default_rng(1).permutation(st.ni)
+    ms3 = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260361)
+    ms3.chem = np.ascontiguousarray(ms3.chem[..., perm])
+    ms3.alt = np.ascontiguousarray(ms3.alt[..., perm])
+    ms3.dz8w = np.ascontiguousarray(ms3.dz8w[..., perm])
+    got3 = run_hip_optics(wa, st, ms3)
+    for n in ("tauaer2", "waer2", "gaer2", "tauaerlw5", "tauaerlw6"):
+        np.testing.assert_array_equal(got3[n], got[n][..., perm], err_msg=n)

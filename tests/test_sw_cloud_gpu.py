@@ -81,3 +81,38 @@ def test_cloud_refusals_and_fatal_sizes(hip_lib, wa, sw_table_file):
     st.a2["xcoszen"][...] = 0.5
     with pytest.raises(wa.engine.WrfFatal, match="ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS"):
         run_hip_swrad(eng, st, cloud=cloud)
+
+
+def test_cloudy_full_size_properties_200x200x40(hip_lib, wa, sw_table_file):
+    """BASELINE size with cloud in a fifth of the columns: size-independent properties -- the clear-sky fluxes of a
+    cloudy run are the total-sky fluxes of the same state run without cloud (bitwise), cloud-free columns are
+    untouched by icloud, and a permutation of the columns permutes the results (the McICA seeds depend on the column's
+    own pressures only)."""
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(200, 200, 40, seed=20260430, night_fraction=0.1)
+    base = run_hip_swrad(eng, st, profiles=False)                      # icloud = 0
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260431, cloudy_fraction=0.2)
+    got = run_hip_swrad(eng, st, cloud=cloud, profiles=False)
+    day = st.a2["xcoszen"] > 0
+    cloudy = (st.a3["cldfra3d"].sum(axis=1) > 0) & day
+    clear = (st.a3["cldfra3d"].sum(axis=1) == 0) & day
+    assert cloudy.sum() > 4000 and clear.sum() > 20000
+    for n in got:
+        if got[n].ndim == 2:
+            assert np.isfinite(got[n][day]).all(), n
+    for c, t in (("swuptc", "swupt"), ("swdnbc", "swdnb"), ("swupbc", "swupb")):
+        np.testing.assert_array_equal(got[c][day], base[t][day], err_msg=c)
+    for n in ("swupt", "swdnb", "swuptcln", "gsw"):
+        np.testing.assert_array_equal(got[n][clear], base[n][clear], err_msg=n)
+    assert (got["swcf"][clear] == 0).all()
+    # cloud reflects: more upward flux at the top and less sunlight at the surface in most cloudy columns (McICA
+    # samples one cloud state per g-point, so single columns may go either way)
+    assert (got["swupt"][cloudy] > got["swuptc"][cloudy]).mean() > 0.7
+    assert (got["swdnb"][cloudy] <= got["swdnbc"][cloudy]).mean() > 0.9
+    perm = np.random.default_rng(0).permutation(st.ni)
+    for d in (st.a2, st.a3):
+        for n in d:
+            d[n] = np.ascontiguousarray(d[n][..., perm])
+    got2 = run_hip_swrad(eng, st, cloud=cloud, profiles=False)
+    for n in ("swupt", "swdnb", "swuptcln", "swcf"):
+        np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)
