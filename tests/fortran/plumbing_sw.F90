@@ -4,7 +4,8 @@
 PROGRAM plumbing_sw
    USE module_ra_rrtmg_sw, ONLY : rrtmg_swrad, rrtmg_swinit
    IMPLICIT NONE
-   INTEGER :: ni, nj, nk, clean, icloud, aeropt
+   INTEGER :: ni, nj, nk, clean, icloud, aeropt, ssib, sfphys
+   REAL, ALLOCATABLE, DIMENSION(:,:) :: alswvisdir, alswvisdif, alswnirdir, alswnirdif
    REAL, ALLOCATABLE, DIMENSION(:,:,:,:) :: aerod
    REAL, ALLOCATABLE, DIMENSION(:,:,:) :: cldfra3d, qc3d, qr3d, qi3d, qs3d
    INTEGER :: ids,ide,jds,jde,kds,kde, ims,ime,jms,jme,kms,kme, its,ite,jts,jte,kts,kte
@@ -20,7 +21,9 @@ PROGRAM plumbing_sw
    CALL get_command_argument(2, fout)
    OPEN(11, file=TRIM(fin), access='stream', form='unformatted', status='old')
    READ(11) ni, nj, nk, clean
-   aeropt = clean / 100           ! header word: clean_atm_diag + 10*icloud + 100*aer_opt
+   ssib = clean / 1000            ! header word: clean_atm_diag + 10*icloud + 100*aer_opt + 1000*ssib
+   clean = MOD(clean, 1000)
+   aeropt = clean / 100
    clean = MOD(clean, 100)
    icloud = clean / 10
    clean = MOD(clean, 10)
@@ -53,8 +56,16 @@ PROGRAM plumbing_sw
    ALLOCATE(aerod(ims:ime,kms:kme,jms:jme,6))
    aerod = 0.
    IF (aeropt == 1) READ(11) aerod
+   ALLOCATE(alswvisdir(ims:ime,jms:jme), alswvisdif(ims:ime,jms:jme), alswnirdir(ims:ime,jms:jme), alswnirdif(ims:ime,jms:jme))
+   alswvisdir = 0.; alswvisdif = 0.; alswnirdir = 0.; alswnirdif = 0.
+   sfphys = 2
    CLOSE(11)
    rho3d = 1.; dz8w = 100.; xlat = 0.; xlong = 0.; xland = 1.; xice = 0.; snow = 0.
+   IF (ssib == 1) THEN   ! SSiB land surface: spectral albedos derived from the broadband one, water in every 3rd column
+      sfphys = 8
+      alswvisdir = 0.5 * albedo; alswvisdif = 0.6 * albedo; alswnirdir = 1.4 * albedo; alswnirdif = 1.5 * albedo
+      xland(ims:ime:3, :) = 2.
+   END IF
    re_c = 0.; re_i = 0.; re_s = 0.
    rthratensw = -7777.; gsw = -7777.; swcf = -7777.; coszr = -7777.
    NULLIFY(tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw)
@@ -80,7 +91,8 @@ PROGRAM plumbing_sw
         CLDFRA3D=cldfra3d, QC3D=qc3d, QR3D=qr3d, QI3D=qi3d, QS3D=qs3d, &
         F_QV=.TRUE., F_QC=.TRUE., F_QR=.TRUE., F_QI=.TRUE., F_QS=.TRUE., F_QG=.FALSE., &
         XLAND=xland, XICE=xice, SNOW=snow,                            &
-        QV3D=qv3d, AER_OPT=aeropt, AEROD=aerod, NO_SRC=6, sf_surface_physics=2, &
+        QV3D=qv3d, AER_OPT=aeropt, AEROD=aerod, NO_SRC=6, sf_surface_physics=sfphys, &
+        ALSWVISDIR=alswvisdir, ALSWVISDIF=alswvisdif, ALSWNIRDIR=alswnirdir, ALSWNIRDIF=alswnirdif, &
         TAUAER300=tauaer300, TAUAER400=tauaer400,                     &
         TAUAER600=tauaer600, TAUAER999=tauaer999,                     &
         GAER300=gaer300, GAER400=gaer400, GAER600=gaer600, GAER999=gaer999, &

@@ -90,6 +90,29 @@ def test_shim_plumbing_4x4x40(hip_lib, sw_oracle, wa, tmp_path, fflags, dt, rtol
 
 
 @pytest.mark.gpu
+def test_shim_ssib_albedos(hip_lib, sw_oracle, wa, tmp_path):
+    """sf_surface_physics = 8 through the Fortran interface: the four spectral albedos where xland < 1.5."""
+    from helpers import AER, IN2, IN3, alloc_outputs, dims_of
+    from oracle import oracle as orc
+    exe = build_driver(hip_lib, "-O1 -fdefault-real-8")
+    st = wa.synth.make_wrf_state(4, 4, 40, seed=20260000, night_fraction=0.2)
+    wa.synth.write_sw_data(str(tmp_path / "RRTMG_SW_DATA_DBL"), seed=20260001, real_bytes=8)
+    write_state(tmp_path / "in.bin", st, 1001, "<f8")
+    r = subprocess.run([exe, "in.bin", "out.bin"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = read_out(tmp_path / "out.bin", st, "<f8")
+    arrays = {n: st.a2[n] for n in IN2}
+    arrays.update({n: st.a3[n] for n in IN3 + AER})
+    alb = st.a2["albedo"]
+    xland = np.ones_like(alb)
+    xland[:, ::3] = 2.0                                   # Fortran xland(ims:ime:3, :) = 2.
+    arrays.update(xland=xland, alswvisdir=0.5 * alb, alswvisdif=0.6 * alb, alswnirdir=1.4 * alb, alswnirdif=1.5 * alb)
+    ref = alloc_outputs(st)
+    orc.swrad_tile(sw_oracle, dims_of(st), arrays, 1370.0, 1, 1, ref)
+    compare_sw(got, ref, 1e-9, 1e-9, names=[n for n in got if n in ref])
+
+
+@pytest.mark.gpu
 def test_shim_aer_opt_1(hip_lib, sw_oracle, wa, tmp_path):
     """aer_opt = 1 through the Fortran interface: aerod(ims:ime,kms:kme,jms:jme,1:6) replaces the other aerosol
     inputs (iaer = 6)."""
