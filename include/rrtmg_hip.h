@@ -91,7 +91,9 @@ typedef struct rrtmg_hip_swrad_args {
     const void *xland, *xice, *snow;                       /* 2-D */
     int has_reqc, has_reqi, has_reqs;
     int warm_rain, progn;
-    int is_cammgmp_used, f_ice_phy, mp_physics;            /* CAM-MG radii and the Ferrier/HWRF splits are refused */
+    int is_cammgmp_used;                                   /* radii from lradius / iradius (below) */
+    int f_ice_phy;                                         /* 1: F_ICE_PHY present with F_QC, F_QS and no F_QI ("MP option 5") */
+    int mp_physics;                                        /* FER_MP_HIRES (5) / _ADVECT (15): qi3d = all frozen water */
     double g;                                              /* gravity the driver passes (G), m s-2 */
     /* band-resolved aerosol input of aer_opt = 2 / 3 (Fortran pointers tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw,
      * (ims:ime, kms:kme, jms:jme, 1:14), SW:10982-10991): NULL = not associated.  Where the WRF-Chem arrays
@@ -105,6 +107,9 @@ typedef struct rrtmg_hip_swrad_args {
     /* SSiB land surface (sf_surface_physics = 8, SW:10692-10703): spectral albedos (2-D) used where xland < 1.5;
      * the four together or none.  NULL = the broadband albedo everywhere.  xland is then read whatever icloud. */
     const void *alswvisdir, *alswvisdif, *alswnirdir, *alswnirdif;
+    /* is_cammgmp_used: effective radii from the CAM-MG microphysics, lradius / iradius(ims:ime,kms:kme,jms:jme) in
+     * um (SW:10883-10898); required when is_cammgmp_used /= 0. */
+    const void *lradius, *iradius;
 } rrtmg_hip_swrad_args;
 
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);
@@ -211,8 +216,9 @@ typedef struct rrtmg_hip_lwrad_args {
     const void *xland, *xice, *snow;
     int has_reqc, has_reqi, has_reqs;
     int warm_rain, progn;
-    int is_cammgmp_used, f_ice_phy, mp_physics;
+    int is_cammgmp_used, f_ice_phy, mp_physics;            /* as in rrtmg_hip_swrad_args */
     double g;
+    const void *lradius, *iradius;                         /* CAM-MG effective radii (um), LW:12473-12488 */
 } rrtmg_hip_lwrad_args;
 
 int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *args, char *err);

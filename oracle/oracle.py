@@ -137,7 +137,8 @@ class SwTileIn(C.Structure):
                 + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
                 + [("g", C.c_double), ("seed_real4", C.c_int)]
                 + [(n, dp) for n in ("tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw", "aerod",
-                                     "alswvisdir", "alswvisdif", "alswnirdir", "alswnirdif")])
+                                     "alswvisdir", "alswvisdif", "alswnirdir", "alswnirdif")]
+                + [("f_ice_phy", C.c_int), ("fer_hires", C.c_int), ("iradius", dp), ("lradius", dp)])
 
 
 SW_TILE_OUT = ["rthratensw", "gsw", "swcf", "coszr",
@@ -180,8 +181,9 @@ def swrad_tile(orc: "SwOracle", dims: dict, arrays: dict, solcon, aer_ra_feedbac
     ti.clean_atm_diag = int(clean_atm_diag)
     ti.g = 9.81
     if cloud:
-        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4"):
+        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4", "f_ice_phy"):
             setattr(ti, n, int(cloud.get(n, 0)))
+        ti.fer_hires = int(cloud.get("mp_physics", 0) in (5, 15))
         ti.g = float(cloud.get("g", 9.81))
     to = SwTileOut()
     for n in SW_TILE_OUT:

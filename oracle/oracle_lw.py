@@ -34,7 +34,8 @@ class LwTileIn(C.Structure):
                 + [("icloud", C.c_int)]
                 + [(n, dp) for n in CLOUD3 + CLOUD2]
                 + [(n, C.c_int) for n in ("has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn")]
-                + [("g", C.c_double), ("seed_real4", C.c_int)])
+                + [("g", C.c_double), ("seed_real4", C.c_int)]
+                + [("f_ice_phy", C.c_int), ("fer_hires", C.c_int), ("iradius", dp), ("lradius", dp)])
 
 
 LW_TILE_OUT = ["rthratenlw", "glw", "olr", "lwcf",
@@ -132,10 +133,11 @@ def lwrad_tile(orc: LwOracle, dims: dict, nlay: int, arrays: dict, aer_ra_feedba
     ti.clean_atm_diag = int(clean_atm_diag)
     ti.g = 9.81
     if cloud:
-        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4"):
+        for n in ("icloud", "has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "seed_real4", "f_ice_phy"):
             setattr(ti, n, int(cloud.get(n, 0)))
+        ti.fer_hires = int(cloud.get("mp_physics", 0) in (5, 15))
         ti.g = float(cloud.get("g", 9.81))
-        for n in CLOUD3 + CLOUD2:
+        for n in CLOUD3 + CLOUD2 + ["iradius", "lradius"]:
             if arrays.get(n) is not None:
                 a = np.ascontiguousarray(arrays[n], dtype=np.float64)
                 keep.append(a)

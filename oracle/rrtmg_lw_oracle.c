@@ -1338,6 +1338,16 @@ int lw_oracle_lwrad_tile(const LwTables *t, const LwTileIn *in, LwTileOut *out, 
                                      in->has_reqc, in->has_reqi, in->has_reqs, in->warm_rain, in->progn,
                                      in->xland ? in->xland[I2(i, j)] : 1., in->xice ? in->xice[I2(i, j)] : 0.,
                                      in->snow ? in->snow[I2(i, j)] : 0., in->g};
+                    double crad[2][MAXLAY];
+                    cw.f_ice_phy = in->f_ice_phy; cw.fer_hires = in->fer_hires;
+                    cw.iradius = NULL; cw.lradius = NULL;
+                    if (in->iradius && in->lradius) {
+                        for (int k = 0; k < nk; ++k) {
+                            crad[0][k] = in->iradius[I3(i, in->kts + k, j)];
+                            crad[1][k] = in->lradius[I3(i, in->kts + k, j)];
+                        }
+                        cw.iradius = crad[0]; cw.lradius = crad[1];
+                    }
                 int fl[3];
                 if (oracle_cloud_state(&cw, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], fl)) { rc = 1; break; }
                 for (int k = nk; k < nlayers; ++k) {   /* LW:12543-12553 */

@@ -83,6 +83,10 @@ typedef struct {
     const double *qndrop;                         /* droplet number (1/kg), used with progn = 1 */
     int has_reqc, has_reqi, has_reqs, warm_rain, progn;
     double xland, xice, snow, g;
+    /* variants: "MP option 5" split of snow (SW:10461-10472), Ferrier-Aligo (SW:10474-10492), CAM-MG radii in um
+     * (SW:10883-10898; both arrays or NULL) */
+    int f_ice_phy, fer_hires;
+    const double *iradius, *lradius;
 } OracleCloudWrf;
 int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, double *ciwp, double *cswp,
                        double *rel, double *rei, double *res, int *flags3);
@@ -135,6 +139,8 @@ typedef struct {
     const double *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   /* (i,k,j,band), optional (SW:10982-10991) */
     const double *aerod;                                     /* (i,k,j,6), optional: aer_opt = 1 (SW:11083-11100) */
     const double *alswvisdir, *alswvisdif, *alswnirdir, *alswnirdif;   /* SSiB albedos (2-D), optional (SW:10692-10703) */
+    int f_ice_phy, fer_hires;                                /* cloud variants, see OracleCloudWrf */
+    const double *iradius, *lradius;                         /* 3-D, CAM-MG radii */
 } SwTileIn;
 
 /* iaer = 6: band optical properties of the mixture of the six ECMWF aerosol types, SW:9313-9340.
@@ -215,6 +221,8 @@ typedef struct {
     int has_reqc, has_reqi, has_reqs, warm_rain, progn;
     double g;
     int seed_real4;
+    int f_ice_phy, fer_hires;                                /* cloud variants, see OracleCloudWrf */
+    const double *iradius, *lradius;                         /* 3-D, CAM-MG radii */
 } LwTileIn;
 
 typedef struct {

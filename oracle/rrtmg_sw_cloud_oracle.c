@@ -248,6 +248,13 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
             if (w->t[k] < 273.15) { qi1d[k] = qc1d[k]; qs1d[k] = qr1d[k]; qc1d[k] = 0.; qr1d[k] = 0.; }
     if (w->qi) for (int k = 0; k < nk; ++k) qi1d[k] = fmax(0., w->qi[k]);
     if (w->qs) for (int k = 0; k < nk; ++k) qs1d[k] = fmax(0., w->qs[k]);
+    if (w->f_ice_phy)   /* "MP option 5", SW:10461-10472 (LW:12003-12014) */
+        for (int k = 0; k < nk; ++k) {
+            const double s3 = w->qs ? w->qs[k] : 0.;
+            qi1d[k] = fmax(0., 0.1 * s3); qs1d[k] = 0.9 * s3;
+        }
+    if (w->fer_hires)   /* qi3d saves all frozen water, SW:10474-10492 (LW:12016-12034) */
+        for (int k = 0; k < nk; ++k) { qi1d[k] = w->qi ? fmax(0., w->qi[k]) : 0.; qs1d[k] = 0.0; }
     int inflg = 2, iceflg = 3, liqflg = 1;
     for (int k = 0; k < nk; ++k) {
         const double cf3 = w->cldfra ? w->cldfra[k] : 0.;
@@ -324,6 +331,12 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
         if (inflg >= 3) reliq = recloud1d[k];
         if (iceflg >= 4) reice = reice1d[k];
         if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+        if (w->iradius) {   /* CAM-MG microphysics supplies the radii, SW:10883-10898 (LW:12473-12488) */
+            reice = (qi1d[k] > 1.e-20 || qs1d[k] > 1.e-20) ? w->iradius[k] : 25.;
+            reice = fmax(5., fmin(140.0, reice));
+            reliq = qc1d[k] > 1.e-20 ? w->lradius[k] : 10.;
+            reliq = fmax(2.5, fmin(60.0, reliq));
+        }
         clwp[k] = cliqwp; ciwp[k] = cicewp; rel[k] = reliq; rei[k] = reice;
         if (inflg == 5) { cswp[k] = csnowp; res[k] = resnow1d[k]; }
         else { cswp[k] = 0.0; res[k] = 10.0; }

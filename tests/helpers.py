@@ -43,6 +43,7 @@ def cloud_arrays(st, cloud):
     need = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d"]
     need += ["re_cloud"] * bool(cloud.get("has_reqc")) + ["re_ice"] * bool(cloud.get("has_reqi"))
     need += ["re_snow"] * bool(cloud.get("has_reqs")) + ["qndrop3d"] * (cloud.get("progn") == 1)
+    need += ["lradius", "iradius"] * bool(cloud.get("is_cammgmp_used"))
     arr = {n: st.a3[n] for n in need if n in st.a3 and n not in cloud.get("absent", ())}
     arr.update({n: st.a2[n] for n in CLD2})
     return arr

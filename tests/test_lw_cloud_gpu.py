@@ -82,7 +82,7 @@ def test_lw_cloud_refusals_and_fatal_sizes(hip_lib, wa, lw_table_file):
     eng, nlay = _init(wa, lw_table_file, 30)
     st = wa.synth.make_wrf_state(3, 2, 30, seed=20260540)
     cloud = wa.synth_clouds.add_clouds(st, seed=20260541, cloudy_fraction=1.0, with_radii=True)
-    with pytest.raises(wa.engine.WrfFatal, match="CAM-MG"):
+    with pytest.raises(wa.engine.WrfFatal, match="lradius and iradius"):
         run_hip_lwrad(eng, st, cloud=dict(cloud, is_cammgmp_used=True))
     with pytest.raises(wa.engine.WrfFatal, match="cldfra3d"):
         run_hip_lwrad(eng, st, cloud=dict(cloud, absent=("cldfra3d",)))
@@ -127,3 +127,27 @@ def test_cloudy_lw_full_size_properties_200x200x40(hip_lib, wa, lw_table_file):
     got2 = run_hip_lwrad(eng, st, cloud=cloud, profiles=False)
     for n in ("lwupt", "lwdnb", "lwuptcln", "lwcf"):
         np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)
+
+
+@pytest.mark.parametrize("variant", ["f_ice_phy", "fer_hires", "cammgmp"])
+def test_lw_cloud_microphysics_variants(hip_lib, wa, lw_table_file, lw_oracle, variant):
+    """The hydrometeor variants of the wrapper (LW:12003-12034, 12473-12488), as in the shortwave test."""
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(7, 5, 40, seed=20260460)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260461, cloudy_fraction=0.7)
+    rng = np.random.default_rng(20260462)
+    if variant == "f_ice_phy":
+        cloud.update(f_ice_phy=1, absent=("qi3d",))
+        st.a3["qs3d"] = st.a3["qs3d"] + st.a3["qi3d"]
+    elif variant == "fer_hires":
+        cloud.update(mp_physics=15)
+    else:
+        cloud.update(is_cammgmp_used=1)
+        st.a3["lradius"] = rng.uniform(1.0, 70.0, st.a3["qc3d"].shape)
+        st.a3["iradius"] = rng.uniform(2.0, 160.0, st.a3["qc3d"].shape)
+    got = run_hip_lwrad(eng, st, cloud=cloud)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, cloud=cloud)
+    assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+    plain = {k: v for k, v in cloud.items() if k not in ("f_ice_phy", "mp_physics", "is_cammgmp_used", "absent")}
+    base = run_hip_lwrad(eng, st, cloud=plain)
+    assert np.abs(got["lwupt"] - base["lwupt"]).max() > 1e-3

@@ -68,10 +68,10 @@ def test_cloud_refusals_and_fatal_sizes(hip_lib, wa, sw_table_file):
     eng = _init(wa, sw_table_file)
     st = wa.synth.make_wrf_state(3, 2, 30, seed=20260440)
     cloud = wa.synth_clouds.add_clouds(st, seed=20260441, cloudy_fraction=1.0, with_radii=True)
-    with pytest.raises(wa.engine.WrfFatal, match="CAM-MG"):
+    with pytest.raises(wa.engine.WrfFatal, match="lradius and iradius"):     # CAM-MG radii announced, not passed
         run_hip_swrad(eng, st, cloud=dict(cloud, is_cammgmp_used=True))
-    with pytest.raises(wa.engine.WrfFatal, match="Ferrier"):
-        run_hip_swrad(eng, st, cloud=dict(cloud, mp_physics=5))
+    with pytest.raises(wa.engine.WrfFatal, match="FER_MP_HIRES needs qi3d"):
+        run_hip_swrad(eng, st, cloud=dict(cloud, mp_physics=5, absent=("qi3d",)))
     with pytest.raises(wa.engine.WrfFatal, match="cldfra3d"):
         run_hip_swrad(eng, st, cloud=dict(cloud, absent=("cldfra3d",)))
     # a microphysics ice radius beyond the Fu table is fatal in cldprmc_sw (SW:2168-2173)
@@ -116,3 +116,30 @@ def test_cloudy_full_size_properties_200x200x40(hip_lib, wa, sw_table_file):
     got2 = run_hip_swrad(eng, st, cloud=cloud, profiles=False)
     for n in ("swupt", "swdnb", "swuptcln", "swcf"):
         np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)
+
+
+@pytest.mark.parametrize("variant", ["f_ice_phy", "fer_hires", "cammgmp"])
+def test_cloud_microphysics_variants(hip_lib, wa, sw_table_file, sw_oracle, variant):
+    """The hydrometeor variants of the wrapper (SW:10461-10492, 10883-10898): "MP option 5" (snow carried alone and
+    split 10/90 into ice and snow), Ferrier-Aligo (qi3d = all frozen water) and CAM-MG (effective radii supplied).
+    HIP against the oracle's restatement of the same lines."""
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(7, 5, 40, seed=20260450, night_fraction=0.1)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260451, cloudy_fraction=0.7)
+    rng = np.random.default_rng(20260452)
+    if variant == "f_ice_phy":
+        cloud.update(f_ice_phy=1, absent=("qi3d",))                  # F_QC, F_QS, no F_QI
+        st.a3["qs3d"] = st.a3["qs3d"] + st.a3["qi3d"]
+    elif variant == "fer_hires":
+        cloud.update(mp_physics=5)
+    else:
+        cloud.update(is_cammgmp_used=1)
+        st.a3["lradius"] = rng.uniform(1.0, 70.0, st.a3["qc3d"].shape)   # beyond both clamps
+        st.a3["iradius"] = rng.uniform(2.0, 160.0, st.a3["qc3d"].shape)
+    got = run_hip_swrad(eng, st, cloud=cloud)
+    ref = run_oracle_swrad(sw_oracle, st, cloud=cloud)
+    assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+    plain = {k: v for k, v in cloud.items() if k not in ("f_ice_phy", "mp_physics", "is_cammgmp_used", "absent")}
+    base = run_hip_swrad(eng, st, cloud=plain)
+    day = st.a2["xcoszen"] > 0
+    assert np.abs(got["swupt"] - base["swupt"])[day].max() > 1e-3     # the variant matters

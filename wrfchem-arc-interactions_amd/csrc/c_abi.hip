@@ -195,10 +195,11 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     if (!st.ready) return fail(err, "rrtmg_hip_swrad: rrtmg_hip_sw_init has not been called");
     if (a->real_bytes != 4 && a->real_bytes != 8) return fail(err, "rrtmg_hip_swrad: real_bytes must be 4 or 8");
     if (a->icloud != 0) {
-        if (a->is_cammgmp_used)
-            return fail(err, "rrtmg_hip_swrad: is_cammgmp_used (CAM-MG effective radii) is not implemented");
-        if (a->f_ice_phy || a->mp_physics == 5 || a->mp_physics == 15)
-            return fail(err, "rrtmg_hip_swrad: the Ferrier / HWRF hydrometeor splits (F_ICE_PHY, FER_MP_HIRES) are not implemented");
+        if (a->is_cammgmp_used && !(a->lradius && a->iradius))
+            return fail(err, "rrtmg_hip_swrad: is_cammgmp_used needs lradius and iradius");
+        if ((a->mp_physics == 5 || a->mp_physics == 15) && !a->qi3d)
+            return fail(err, "rrtmg_hip_swrad: FER_MP_HIRES needs qi3d");
+        if (a->f_ice_phy && !a->qs3d) return fail(err, "rrtmg_hip_swrad: the F_ICE_PHY split needs qs3d");
         if (!a->cldfra3d) return fail(err, "rrtmg_hip_swrad: icloud /= 0 needs cldfra3d");
         if ((a->has_reqc && !a->re_cloud) || (a->has_reqi && !a->re_ice) || (a->has_reqs && !a->re_snow))
             return fail(err, "rrtmg_hip_swrad: has_reqc/has_reqi/has_reqs set without re_cloud/re_ice/re_snow");
@@ -239,6 +240,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         if (nk + 1 < 4) return fail(err, "rrtmg_hip_swrad: the McICA seeds need at least four layers");
         k.has_reqc = a->has_reqc; k.has_reqi = a->has_reqi; k.has_reqs = a->has_reqs;
         k.warm_rain = a->warm_rain; k.progn = a->progn; k.grav = a->g;
+        k.f_ice_phy = a->f_ice_phy; k.fer_hires = (a->mp_physics == 5 || a->mp_physics == 15) ? 1 : 0;
         k.cldtab = static_cast<const double *>(st.dCld);
         // KISS jump table of this layer count (permuteseed = 1, SW:10952), built once per nlay
         std::lock_guard<std::mutex> lock(st.jump_mutex);
@@ -285,6 +287,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             k.re_snow = a->has_reqs ? a->re_snow : nullptr;
             k.qndrop3d = a->progn == 1 ? a->qndrop3d : nullptr;
             k.xland = a->xland; k.xice = a->xice; k.snow = a->snow;
+            if (a->is_cammgmp_used) { k.iradius = a->iradius; k.lradius = a->lradius; }
         }
     } else {
 #define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
@@ -318,6 +321,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             if (a->has_reqs) IN3(re_snow);
             if (a->progn == 1) IN3(qndrop3d);
             IN2(xland); IN2(xice); IN2(snow);
+            if (a->is_cammgmp_used) { IN3(iradius); IN3(lradius); }
         }
         OUT(rthratensw, n3); OUT(coszr, n2); OUT(gsw, n2); OUT(swcf, n2);
         OUT(swupt, n2); OUT(swuptc, n2); OUT(swuptcln, n2); OUT(swdnt, n2); OUT(swdntc, n2); OUT(swdntcln, n2);

@@ -189,10 +189,11 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     if (!st.ready) return failw(err, "rrtmg_hip_lwrad: rrtmg_hip_lw_init has not been called");
     if (a->real_bytes != 4 && a->real_bytes != 8) return failw(err, "rrtmg_hip_lwrad: real_bytes must be 4 or 8");
     if (a->icloud != 0) {
-        if (a->is_cammgmp_used)
-            return failw(err, "rrtmg_hip_lwrad: is_cammgmp_used (CAM-MG effective radii) is not implemented");
-        if (a->f_ice_phy || a->mp_physics == 5 || a->mp_physics == 15)
-            return failw(err, "rrtmg_hip_lwrad: the Ferrier / HWRF hydrometeor splits (F_ICE_PHY, FER_MP_HIRES) are not implemented");
+        if (a->is_cammgmp_used && !(a->lradius && a->iradius))
+            return failw(err, "rrtmg_hip_lwrad: is_cammgmp_used needs lradius and iradius");
+        if ((a->mp_physics == 5 || a->mp_physics == 15) && !a->qi3d)
+            return failw(err, "rrtmg_hip_lwrad: FER_MP_HIRES needs qi3d");
+        if (a->f_ice_phy && !a->qs3d) return failw(err, "rrtmg_hip_lwrad: the F_ICE_PHY split needs qs3d");
         if (!a->cldfra3d) return failw(err, "rrtmg_hip_lwrad: icloud /= 0 needs cldfra3d");
         if ((a->has_reqc && !a->re_cloud) || (a->has_reqi && !a->re_ice) || (a->has_reqs && !a->re_snow))
             return failw(err, "rrtmg_hip_lwrad: has_reqc/has_reqi/has_reqs set without re_cloud/re_ice/re_snow");
@@ -230,6 +231,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         if (nk < 4) return failw(err, "rrtmg_hip_lwrad: the McICA seeds need at least four layers");
         k.has_reqc = a->has_reqc; k.has_reqi = a->has_reqi; k.has_reqs = a->has_reqs;
         k.warm_rain = a->warm_rain; k.progn = a->progn; k.grav = a->g;
+        k.f_ice_phy = a->f_ice_phy; k.fer_hires = (a->mp_physics == 5 || a->mp_physics == 15) ? 1 : 0;
         k.cldtab = static_cast<const double *>(st.dCld);
         // KISS jump table: NLAYERS draws per sub-column, permuteseed = 150 (LW:12555)
         std::lock_guard<std::mutex> lock(st.scratch_mutex);
@@ -262,6 +264,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             k.re_snow = a->has_reqs ? a->re_snow : nullptr;
             k.qndrop3d = a->progn == 1 ? a->qndrop3d : nullptr;
             k.xland = a->xland; k.xice = a->xice; k.snow = a->snow;
+            if (a->is_cammgmp_used) { k.iradius = a->iradius; k.lradius = a->lradius; }
         }
     } else {
 #define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
@@ -282,6 +285,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             if (a->has_reqs) IN3(re_snow);
             if (a->progn == 1) IN3(qndrop3d);
             IN2(xland); IN2(xice); IN2(snow);
+            if (a->is_cammgmp_used) { IN3(iradius); IN3(lradius); }
         }
         OUT(rthratenlw, n3); OUT(glw, n2); OUT(olr, n2); OUT(lwcf, n2);
         OUT(lwupt, n2); OUT(lwuptc, n2); OUT(lwuptcln, n2); OUT(lwdnt, n2); OUT(lwdntc, n2); OUT(lwdntcln, n2);

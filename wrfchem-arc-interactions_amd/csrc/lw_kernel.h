@@ -26,6 +26,8 @@ struct LwKernelArgs {
     int col0;                           // first tile column of this batch
     // clouds (icloud != 0), as in SwKernelArgs
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    int f_ice_phy, fer_hires;            // "MP option 5" split of snow; Ferrier-Aligo (qi3d = all frozen water)
+    const void *iradius, *lradius;       // CAM-MG effective radii (um), both or none
     double grav;
     const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
     const uint32_t *jump;               // KISS jump table for NLAYERS draws per sub-column: [LW_NGPT][36]

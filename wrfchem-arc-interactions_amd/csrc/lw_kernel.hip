@@ -686,6 +686,13 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (!a.qi3d && !a.warm_rain && t1d < 273.15) { qi = qc; qs = qr; qc = 0.; qr = 0.; }
                 if (a.qi3d) qi = fmax(0., ldr(a.qi3d, q, r4));
                 if (a.qs3d) qs = fmax(0., ldr(a.qs3d, q, r4));
+                if (a.f_ice_phy) {        // "MP option 5": one frozen species carried as snow, LW:12003-12014
+                    const double s3 = a.qs3d ? ldr(a.qs3d, q, r4) : 0.;
+                    qi = fmax(0., 0.1 * s3); qs = 0.9 * s3;
+                }
+                if (a.fer_hires) {        // Ferrier-Aligo: qi3d holds all frozen water, LW:12016-12034
+                    qi = a.qi3d ? fmax(0., ldr(a.qi3d, q, r4)) : 0.; qs = 0.0;
+                }
                 cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
                 const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;
                 int inflg = 2;
@@ -761,6 +768,12 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (inflg >= 3) reliq = recloud;
                 if (iceflg >= 4) reice = reice1;
                 if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+                if (a.iradius) {          // CAM-MG microphysics supplies the radii, LW:12473-12488
+                    reice = (qi > 1.e-20 || qs > 1.e-20) ? ldr(a.iradius, q, r4) : 25.;
+                    reice = fmax(5., fmin(140.0, reice));
+                    reliq = qc > 1.e-20 ? ldr(a.lradius, q, r4) : 10.;
+                    reliq = fmax(2.5, fmin(60.0, reliq));
+                }
                 if (inflg == 5) resno = resnow1; else { cswp = 0.0; resno = 10.0; }
             }
             double *cb = rec + lw_rec_base_doubles(nl);

@@ -26,6 +26,8 @@ struct SwKernelArgs {
                                          // 1 ice size, 2 snow size, 3 liquid radius out of bounds (cldprmc_sw)
     // clouds (icloud != 0)
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
+    int f_ice_phy, fer_hires;            // "MP option 5" split of snow; Ferrier-Aligo (qi3d = all frozen water)
+    const void *iradius, *lradius;       // CAM-MG effective radii (um), both or none
     double grav;
     const void *cldfra3d, *qc3d, *qr3d, *qi3d, *qs3d, *re_cloud, *re_ice, *re_snow, *qndrop3d, *xland, *xice, *snow;
     const void *tauaer3d_sw, *ssaaer3d_sw, *asyaer3d_sw;   // (i,k,j,band) band-resolved aerosol input, optional

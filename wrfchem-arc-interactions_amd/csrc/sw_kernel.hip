@@ -622,6 +622,13 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     if (!a.qi3d && !a.warm_rain && tavel < 273.15) { qi = qc; qs = qr; qc = 0.; qr = 0.; }
                     if (a.qi3d) qi = fmax(0., ldr(a.qi3d, q, r4));
                     if (a.qs3d) qs = fmax(0., ldr(a.qs3d, q, r4));
+                    if (a.f_ice_phy) {        // "MP option 5": one frozen species carried as snow, SW:10461-10472
+                        const double s3 = a.qs3d ? ldr(a.qs3d, q, r4) : 0.;
+                        qi = fmax(0., 0.1 * s3); qs = 0.9 * s3;
+                    }
+                    if (a.fer_hires) {        // Ferrier-Aligo: qi3d holds all frozen water, SW:10474-10492
+                        qi = a.qi3d ? fmax(0., ldr(a.qi3d, q, r4)) : 0.; qs = 0.0;
+                    }
                     cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
                     const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;
                     int iceflg = 3, inflg = 2;
@@ -697,6 +704,12 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     if (inflg >= 3) reliq = recloud;
                     if (iceflg >= 4) reice = reice1;
                     if (iceflg == 3) { reice = reice * 1.0315; reice = fmin(140.0, reice); }
+                    if (a.iradius) {          // CAM-MG microphysics supplies the radii, SW:10883-10898
+                        reice = (qi > 1.e-20 || qs > 1.e-20) ? ldr(a.iradius, q, r4) : 25.;
+                        reice = fmax(5., fmin(140.0, reice));
+                        reliq = qc > 1.e-20 ? ldr(a.lradius, q, r4) : 10.;
+                        reliq = fmax(2.5, fmin(60.0, reliq));
+                    }
                     if (inflg == 5) resno = resnow1; else { cswp = 0.0; resno = 10.0; }
                 }
                 c.cldf[k] = cf < 1.0e-20 ? 0. : cf;   // generate_stochastic_clouds_sw, SW:1677-1684

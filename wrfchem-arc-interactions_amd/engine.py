@@ -47,6 +47,7 @@ _CLDFLAGS = ["has_reqc", "has_reqi", "has_reqs", "warm_rain", "progn", "is_cammg
 _AER4 = ["tauaer3d_sw", "ssaaer3d_sw", "asyaer3d_sw"]   # (14, nj, nk_mem, ni) == Fortran (i,k,j,band)
 _AEROD = ["aerod"]                                      # (6, nj, nk_mem, ni) == Fortran (i,k,j,type), aer_opt = 1
 _SSIB = ["alswvisdir", "alswvisdif", "alswnirdir", "alswnirdif"]   # 2-D spectral albedos of sf_surface_physics = 8
+_CAMRAD = ["lradius", "iradius"]                        # 3-D effective radii (um) of the CAM-MG microphysics
 
 
 class SwradArgs(C.Structure):
@@ -58,7 +59,7 @@ class SwradArgs(C.Structure):
                 + [(n, C.c_void_p) for n in _CLD3 + _CLD2]
                 + [(n, C.c_int) for n in _CLDFLAGS]
                 + [("g", C.c_double)]
-                + [(n, C.c_void_p) for n in _AER4 + _AEROD + _SSIB])
+                + [(n, C.c_void_p) for n in _AER4 + _AEROD + _SSIB + _CAMRAD])
 
 
 _lib = None
@@ -144,7 +145,7 @@ def rrtmg_swrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
                      is_cammgmp_used=is_cammgmp_used, f_ice_phy=f_ice_phy, mp_physics=mp_physics).items():
         setattr(a, n, int(v))
     a.g = float(g)
-    known = set(_IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F + _CLD3 + _CLD2 + _AER4 + _AEROD + _SSIB)
+    known = set(_IN2 + _IN3 + _OUT3 + _OUT2 + _OUT3F + _CLD3 + _CLD2 + _AER4 + _AEROD + _SSIB + _CAMRAD)
     unknown = set(arrays) - known
     if unknown:
         raise TypeError(f"unknown RRTMG_SWRAD arguments: {sorted(unknown)}")

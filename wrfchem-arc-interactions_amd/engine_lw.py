@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from .engine import CP, ERRLEN, WrfFatal, _CLD2, _CLD3, _CLDFLAGS, _check, _ptr, load_library
+from .engine import CP, ERRLEN, WrfFatal, _CAMRAD, _CLD2, _CLD3, _CLDFLAGS, _check, _ptr, load_library
 
 _IN2 = ["emiss", "tsk"]
 _IN3 = ["t3d", "t8w", "p3d", "p8w", "pi3d", "qv3d", "o33d"]
@@ -28,7 +28,8 @@ class LwradArgs(C.Structure):
                 + [(n, C.c_void_p) for n in _OUT]
                 + [(n, C.c_void_p) for n in _CLD3 + _CLD2]
                 + [(n, C.c_int) for n in _CLDFLAGS]
-                + [("g", C.c_double)])
+                + [("g", C.c_double)]
+                + [(n, C.c_void_p) for n in _CAMRAD])
 
 
 EXPORTS_LW = ["rrtmg_hip_lw_init", "rrtmg_hip_lw_nlayers", "rrtmg_hip_lwrad", "rrtmg_hip_lw_status",
@@ -80,7 +81,7 @@ def rrtmg_lwrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
                      is_cammgmp_used=is_cammgmp_used, f_ice_phy=f_ice_phy, mp_physics=mp_physics).items():
         setattr(a, n, int(v))
     a.g = float(g)
-    known = set(_IN2 + _IN3 + _AER + _OUT + _CLD3 + _CLD2)
+    known = set(_IN2 + _IN3 + _AER + _OUT + _CLD3 + _CLD2 + _CAMRAD)
     unknown = set(arrays) - known
     if unknown:
         raise TypeError(f"unknown RRTMG_LWRAD arguments: {sorted(unknown)}")

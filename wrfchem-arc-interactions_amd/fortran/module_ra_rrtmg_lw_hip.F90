@@ -67,6 +67,7 @@ MODULE module_ra_rrtmg_lw
       INTEGER(c_int) :: warm_rain, progn
       INTEGER(c_int) :: is_cammgmp_used, f_ice_phy, mp_physics
       REAL(c_double) :: g
+      TYPE(c_ptr) :: lradius, iradius
    END TYPE lwrad_args
 
    INTERFACE
@@ -226,6 +227,12 @@ CONTAINS
       a%progn = 0
       IF (PRESENT(progn)) a%progn = progn
       a%is_cammgmp_used = MERGE(1, 0, is_cammgmp_used)
+      a%lradius = c_null_ptr; a%iradius = c_null_ptr
+      IF (is_cammgmp_used) THEN   ! effective radii from the CAM-MG microphysics
+         IF (.NOT. (PRESENT(lradius) .AND. PRESENT(iradius))) CALL wrf_error_fatal( &
+            'rrtmg (HIP): is_cammgmp_used needs lradius and iradius')
+         a%lradius = c_loc(lradius); a%iradius = c_loc(iradius)
+      END IF
       a%f_ice_phy = 0
       IF (PRESENT(f_ice_phy) .AND. PRESENT(f_qc) .AND. PRESENT(f_qi) .AND. PRESENT(f_qs)) THEN
          IF (f_qc .AND. .NOT. f_qi .AND. f_qs) a%f_ice_phy = 1

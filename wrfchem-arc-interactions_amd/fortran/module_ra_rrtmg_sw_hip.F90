@@ -58,6 +58,7 @@ MODULE module_ra_rrtmg_sw
       TYPE(c_ptr) :: tauaer3d_sw, ssaaer3d_sw, asyaer3d_sw
       TYPE(c_ptr) :: aerod
       TYPE(c_ptr) :: alswvisdir, alswvisdif, alswnirdir, alswnirdif
+      TYPE(c_ptr) :: lradius, iradius
    END TYPE swrad_args
 
    INTERFACE
@@ -269,6 +270,12 @@ CONTAINS
       a%progn = 0
       IF (PRESENT(progn)) a%progn = progn
       a%is_cammgmp_used = MERGE(1, 0, is_cammgmp_used)
+      a%lradius = c_null_ptr; a%iradius = c_null_ptr
+      IF (is_cammgmp_used) THEN   ! effective radii from the CAM-MG microphysics
+         IF (.NOT. (PRESENT(lradius) .AND. PRESENT(iradius))) CALL wrf_error_fatal( &
+            'rrtmg (HIP): is_cammgmp_used needs lradius and iradius')
+         a%lradius = c_loc(lradius); a%iradius = c_loc(iradius)
+      END IF
       ! the Ferrier-type split of snow into ice (SW:10438-10450) needs F_ICE_PHY with F_QC, F_QS and no F_QI
       a%f_ice_phy = 0
       IF (PRESENT(f_ice_phy) .AND. PRESENT(f_qc) .AND. PRESENT(f_qi) .AND. PRESENT(f_qs)) THEN
