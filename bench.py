@@ -313,11 +313,17 @@ def main():
         dom_name, dom_ms, dom_bpc = max(cand, key=lambda c: c[1])
         achieved = ncol * dom_bpc / (dom_ms * 1e-3) / 1e9
         traffic = None
+        valu = {}
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
+                kd = tj.get("kernels", {}).get(dom_name, {})
+                if kd.get("valu_issue_frac") is not None:   # what actually binds this kernel
+                    valu = {"fp64_valu_issue_frac": kd["valu_issue_frac"],
+                            "valu_wave_instructions": kd["valu_wave_instructions"],
+                            "source": tj.get("source")}
                 if traffic is None and dom_name == "sw_column_kernel":
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
@@ -354,6 +360,7 @@ def main():
                          "optics_stage_ms": opt_ms, "optics_kernel_ms": opt_part_ms.get("sw", 0.0),
                          "optics_lw_kernel_ms": opt_part_ms.get("lw", 0.0), "optics_algorithmic_bytes_per_column": obpc,
                          "step_algorithmic_GBs": ncol * (bpc + obpc) / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
+                         "valu": valu,
                          "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
         }
         if world == 1 and not args.no_cpu and args.clouds <= 0.0:

@@ -59,6 +59,8 @@ def main():
             peak = mean["GRBM_GUI_ACTIVE"] / 8 * 256 * 4 / 4
             lines.append(f"# VALU issue: {mean['SQ_INSTS_VALU']:.4g} wave-instructions / {peak:.4g} issue slots "
                          f"= {mean['SQ_INSTS_VALU'] / peak:.3f}")
+            traffic.setdefault(k.replace("rrtmg::", ""), {}).update(
+                valu_wave_instructions=mean["SQ_INSTS_VALU"], valu_issue_frac=mean["SQ_INSTS_VALU"] / peak)
     with open(os.path.join(root, f"{tag}_pmc.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     if traffic:
