@@ -280,6 +280,30 @@ typedef struct rrtmg_hip_optics_args {
 
 int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *args, char *err);
 int rrtmg_hip_optics_finalize(void);
+
+/* Modal aerosol (MADE/SORGAM type: log-normal modes with fixed geometric standard deviations) -> the sectional
+ * form above, so that rrtmg_hip_optical_averaging serves both tracer families (north_star: "MOSAIC/MADE size
+ * bins").  Per mode: number (#/kg) and species masses (ug/kg, slots as in RRTMG_HIP_AER_*; idx[m][s] 1-based into
+ * chem, 0 = not carried).  The mode's number-median diameter follows from number and dry volume; each section of
+ * rrtmg_hip_optics_init receives the log-normal's share of number and (volume-weighted) of every species mass, the
+ * end sections taking the tails (number and mass are conserved).  chem_sec(ims:ime, kms:kme, jms:jme, nbin*10):
+ * species s of section b at 1-based index b*10 + s + 1 = the table rrtmg_hip_modal_section_idx fills for
+ * rrtmg_hip_optics_args.idx (with num_chem = nbin*10).  The specification is the engine's own. */
+#define RRTMG_HIP_MAXMODE 4
+typedef struct rrtmg_hip_modal_args {
+    int ims, ime, jms, jme, kms, kme;
+    int its, ite, jts, jte, kts, kte;
+    int real_bytes;
+    int mem;
+    void *stream;
+    int nmode, num_chem;
+    double sigma[RRTMG_HIP_MAXMODE];                          /* MADE: 1.7 (Aitken), 2.0 (accumulation), 2.2 (coarse) */
+    int idx[RRTMG_HIP_MAXMODE][RRTMG_HIP_AER_NSPEC];
+    const void *chem;                                         /* (ims:ime, kms:kme, jms:jme, num_chem) */
+    void *chem_sec;                                           /* (ims:ime, kms:kme, jms:jme, nbin*10), output */
+} rrtmg_hip_modal_args;
+int rrtmg_hip_modal_to_sections(const rrtmg_hip_modal_args *args, char *err);
+int rrtmg_hip_modal_section_idx(int nbin, int *idx /* [RRTMG_HIP_MAXBIN][RRTMG_HIP_AER_NSPEC] */);
 /* host-only: wavelengths (um) of the 20 spectral points and the table the engine would use */
 int rrtmg_hip_optics_table_info(double *wavelength_um20, double *refindex_9x20x2, double *density9);
 

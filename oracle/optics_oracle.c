@@ -184,3 +184,42 @@ void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk
                     for (int f = 0; f < 2; ++f) lw2[((size_t)b * 2 + f) * n3 + q] = olw[b * 2 + f];
             }
 }
+
+/* Modal (MADE/SORGAM-type) aerosol -> sections: the specification of modal_sections.hip restated for one cell.
+ * mass[nmode][9] (ug/kg, species order of the optics), num[nmode] (#/kg), sigma[nmode] -> secmass[nbin][9],
+ * secnum[nbin].  Log-normal shares of number (around dgn) and of mass (around dgv = dgn exp(3 ln^2 sigma)); the end
+ * sections take the tails.  Parity unpinned (no reference arithmetic exists for this stage). */
+static double phi_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+
+void optics_oracle_modal_cell(const optics_oracle_tables *t, int nmode, const double *mass, const double *num,
+                              const double *sigma, double *secmass, double *secnum)
+{
+    const double pi = 3.14159265358979323846;
+    for (int b = 0; b < t->nbin; ++b) {
+        secnum[b] = 0.;
+        for (int s = 0; s < 9; ++s) secmass[b * 9 + s] = 0.;
+    }
+    for (int m = 0; m < nmode; ++m) {
+        double vdry = 0., mm[9];
+        for (int s = 0; s < 9; ++s) {
+            mm[s] = fmax(mass[m * 9 + s], 0.);
+            if (s != 8) vdry += mm[s] / t->dens[s];
+        }
+        const double n = fmax(num[m], 0.);
+        if (!(vdry > 1.e-25) || !(n > 0.)) continue;
+        const double ls = log(sigma[m]);
+        const double lndgn = log(1.e4 * cbrt(vdry * 1.e-6 / n * (6. / pi))) - 1.5 * ls * ls;
+        const double lndgv = lndgn + 3. * ls * ls;
+        const double rls = 1. / ls;
+        double cn_lo = 0., cv_lo = 0.;
+        for (int b = 0; b < t->nbin; ++b) {
+            const int last = b == t->nbin - 1;
+            const double cn_hi = last ? 1. : phi_cdf((log(t->dhi_um[b]) - lndgn) * rls);
+            const double cv_hi = last ? 1. : phi_cdf((log(t->dhi_um[b]) - lndgv) * rls);
+            const double fn = cn_hi - cn_lo, fv = cv_hi - cv_lo;
+            for (int s = 0; s < 9; ++s) secmass[b * 9 + s] += mm[s] * fv;
+            secnum[b] += n * fn;
+            cn_lo = cn_hi; cv_lo = cv_hi;
+        }
+    }
+}

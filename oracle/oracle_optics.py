@@ -97,3 +97,34 @@ def tile(tables, chem, alt, dz8w, idx, dims, mix=0):
         out[f"tauaerlw{b + 1}"] = lw2[b, 0]
         out[f"extaerlw{b + 1}"] = lw2[b, 1]
     return out
+
+
+def modal_to_sections(tables, chem, idx_mode, sigma, dims):
+    """Modal tracers -> sectional tracers (modal_sections.hip restated).  chem (num_chem, nj_m, nk_m, ni_m);
+    idx_mode [nmode][10] 1-based (0 = absent); sigma [nmode].  Returns chem_sec (nbin*10, nj_m, nk_m, ni_m), filled
+    inside the tile its:ite, kts:kte, jts:jte and zero elsewhere."""
+    chem = np.ascontiguousarray(chem, dtype=np.float64)
+    idx_mode = np.asarray(idx_mode, dtype=np.int64)
+    nmode = idx_mode.shape[0]
+    nbin = tables.nbin
+    _, nj_m, nk_m, ni_m = chem.shape
+    d = dims
+    l = _lib()
+    l.optics_oracle_modal_cell.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp]
+    sec = np.zeros((nbin * NSLOT, nj_m, nk_m, ni_m))
+    sig = np.ascontiguousarray(sigma, dtype=np.float64)
+    mass, num = np.zeros((nmode, NSPEC)), np.zeros(nmode)
+    sm, sn = np.zeros((nbin, NSPEC)), np.zeros(nbin)
+    for j in range(d["jts"] - d["jms"], d["jte"] - d["jms"] + 1):
+        for k in range(d["kts"] - d["kms"], d["kte"] - d["kms"] + 1):
+            for i in range(d["its"] - d["ims"], d["ite"] - d["ims"] + 1):
+                for m in range(nmode):
+                    for s in range(NSPEC):
+                        mass[m, s] = chem[idx_mode[m, s] - 1, j, k, i] if idx_mode[m, s] > 0 else 0.0
+                    num[m] = chem[idx_mode[m, NSPEC] - 1, j, k, i] if idx_mode[m, NSPEC] > 0 else 0.0
+                l.optics_oracle_modal_cell(C.addressof(tables), nmode, mass.ctypes.data_as(dp), num.ctypes.data_as(dp),
+                                           sig.ctypes.data_as(dp), sm.ctypes.data_as(dp), sn.ctypes.data_as(dp))
+                for b in range(nbin):
+                    sec[b * NSLOT:b * NSLOT + NSPEC, j, k, i] = sm[b]
+                    sec[b * NSLOT + NSPEC, j, k, i] = sn[b]
+    return sec

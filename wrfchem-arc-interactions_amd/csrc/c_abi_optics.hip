@@ -75,6 +75,11 @@ struct Staging {
 };
 
 }  // namespace
+
+// for modal_sections.hip
+bool optics_ready() { return g_opt.ready; }
+int optics_device() { return g_opt.device; }
+const OpticsTables &optics_tables() { return g_opt.tab; }
 }  // namespace rrtmg
 
 using namespace rrtmg;

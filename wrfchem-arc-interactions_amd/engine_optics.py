@@ -34,7 +34,18 @@ class OpticsArgs(C.Structure):
 
 
 EXPORTS_OPTICS = ["rrtmg_hip_optics_init", "rrtmg_hip_optical_averaging", "rrtmg_hip_optics_finalize",
-                  "rrtmg_hip_optics_table_info"]
+                  "rrtmg_hip_optics_table_info", "rrtmg_hip_modal_to_sections", "rrtmg_hip_modal_section_idx"]
+
+MAXMODE = 4
+MADE_SIGMA = (1.7, 2.0, 2.2)    # Aitken, accumulation, coarse mode of MADE/SORGAM
+
+
+class ModalArgs(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("ims", "ime", "jms", "jme", "kms", "kme",
+                                         "its", "ite", "jts", "jte", "kts", "kte", "real_bytes", "mem")]
+                + [("stream", C.c_void_p), ("nmode", C.c_int), ("num_chem", C.c_int),
+                   ("sigma", C.c_double * MAXMODE), ("idx", (C.c_int * NSLOT) * MAXMODE),
+                   ("chem", C.c_void_p), ("chem_sec", C.c_void_p)])
 
 _ready = False
 
@@ -121,3 +132,46 @@ def optical_averaging(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
 
 def optics_finalize():
     _lib().rrtmg_hip_optics_finalize()
+
+
+def modal_section_idx(nbin):
+    """idx table ([nbin][10], 1-based) of the sectional array modal_to_sections fills."""
+    buf = (C.c_int * (MAXBIN * NSLOT))()
+    lib = _lib()
+    lib.rrtmg_hip_modal_section_idx.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    if lib.rrtmg_hip_modal_section_idx(int(nbin), buf) != 0:
+        raise ValueError("nbin must be 1..8")
+    return np.array(buf, dtype=np.int64).reshape(MAXBIN, NSLOT)[:nbin]
+
+
+def modal_to_sections(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, chem, idx, sigma, chem_sec,
+                      stream=None):
+    """Modal aerosol (MADE/SORGAM type) -> the sectional tracers optical_averaging takes.  chem: (num_chem, nj_m, nk_m,
+    ni_m); idx[mode][slot] 1-based species numbers in SPECIES order (0 = not carried); sigma[mode]; chem_sec:
+    (nbin*10, nj_m, nk_m, ni_m), written inside the tile (use modal_section_idx(nbin) as its idx table)."""
+    lib = _lib()
+    lib.rrtmg_hip_modal_to_sections.argtypes = [C.POINTER(ModalArgs), C.c_char_p]
+    a = ModalArgs()
+    for n, v in dict(ims=ims, ime=ime, jms=jms, jme=jme, kms=kms, kme=kme, its=its, ite=ite, jts=jts, jte=jte,
+                     kts=kts, kte=kte).items():
+        setattr(a, n, int(v))
+    idx = np.asarray(idx, dtype=np.int64)
+    if idx.ndim != 2 or idx.shape[1] != NSLOT or idx.shape[0] > MAXMODE or len(sigma) != idx.shape[0]:
+        raise ValueError("idx must be [nmode <= 4][10] with one sigma per mode")
+    a.nmode = idx.shape[0]
+    for m in range(idx.shape[0]):
+        a.sigma[m] = float(sigma[m])
+        for s in range(NSLOT):
+            a.idx[m][s] = int(idx[m, s])
+    a.num_chem = int(chem.shape[0])
+    pc, dev_c, sz_c = _ptr(chem)
+    ps, dev_s, sz_s = _ptr(chem_sec)
+    if dev_c != dev_s or sz_c != sz_s:
+        raise ValueError("chem and chem_sec must live in the same memory space and have the same REAL size")
+    a.chem, a.chem_sec = pc, ps
+    a.real_bytes, a.mem = int(sz_c), 1 if dev_c else 0
+    if dev_c:
+        import torch
+        a.stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib.rrtmg_hip_modal_to_sections(C.byref(a), err), err)

@@ -18,7 +18,7 @@ MODULE module_optical_averaging_hip
 
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: optical_averaging_hip, optical_averaging_hip_init
+   PUBLIC :: optical_averaging_hip, optical_averaging_hip_init, modal_to_sections_hip
    PUBLIC :: aer_so4, aer_no3, aer_cl, aer_nh4, aer_na, aer_oin, aer_oc, aer_bc, aer_water, aer_num, aer_nspec, aer_maxbin
 
    INTEGER, PARAMETER :: errlen = 256
@@ -39,6 +39,19 @@ MODULE module_optical_averaging_hip
       TYPE(c_ptr) :: tauaerlw(16), extaerlw(16)
    END TYPE optics_args
 
+   ! mirrors struct rrtmg_hip_modal_args of include/rrtmg_hip.h
+   INTEGER, PARAMETER :: aer_maxmode = 4
+   TYPE, BIND(C) :: modal_args
+      INTEGER(c_int) :: ims, ime, jms, jme, kms, kme
+      INTEGER(c_int) :: its, ite, jts, jte, kts, kte
+      INTEGER(c_int) :: real_bytes, mem
+      TYPE(c_ptr)    :: stream
+      INTEGER(c_int) :: nmode, num_chem
+      REAL(c_double) :: sigma(aer_maxmode)
+      INTEGER(c_int) :: idx(aer_nspec, aer_maxmode)       ! C: idx[mode][species]
+      TYPE(c_ptr) :: chem, chem_sec
+   END TYPE modal_args
+
    INTERFACE
       INTEGER(c_int) FUNCTION rrtmg_hip_optics_init(nbin, dlo_um, dhi_um, refindex, density, device, err) &
             BIND(C, name='rrtmg_hip_optics_init')
@@ -53,6 +66,11 @@ MODULE module_optical_averaging_hip
          TYPE(optics_args), INTENT(IN) :: args
          CHARACTER(kind=c_char), INTENT(INOUT) :: err(*)
       END FUNCTION rrtmg_hip_optical_averaging
+      INTEGER(c_int) FUNCTION rrtmg_hip_modal_to_sections(args, err) BIND(C, name='rrtmg_hip_modal_to_sections')
+         IMPORT :: c_int, c_char, modal_args
+         TYPE(modal_args), INTENT(IN) :: args
+         CHARACTER(kind=c_char), INTENT(INOUT) :: err(*)
+      END FUNCTION rrtmg_hip_modal_to_sections
       INTEGER(c_int) FUNCTION rrtmg_hip_pick_device() BIND(C, name='rrtmg_hip_pick_device')
          IMPORT :: c_int
       END FUNCTION rrtmg_hip_pick_device
@@ -85,6 +103,45 @@ CONTAINS
                                  c_null_ptr, c_null_ptr, rrtmg_hip_pick_device(), err)
       IF (rc /= 0) CALL fatal_from_c(err)
    END SUBROUTINE optical_averaging_hip_init
+
+!------------------------------------------------------------------
+!  Modal aerosol (MADE/SORGAM type) -> sections: idx(species, mode) as below but per mode (e.g. idx(aer_so4,2) =
+!  p_so4aj), sigma(mode) the geometric standard deviations (MADE: 1.7, 2.0, 2.2).  chem_sec(i,k,j, nbin*10) and
+!  idx_sec(species, bin) are what optical_averaging_hip then takes (with num_chem = nbin*10).
+   SUBROUTINE modal_to_sections_hip(nbin_o, nmode, sigma, num_chem, idx, chem, chem_sec, idx_sec, &
+                                    ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte)
+      INTEGER, INTENT(IN) :: nbin_o, nmode, num_chem
+      INTEGER, INTENT(IN) :: ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte
+      REAL, INTENT(IN) :: sigma(nmode)
+      INTEGER, INTENT(IN) :: idx(aer_nspec, nmode)
+      REAL, DIMENSION(ims:ime,kms:kme,jms:jme,num_chem), INTENT(IN), TARGET :: chem
+      REAL, DIMENSION(ims:ime,kms:kme,jms:jme,nbin_o*aer_nspec), INTENT(INOUT), TARGET :: chem_sec
+      INTEGER, INTENT(OUT) :: idx_sec(aer_nspec, nbin_o)
+      TYPE(modal_args) :: a
+      CHARACTER(kind=c_char) :: err(errlen)
+      INTEGER :: m, b, s
+      EXTERNAL wrf_error_fatal
+      IF (nmode > aer_maxmode) CALL wrf_error_fatal('modal_to_sections_hip: at most 4 modes')
+      a%ims = ims; a%ime = ime; a%jms = jms; a%jme = jme; a%kms = kms; a%kme = kme
+      a%its = its; a%ite = ite; a%jts = jts; a%jte = jte; a%kts = kts; a%kte = kte
+      a%real_bytes = INT(STORAGE_SIZE(sigma(1)) / 8, c_int)
+      a%mem = 0
+      a%stream = c_null_ptr
+      a%nmode = nmode; a%num_chem = num_chem
+      a%sigma = 2.0_c_double; a%idx = 0
+      DO m = 1, nmode
+         a%sigma(m) = REAL(sigma(m), c_double)
+         a%idx(:, m) = idx(:, m)
+      END DO
+      a%chem = c_loc(chem); a%chem_sec = c_loc(chem_sec)
+      err = c_null_char
+      IF (rrtmg_hip_modal_to_sections(a, err) /= 0) CALL fatal_from_c(err)
+      DO b = 1, nbin_o
+         DO s = 1, aer_nspec
+            idx_sec(s, b) = (b - 1) * aer_nspec + s
+         END DO
+      END DO
+   END SUBROUTINE modal_to_sections_hip
 
 !------------------------------------------------------------------
 !  idx(species, bin): species number in chem of aer_so4 .. aer_num for each section (0 = not carried), e.g.

@@ -103,3 +103,60 @@ def make_mosaic_state(st, nbin=4, seed=20260005, empty_fraction=0.02) -> MosaicS
             c = chem[base + REGISTRY_ORDER.index(sp), :, :nk, :]
             c[empty] = 0.0
     return MosaicState(nbin=nbin, chem=chem, alt=alt, dz8w=st.a3["dz8w"].copy(), idx=idx, names=names)
+
+
+@dataclass
+class ModalState:
+    chem: np.ndarray          # (num_chem, nj, kme, ni)
+    idx: np.ndarray           # [3 modes][10] 1-based, SPECIES order
+    sigma: tuple
+    alt: np.ndarray
+    dz8w: np.ndarray
+    names: list
+
+
+def make_made_state(st, seed=20260008, empty_fraction=0.03) -> ModalState:
+    """Synthetic MADE/SORGAM-type aerosol: Aitken, accumulation and coarse mode (sigma 1.7 / 2.0 / 2.2) with number
+    and species masses per mode; median diameters scatter around 0.03, 0.2 and 3 um; the coarse mode carries sea
+    salt and dust only; some cells have empty modes."""
+    rng = np.random.default_rng(seed)
+    nj, kme, ni = st.a3["rho3d"].shape
+    nk = st.nk
+    rho = st.a3["rho3d"][:, :nk, :]
+    dz = st.a3["dz8w"][:, :nk, :]
+    z = np.cumsum(dz, axis=1) - 0.5 * dz
+    shp3 = (nj, nk, ni)
+    sigma = (1.7, 2.0, 2.2)
+    dens = np.array([1.8, 1.8, 2.2, 1.8, 2.2, 2.6, 1.0, 1.7])            # so4 no3 cl nh4 na oin oc bc
+    names = ["gas1", "gas2"]
+    for m in ("i", "j", "c"):
+        names += [f"{s}a{m}" for s in SPECIES[:9]] + [f"n{m}"]
+    chem = np.zeros((len(names), nj, kme, ni))
+    chem[:2, :, :nk, :] = rng.uniform(0, 1, (2,) + shp3)
+    idx = np.zeros((3, 10), dtype=np.int64)
+    load0 = [10.0 ** rng.uniform(-1.0, 0.5, shp3), 10.0 ** rng.uniform(0.3, 1.7, shp3), 10.0 ** rng.uniform(0.0, 1.5, shp3)]
+    comp = [rng.dirichlet([4, 2, 0.1, 2, 0.1, 0.2, 3, 1.0], shp3), rng.dirichlet([4, 2, 0.3, 2, 0.3, 0.8, 3, 0.6], shp3),
+            rng.dirichlet([0.01, 0.01, 2, 0.01, 2, 6, 0.01, 0.01], shp3)]
+    dg0 = (0.03, 0.2, 3.0)
+    prof = np.exp(-z / 2000.0)
+    for m in range(3):
+        base = 2 + m * 10
+        idx[m] = np.arange(base + 1, base + 11)
+        mass = load0[m] * prof / rho                                     # ug per kg of dry air
+        dry = mass[..., None] * comp[m]                                   # (nj, nk, ni, 8)
+        empty = rng.uniform(size=shp3) < empty_fraction
+        dry[empty] = 0.0
+        for s in range(8):
+            chem[base + s, :, :nk, :] = dry[..., s]
+        water = mass * rng.uniform(0.0, 2.0, shp3) * (~empty)
+        chem[base + 8, :, :nk, :] = water
+        vol = (dry / dens).sum(axis=-1) * 1.0e-6                          # cm3 per kg (ug / (g cm-3) = 1e-6 cm3)
+        dgn = dg0[m] * 10.0 ** rng.uniform(-0.25, 0.25, shp3) * 1.0e-4    # cm
+        ls = np.log(sigma[m])
+        num = vol / (np.pi / 6.0 * dgn ** 3 * np.exp(4.5 * ls * ls))
+        num[empty] = 0.0
+        chem[base + 9, :, :nk, :] = num
+    alt = np.zeros((nj, kme, ni))
+    alt[:, :nk, :] = 1.0 / rho
+    alt[:, nk:, :] = 1.0
+    return ModalState(chem=chem, idx=idx, sigma=sigma, alt=alt, dz8w=st.a3["dz8w"].copy(), names=names)
