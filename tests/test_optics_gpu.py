@@ -148,3 +148,35 @@ def test_optics_full_size_properties_200x200x40(hip_lib, wa):
     got3 = run_hip_optics(wa, st, ms3)
     for n in ("tauaer2", "waer2", "gaer2", "tauaerlw5", "tauaerlw6"):
         np.testing.assert_array_equal(got3[n], got[n][..., perm], err_msg=n)
+
+
+def test_optics_mixed_precision_longwave(hip_lib, wa):
+    """The "mixed" path (BASELINE configs[4]): longwave bands in fp32.  The shortwave outputs keep their fp64 bits;
+    the longwave absorption optical depths stay within 2e-4 of the fp64 oracle (fp32 series with the psi_n ratio
+    recurrence; measured worst case of the efficiencies 6e-5)."""
+    _init(wa, 8)
+    st = wa.synth.make_wrf_state(9, 6, 30, seed=20260370)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260371)
+    ref64 = run_hip_optics(wa, st, ms)
+    try:
+        wa.engine_optics.optics_precision("mixed")
+        got = run_hip_optics(wa, st, ms)
+    finally:
+        wa.engine_optics.optics_precision("f64")
+    orc = run_oracle_optics(wa, st, ms)
+    mask = tile_mask(st, ms.alt.shape)
+    for n in SW_NAMES:
+        np.testing.assert_array_equal(got[n], ref64[n], err_msg=n)
+    worst = 0.0
+    for n in LW_NAMES:
+        g, r = got[n][mask], orc[n][mask]
+        assert np.isfinite(g).all(), n
+        rel = np.abs(g - r) / np.maximum(np.abs(r), 1e-300)
+        big = r > 1e-12 * r.max()
+        worst = max(worst, float(rel[big].max()))
+        assert (g[~big] <= 1e-10 * r.max() + 2 * r[~big]).all(), n
+    assert worst < 2e-4, worst
+    assert not np.array_equal(got["tauaerlw8"], ref64["tauaerlw8"])          # the path really ran in fp32
+    again = run_hip_optics(wa, st, ms)
+    for n in LW_NAMES:
+        np.testing.assert_array_equal(again[n], ref64[n], err_msg=n)          # and switching back restores fp64

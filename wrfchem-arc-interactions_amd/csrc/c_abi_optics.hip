@@ -16,6 +16,7 @@ namespace {
 struct OpticsState {
     bool ready = false;
     int device = 0;
+    int precision = 0;       // 0 fp64, 1 longwave bands in fp32 (rrtmg_hip_optics_precision)
     OpticsTables tab{};
 };
 OpticsState g_opt;
@@ -187,11 +188,19 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
             HIPCHK(out(a->tauaerlw[b], &k.tauaerlw[b])); HIPCHK(out(a->extaerlw[b], &k.extaerlw[b]));
         }
     }
-    HIPCHK(optics_launch(k, stream));
+    HIPCHK(optics_launch(k, stream, g_opt.precision));
     if (a->mem != 1) {
         for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, n3, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
     }
+    return 0;
+}
+
+extern "C" int rrtmg_hip_optics_precision(int mode, char *err)
+{
+    if (mode != 0 && mode != 1) return failo(err, "rrtmg_hip_optics_precision: mode must be 0 (fp64) or 1 (longwave bands in fp32)");
+    std::lock_guard<std::mutex> lock(g_opt_mutex);
+    g_opt.precision = mode;
     return 0;
 }
 

@@ -7,6 +7,7 @@
 namespace rrtmg {
 
 hipError_t optics_upload_tables(const OpticsTables &t);
-hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream);
+// precision: 0 = fp64 throughout, 1 = longwave bands in fp32 ("mixed")
+hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int precision);
 
 }  // namespace rrtmg

@@ -181,6 +181,8 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
 // accurate), use register blocks of OPT_MB2 terms and the two halves of the thread's checkpoint column
 // (OPT_NCK/2 checkpoints each: nstop <= OPT_MB2*OPT_NCK/2 = 64, the caller checks).  Extinction and scattering only.
 constexpr int OPT_MB2 = 8, OPT_NCK2 = OPT_NCK / 2;
+constexpr double OPT_XMAX32 = 47.0;   // x + 4 x^(1/3) + 2 < 64 = OPT_MB2 * OPT_NCK2
+constexpr int OPT_NCK32 = OPT_NCK2 + OPT_NCK2 / 2;   // LDS slots per thread of the fp32 pair
 
 struct MieSetup {
     cplx yinv, minv;
@@ -248,6 +250,131 @@ __device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2,
     const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
     qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
     qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
+}
+
+// ---- single-precision pair (the "mixed" optics path: longwave bands in fp32, everything else fp64) ----
+// Same series, two changes that fp32 needs.  (1) psi_n(x) is carried upward by its recurrence only while n <= x
+// (the oscillatory range, where errors do not grow); beyond, psi_n = psi_{n-1} / (n/x + A_n(x)) with the logarithmic
+// derivative A_n of the real argument obtained by the same downward recurrence as D_n -- the plain recurrence
+// cancels catastrophically there (psi_1 = sin x / x - cos x is off by 5 % at x = 0.002 in fp32).  (2) a_n and b_n
+// take one reciprocal each (the product of their denominators overflows fp32).  Reciprocals are v_rcp_f32 (1 ulp).
+// Measured against the fp64 oracle over x = 0.0016 .. 40: absorption efficiency within 6e-5, median 2e-7.
+__device__ __forceinline__ float rcpf(float b) { return __builtin_amdgcn_rcpf(b); }
+// The two evaluations of a pair travel as the two components of packed fp32 values (v_pk_fma_f32 and friends
+// process both per instruction); complex numbers are (re, im) of such pairs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct cplx2 { v2f re, im; };
+__device__ __forceinline__ v2f rcp2(v2f b) { return v2f{rcpf(b.x), rcpf(b.y)}; }
+__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+__device__ __forceinline__ cplx2 cadd2(cplx2 a, cplx2 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx2 csub2(cplx2 a, cplx2 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx2 cmul2(cplx2 a, cplx2 b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx2 crecip2(cplx2 a)
+{
+    const v2f r = rcp2(a.re * a.re + a.im * a.im);
+    return {a.re * r, -a.im * r};
+}
+struct MieSetup32 {      // both evaluations of the pair
+    cplx2 m, yinv, minv;
+    v2f x, xinv;
+    int nstop1, nstop2, nmx;
+};
+__device__ __forceinline__ MieSetup32 mie_setup32(float x1, float m1re, float m1im, float x2, float m2re, float m2im)
+{
+    MieSetup32 s;
+    s.x = v2f{x1, x2};
+    s.m = {v2f{m1re, m2re}, v2f{m1im, m2im}};
+    const cplx2 y = {s.x * s.m.re, s.x * s.m.im};
+    const v2f ymod2 = y.re * y.re + y.im * y.im;
+    const float ym1 = sqrtf(ymod2.x), ym2 = sqrtf(ymod2.y);
+    const float xs1 = s.x.x + 4.f * cbrtf(s.x.x) + 2.f, xs2 = s.x.y + 4.f * cbrtf(s.x.y) + 2.f;
+    s.nstop1 = (int)xs1; s.nstop2 = (int)xs2;
+    const float b1 = fmaxf(xs1, ym1), b2 = fmaxf(xs2, ym2);
+    const int n1 = (int)(b1 + (b1 > 8.f ? 8.f * cbrtf(b1) : 0.f)) + 16, n2 = (int)(b2 + (b2 > 8.f ? 8.f * cbrtf(b2) : 0.f)) + 16;
+    s.nmx = n1 > n2 ? n1 : n2;      // a higher start is only more accurate
+    s.yinv = crecip2(y);
+    s.minv = crecip2(s.m);
+    s.xinv = rcp2(s.x);
+    return s;
+}
+struct MieAcc32 { v2f p, pm, c, cm, qs, qe; };   // psi_{n-1}, psi_{n-2}, chi_{n-1}, chi_{n-2}, sums
+__device__ __forceinline__ void mie_term32(MieAcc32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
+{
+    const float en = (float)n;
+    const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
+    const v2f psi = sel2(en > s.x.x, en > s.x.y, A.p * rcp2(nx + An), up * A.p - A.pm);
+    const v2f chi = up * A.c - A.cm;
+    const cplx2 xi = {psi, -chi}, xi1 = {A.p, -A.c};
+    cplx2 t = cmul2(D, s.minv);
+    t.re += nx;
+    const cplx2 na = {t.re * psi - A.p, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
+    t = cmul2(s.m, D);
+    t.re += nx;
+    const cplx2 nb = {t.re * psi - A.p, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
+    const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
+    const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+    const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
+    const float w2 = 2.f * en + 1.f;
+    const v2f zero = v2f{0.f, 0.f};
+    // an evaluation whose series has ended adds nothing
+    A.qs += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
+    A.qe += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re + bn.re), zero);
+    A.pm = A.p; A.p = psi; A.cm = A.c; A.c = chi;
+}
+// register blocks of OPT_MB2 terms; checkpoints of D_n (both evaluations) in slots 0..NCK2-1 and of A_n (both, two
+// checkpoints per slot) in slots NCK2..NCK2+NCK2/2-1 of the thread's column: OPT_NCK32 slots of 16 bytes
+__device__ __forceinline__ void mie_pair32(const MieSetup32 &s, double2 *ck, float &qext1, float &qsca1,
+                                           float &qext2, float &qsca2)
+{
+    const int nstopm = s.nstop1 > s.nstop2 ? s.nstop1 : s.nstop2;
+    const int nck = (nstopm + OPT_MB2 - 1) / OPT_MB2, ntop = nck * OPT_MB2;
+    cplx2 d = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+    v2f a = v2f{0.f, 0.f};
+    for (int n = s.nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), A_{n-1} = n/x - 1/(A_n + n/x)
+        const float en = (float)n;
+        const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
+        d = csub2(ny, crecip2(cadd2(d, ny)));
+        const v2f nx = en * s.xinv;
+        a = nx - rcp2(a + nx);
+        const int n1 = n - 1;
+        if (n1 <= ntop && (n1 & (OPT_MB2 - 1)) == 0) {
+            const int j = n1 / OPT_MB2 - 1;
+            *reinterpret_cast<float4 *>(&ck[(size_t)j * OPT_THREADS]) = make_float4(d.re.x, d.re.y, d.im.x, d.im.y);
+            reinterpret_cast<float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1] = make_float2(a.x, a.y);
+        }
+        if (n1 <= OPT_MB2) break;
+    }
+    MieAcc32 A;
+    float sn1, cs1, sn2, cs2;
+    sincosf(s.x.x, &sn1, &cs1);
+    sincosf(s.x.y, &sn2, &cs2);
+    A.p = v2f{sn1, sn2}; A.pm = v2f{cs1, cs2}; A.c = A.pm; A.cm = -A.p;
+    A.qs = v2f{0.f, 0.f}; A.qe = v2f{0.f, 0.f};
+    for (int j = 0; j < nck; ++j) {
+        cplx2 dd[OPT_MB2];
+        v2f aa[OPT_MB2];
+        const float4 cd = *reinterpret_cast<const float4 *>(&ck[(size_t)j * OPT_THREADS]);
+        const float2 ca = reinterpret_cast<const float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1];
+        dd[OPT_MB2 - 1] = {v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};
+        aa[OPT_MB2 - 1] = v2f{ca.x, ca.y};
+#pragma unroll
+        for (int i = OPT_MB2 - 1; i >= 1; --i) {
+            const float en = (float)(j * OPT_MB2 + i + 1);
+            const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
+            dd[i - 1] = csub2(ny, crecip2(cadd2(dd[i], ny)));
+            const v2f nx = en * s.xinv;
+            aa[i - 1] = nx - rcp2(aa[i] + nx);
+        }
+#pragma unroll
+        for (int i = 0; i < OPT_MB2; ++i) {
+            const int n = j * OPT_MB2 + i + 1;
+            if (n <= nstopm) mie_term32(A, n, dd[i], aa[i], s);
+        }
+    }
+    const v2f f = 2.f * s.xinv * s.xinv;
+    const v2f qs = f * A.qs, qe = f * A.qe;
+    qsca1 = qs.x; qext1 = qe.x;
+    qsca2 = qs.y; qext2 = qe.y;
 }
 
 // refractive index of the internal mixture at wavelength slot w (volume average, or Maxwell-Garnett with BC inclusions)
@@ -354,13 +481,15 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             const cplx mb = mix_index(vol, vwet, a.mix, w2);
             double xb = pi * dwet * frcp(lam2);
             xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
-            if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
-                mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
-            } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
-                double g0, b0;
-                mie_sphere<false>(x, m, ck, qe, qs, g0, b0);
-                mie_sphere<false>(xb, mb, ck, qe2, qs2, g0, b0);
+            {
+                const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
+                if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
+                    mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
+                } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
+                    double g0, b0;
+                    mie_sphere<false>(x, m, ck, qe, qs, g0, b0);
+                    mie_sphere<false>(xb, mb, ck, qe2, qs2, g0, b0);
+                }
             }
         }
         const double dcm = dwet * 1.e-4;
@@ -390,6 +519,110 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
     }
 }
 
+// Mixed path, longwave band pair: the whole cell evaluation in fp32 (particle geometry, refractive index of the
+// mixture, Mie series); tracers are read and optical depths written in the arrays' own type.
+struct cf32 { float re, im; };
+__device__ __forceinline__ cf32 mix_index32(const float *vol, float vwet, int mix, int w)
+{
+    float sr = 0.f, si = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+        if (mix == 1 && sp == OS_BC) continue;
+        sr += vol[sp] * (float)c_opt.refr[sp][w];
+        si += vol[sp] * (float)c_opt.refi[sp][w];
+    }
+    if (mix == 0) {
+        const float vi = rcpf(vwet);
+        return {sr * vi, si * vi};
+    }
+    const float vbc = vol[OS_BC], vmat = vwet - vbc;
+    const cf32 mbc = {(float)c_opt.refr[OS_BC][w], (float)c_opt.refi[OS_BC][w]};
+    if (!(vmat > 1.e-30f * vwet)) return mbc;
+    const float vi = rcpf(vmat);
+    const cf32 mm = {sr * vi, si * vi};
+    if (!(vbc > 0.f)) return mm;
+    // Maxwell-Garnett: e = em (ei + 2em + 2f(ei-em)) / (ei + 2em - f(ei-em))
+    auto mul = [](cf32 p, cf32 q) { return cf32{p.re * q.re - p.im * q.im, p.re * q.im + p.im * q.re}; };
+    const float f = vbc * rcpf(vwet);
+    const cf32 em = mul(mm, mm), ei = mul(mbc, mbc);
+    const cf32 de = {ei.re - em.re, ei.im - em.im};
+    const cf32 base = {ei.re + 2.f * em.re, ei.im + 2.f * em.im};
+    const cf32 nume = {base.re + 2.f * f * de.re, base.im + 2.f * f * de.im};
+    const cf32 deno = {base.re - f * de.re, base.im - f * de.im};
+    const float rd = rcpf(deno.re * deno.re + deno.im * deno.im);
+    const cf32 quo = mul(nume, cf32{deno.re * rd, -deno.im * rd});
+    const cf32 e = mul(em, quo);
+    const float mod = sqrtf(e.re * e.re + e.im * e.im);
+    const float re = sqrtf(0.5f * (mod + e.re)), im = sqrtf(fmaxf(0.5f * (mod - e.re), 0.f));
+    return {re, e.im < 0.f ? -im : im};
+}
+
+__device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, double2 *s_ck)
+{
+    constexpr int NW = OPT_NLW / 2;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, s = b >> 3;
+    const int gl = s / NW, slot = s - gl * NW;
+    const int w = OPT_NSW + 2 * slot, w2 = w + 1;
+    double2 *ck = s_ck + threadIdx.x;
+    const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
+    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
+    if (cell >= ncell) return;
+    const int ib0 = w - OPT_NSW;
+    if (!(a.tauaerlw[ib0] || a.extaerlw[ib0] || a.tauaerlw[ib0 + 1] || a.extaerlw[ib0 + 1])) return;
+    const int it = (int)(cell % a.ni_t);
+    const long r = cell / a.ni_t;
+    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
+    const int r4 = a.real4;
+    const float alt = (float)ldr(a.alt, q, r4), dz = (float)ldr(a.dz8w, q, r4);
+    const float pi = 3.14159265358979323846f;
+    const float rlam = rcpf((float)c_opt.wavelength_um[w]), rlam2 = rcpf((float)c_opt.wavelength_um[w2]);
+    const float ralt = rcpf(alt);
+    float ext = 0.f, sca = 0.f, ext2 = 0.f, sca2 = 0.f;   // 1/cm
+    for (int ib = 0; ib < a.nbin; ++ib) {
+        float vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
+        float vdry = 0.f;
+#pragma unroll
+        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+            const int id = a.idx[ib][sp];
+            const float mass = id >= 0 ? fmaxf((float)ldr(a.chem, (size_t)id * sspec + q, r4), 0.f) : 0.f;
+            vol[sp] = mass * rcpf((float)c_opt.dens[sp]);
+            if (sp != OS_WATER) vdry += vol[sp];
+        }
+        const int idn = a.idx[ib][OS_NUM];
+        float num = idn >= 0 ? fmaxf((float)ldr(a.chem, (size_t)idn * sspec + q, r4), 0.f) : 0.f;
+        if (!(vdry > 1.e-25f)) continue;
+        const float vwet = vdry + vol[OS_WATER];
+        const float vpart = vdry * 1.e-6f * rcpf(fmaxf(num, 1.e-30f));   // cm3 per particle
+        float ddry = 1.e4f * cbrtf(vpart * (6.f / pi));
+        const float dlo = (float)c_opt.dlo_um[ib], dhi = (float)c_opt.dhi_um[ib];
+        if (ddry < dlo || ddry > dhi) {
+            ddry = ddry < dlo ? dlo : dhi;
+            const float dcm = ddry * 1.e-4f;
+            num = vdry * 1.e-6f * rcpf((pi / 6.f) * dcm * dcm * dcm);
+        }
+        const float dwet = ddry * cbrtf(vwet * rcpf(vdry));
+        const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
+        // size parameters capped so that the series fits the register blocks (nstop <= 64); no aerosol reaches
+        // x = 47 at wavelengths >= 3.3 um (diameter 50 um)
+        const float x1 = fminf(pi * dwet * rlam, (float)OPT_XMAX32), x2 = fminf(pi * dwet * rlam2, (float)OPT_XMAX32);
+        const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
+        float qe, qs, qe2, qs2;
+        mie_pair32(t12, ck, qe, qs, qe2, qs2);
+        const float dcm = dwet * 1.e-4f;
+        const float cross = (num * ralt * 1.e-6f) * (0.25f * pi * dcm * dcm);   // #/cm3 * cm2
+        ext += cross * qe; sca += cross * qs;
+        ext2 += cross * qe2; sca2 += cross * qs2;
+    }
+    const float ab = fmaxf(ext - sca, 0.f), ab2 = fmaxf(ext2 - sca2, 0.f);
+    if (a.tauaerlw[ib0]) str(a.tauaerlw[ib0], q, r4, (double)(ab * 100.f * dz));
+    if (a.extaerlw[ib0]) str(a.extaerlw[ib0], q, r4, (double)(ab * 1.e5f));
+    if (a.tauaerlw[ib0 + 1]) str(a.tauaerlw[ib0 + 1], q, r4, (double)(ab2 * 100.f * dz));
+    if (a.extaerlw[ib0 + 1]) str(a.extaerlw[ib0 + 1], q, r4, (double)(ab2 * 1.e5f));
+}
+
 __global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
@@ -400,6 +633,13 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_lw_kernel(const OpticsKern
 {
     __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
     optics_body<true>(a, s_ck);
+}
+
+// the mixed-precision path: longwave band pairs in fp32
+__global__ void __launch_bounds__(OPT_THREADS) optics_lw32_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
+    optics_body_lw32(a, s_ck);
 }
 
 }  // namespace
@@ -417,7 +657,7 @@ hipError_t optics_upload_tables(const OpticsTables &t)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_opt), &t, sizeof(OpticsTables));
 }
 
-hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream)
+hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int precision)
 {
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (ncell <= 0) return hipSuccess;
@@ -430,7 +670,10 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream)
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
     if (any_sw) hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
-    if (any_lw) hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
+    if (any_lw && precision == 1)
+        hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
+    else if (any_lw)
+        hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -34,7 +34,8 @@ class OpticsArgs(C.Structure):
 
 
 EXPORTS_OPTICS = ["rrtmg_hip_optics_init", "rrtmg_hip_optical_averaging", "rrtmg_hip_optics_finalize",
-                  "rrtmg_hip_optics_table_info", "rrtmg_hip_modal_to_sections", "rrtmg_hip_modal_section_idx"]
+                  "rrtmg_hip_optics_table_info", "rrtmg_hip_modal_to_sections", "rrtmg_hip_modal_section_idx",
+                  "rrtmg_hip_optics_precision"]
 
 MAXMODE = 4
 MADE_SIGMA = (1.7, 2.0, 2.2)    # Aitken, accumulation, coarse mode of MADE/SORGAM
@@ -175,3 +176,12 @@ def modal_to_sections(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
         a.stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     err = C.create_string_buffer(ERRLEN)
     _check(lib.rrtmg_hip_modal_to_sections(C.byref(a), err), err)
+
+
+def optics_precision(mode):
+    """"f64" / 0: fp64 throughout (default); "mixed" / 1: the 16 longwave bands in fp32 (BASELINE configs[4])."""
+    m = {"f64": 0, "mixed": 1}.get(mode, mode)
+    lib = _lib()
+    lib.rrtmg_hip_optics_precision.argtypes = [C.c_int, C.c_char_p]
+    err = C.create_string_buffer(ERRLEN)
+    _check(lib.rrtmg_hip_optics_precision(int(m), err), err)

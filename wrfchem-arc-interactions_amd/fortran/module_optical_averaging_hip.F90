@@ -18,7 +18,7 @@ MODULE module_optical_averaging_hip
 
    IMPLICIT NONE
    PRIVATE
-   PUBLIC :: optical_averaging_hip, optical_averaging_hip_init, modal_to_sections_hip
+   PUBLIC :: optical_averaging_hip, optical_averaging_hip_init, modal_to_sections_hip, optical_averaging_hip_precision
    PUBLIC :: aer_so4, aer_no3, aer_cl, aer_nh4, aer_na, aer_oin, aer_oc, aer_bc, aer_water, aer_num, aer_nspec, aer_maxbin
 
    INTEGER, PARAMETER :: errlen = 256
@@ -66,6 +66,11 @@ MODULE module_optical_averaging_hip
          TYPE(optics_args), INTENT(IN) :: args
          CHARACTER(kind=c_char), INTENT(INOUT) :: err(*)
       END FUNCTION rrtmg_hip_optical_averaging
+      INTEGER(c_int) FUNCTION rrtmg_hip_optics_precision(mode, err) BIND(C, name='rrtmg_hip_optics_precision')
+         IMPORT :: c_int, c_char
+         INTEGER(c_int), VALUE :: mode
+         CHARACTER(kind=c_char), INTENT(INOUT) :: err(*)
+      END FUNCTION rrtmg_hip_optics_precision
       INTEGER(c_int) FUNCTION rrtmg_hip_modal_to_sections(args, err) BIND(C, name='rrtmg_hip_modal_to_sections')
          IMPORT :: c_int, c_char, modal_args
          TYPE(modal_args), INTENT(IN) :: args
@@ -103,6 +108,15 @@ CONTAINS
                                  c_null_ptr, c_null_ptr, rrtmg_hip_pick_device(), err)
       IF (rc /= 0) CALL fatal_from_c(err)
    END SUBROUTINE optical_averaging_hip_init
+
+!------------------------------------------------------------------
+!  mode 0: fp64 throughout (default); 1: "mixed" -- the 16 longwave bands in fp32
+   SUBROUTINE optical_averaging_hip_precision(mode)
+      INTEGER, INTENT(IN) :: mode
+      CHARACTER(kind=c_char) :: err(errlen)
+      err = c_null_char
+      IF (rrtmg_hip_optics_precision(INT(mode, c_int), err) /= 0) CALL fatal_from_c(err)
+   END SUBROUTINE optical_averaging_hip_precision
 
 !------------------------------------------------------------------
 !  Modal aerosol (MADE/SORGAM type) -> sections: idx(species, mode) as below but per mode (e.g. idx(aer_so4,2) =
