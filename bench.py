@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--mode", choices=["full", "swlw", "sw"], default="full")
     ap.add_argument("--nbin", type=int, default=4, help="MOSAIC sections of the optics stage (4 or 8)")
     ap.add_argument("--optics-precision", choices=["f64", "mixed"], default="f64",
-                    help="mixed: the 16 longwave bands of the optical averaging in fp32 (BASELINE configs[4])")
+                    help="mixed: the Mie series of the optical averaging in packed fp32 (BASELINE configs[4])")
     ap.add_argument("--cpu-optics-sample", type=int, default=400)
     ap.add_argument("--night", type=float, default=0.0, help="fraction of night columns (0 for kernel timing)")
     ap.add_argument("--cpu-sample", type=int, default=6000)
@@ -350,7 +350,7 @@ def main():
             "metric": "columns/sec, aerosol+clean RRTMG SW+LW double-call; flux RMSE vs reference",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.optics_precision == "f64" or not do_opt else "f64 (longwave optics f32)",
+            "vs_baseline": None, "dtype": "f64" if args.optics_precision == "f64" or not do_opt else "f64 (optical averaging f32)",
             "data": "synthetic",
             "config": {"workload": workload,
                        "columns_per_gpu": ncol, "layers": args.nk, "night_fraction": args.night,

@@ -279,9 +279,9 @@ typedef struct rrtmg_hip_optics_args {
 } rrtmg_hip_optics_args;
 
 int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *args, char *err);
-/* Arithmetic of the stage: 0 = fp64 throughout (default); 1 = "mixed" (BASELINE configs[4]): the 16 longwave bands
- * are evaluated in fp32 (absorption efficiencies within 1e-4 of the fp64 result), the shortwave
- * wavelengths and the particle geometry stay fp64.  Takes effect from the next rrtmg_hip_optical_averaging call. */
+/* Arithmetic of the stage: 0 = fp64 throughout (default); 1 = "mixed" (BASELINE configs[4]): particle geometry and
+ * Mie series in fp32 (efficiencies within 1e-4 of the fp64 result; longwave size parameters capped at 47);
+ * the radiation stays fp64.  Takes effect from the next rrtmg_hip_optical_averaging call. */
 int rrtmg_hip_optics_precision(int mode, char *err);
 int rrtmg_hip_optics_finalize(void);
 

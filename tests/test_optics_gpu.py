@@ -150,10 +150,11 @@ def test_optics_full_size_properties_200x200x40(hip_lib, wa):
         np.testing.assert_array_equal(got3[n], got[n][..., perm], err_msg=n)
 
 
-def test_optics_mixed_precision_longwave(hip_lib, wa):
-    """The "mixed" path (BASELINE configs[4]): longwave bands in fp32.  The shortwave outputs keep their fp64 bits;
-    the longwave absorption optical depths stay within 2e-4 of the fp64 oracle (fp32 series with the psi_n ratio
-    recurrence; measured worst case of the efficiencies 6e-5)."""
+def test_optics_mixed_precision(hip_lib, wa):
+    """The "mixed" path (BASELINE configs[4]): the Mie series in packed fp32 (psi_n by the ratio recurrence beyond
+    n = x).  Against the fp64 oracle: optical depths and coefficients within 2e-4, single-scattering albedo and
+    asymmetry within 1e-4 absolute (measured worst case of the efficiencies 6e-5); switching back restores the fp64
+    bits."""
     _init(wa, 8)
     st = wa.synth.make_wrf_state(9, 6, 30, seed=20260370)
     ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260371)
@@ -165,18 +166,21 @@ def test_optics_mixed_precision_longwave(hip_lib, wa):
         wa.engine_optics.optics_precision("f64")
     orc = run_oracle_optics(wa, st, ms)
     mask = tile_mask(st, ms.alt.shape)
-    for n in SW_NAMES:
-        np.testing.assert_array_equal(got[n], ref64[n], err_msg=n)
     worst = 0.0
-    for n in LW_NAMES:
+    for n in SW_NAMES + LW_NAMES:
         g, r = got[n][mask], orc[n][mask]
         assert np.isfinite(g).all(), n
-        rel = np.abs(g - r) / np.maximum(np.abs(r), 1e-300)
-        big = r > 1e-12 * r.max()
-        worst = max(worst, float(rel[big].max()))
-        assert (g[~big] <= 1e-10 * r.max() + 2 * r[~big]).all(), n
-    assert worst < 2e-4, worst
-    assert not np.array_equal(got["tauaerlw8"], ref64["tauaerlw8"])          # the path really ran in fp32
+        assert (got[n][~mask] == SENTINEL).all(), n
+        if n.startswith(("waer", "gaer")):
+            assert np.abs(g - r).max() < 1e-4, (n, float(np.abs(g - r).max()))
+            continue
+        tol = 2e-3 if n.startswith("bscoef") else 2e-4      # backscatter: an alternating sum
+        big = r > 1e-10 * r.max()
+        rel = np.abs(g - r)[big] / r[big]
+        worst = max(worst, float(rel.max()) / tol)
+        assert rel.max() < tol, (n, float(rel.max()))
+        assert (g[~big] <= 1e-9 * r.max() + 2 * r[~big]).all(), n
+    assert not np.array_equal(got["tauaerlw8"], ref64["tauaerlw8"]) and not np.array_equal(got["tauaer2"], ref64["tauaer2"])
     again = run_hip_optics(wa, st, ms)
-    for n in LW_NAMES:
-        np.testing.assert_array_equal(again[n], ref64[n], err_msg=n)          # and switching back restores fp64
+    for n in SW_NAMES + LW_NAMES:
+        np.testing.assert_array_equal(again[n], ref64[n], err_msg=n)          # switching back restores fp64

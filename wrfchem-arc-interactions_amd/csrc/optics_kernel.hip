@@ -557,6 +557,189 @@ __device__ __forceinline__ cf32 mix_index32(const float *vol, float vwet, int mi
     return {re, e.im < 0.f ? -im : im};
 }
 
+// ---- mixed path, shortwave: two wavelengths of a particle as a packed fp32 pair, series up to nstop = 256 ----
+// 256 terms of D_n and A_n for two evaluations do not fit registers or LDS at 12 waves per CU, so only every 32nd
+// term is kept in LDS (OPT_NCK32 slots, as for the longwave pair) and each block of 8 terms is rebuilt from the
+// checkpoint above it: the chain is walked 2.5 times on average -- ~12 packed instructions per step against ~70 per
+// term of the series.  Asymmetry and backscatter sums as in mie_term<true>.
+constexpr int OPT_SB = 32;     // terms between checkpoints
+struct MieAccF32 { v2f p, pm, c, cm, qs, qe, gs; cplx2 an1, bn1, xb; float sgn; };
+__device__ __forceinline__ void mie_term32_full(MieAccF32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
+{
+    const float en = (float)n;
+    const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
+    const v2f psi = sel2(en > s.x.x, en > s.x.y, A.p * rcp2(nx + An), up * A.p - A.pm);
+    const v2f chi = up * A.c - A.cm;
+    const cplx2 xi = {psi, -chi}, xi1 = {A.p, -A.c};
+    cplx2 t = cmul2(D, s.minv);
+    t.re += nx;
+    const cplx2 na = {t.re * psi - A.p, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
+    t = cmul2(s.m, D);
+    t.re += nx;
+    const cplx2 nb = {t.re * psi - A.p, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
+    const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
+    const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+    const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
+    const float w2 = 2.f * en + 1.f;
+    const v2f zero = v2f{0.f, 0.f};
+    const bool on1 = n <= s.nstop1, on2 = n <= s.nstop2;   // an evaluation whose series has ended adds nothing
+    A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
+    A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
+    v2f dg = (float)c_gw[0][n] * (an.re * bn.re + an.im * bn.im);
+    if (n > 1) dg += (float)c_gw[1][n] * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+    A.gs += sel2(on1, on2, dg, zero);
+    A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
+    A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
+    A.sgn = -A.sgn;
+    A.an1 = an; A.bn1 = bn;
+    A.pm = A.p; A.p = psi; A.cm = A.c; A.c = chi;
+}
+__device__ __forceinline__ void mie_pair32_full(const MieSetup32 &s, double2 *ck, v2f &qext, v2f &qsca, v2f &gasy, v2f &qback)
+{
+    const int nstopm = s.nstop1 > s.nstop2 ? s.nstop1 : s.nstop2;
+    const int nck = (nstopm + OPT_SB - 1) / OPT_SB, ntop = nck * OPT_SB;
+    auto step = [&](cplx2 &d, v2f &a, int n) {   // D_{n-1}, A_{n-1} from D_n, A_n
+        const float en = (float)n;
+        const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
+        d = csub2(ny, crecip2(cadd2(d, ny)));
+        const v2f nx = en * s.xinv;
+        a = nx - rcp2(a + nx);
+    };
+    {
+        cplx2 d = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+        v2f a = v2f{0.f, 0.f};
+        // the start must lie above the highest checkpoint (a higher start is only more accurate)
+        const int nstart = s.nmx > ntop + 1 ? s.nmx : ntop + 1;
+        for (int n = nstart; n >= 2; --n) {
+            step(d, a, n);
+            const int n1 = n - 1;
+            if (n1 <= ntop && (n1 & (OPT_SB - 1)) == 0) {
+                const int j = n1 / OPT_SB - 1;
+                *reinterpret_cast<float4 *>(&ck[(size_t)j * OPT_THREADS]) = make_float4(d.re.x, d.re.y, d.im.x, d.im.y);
+                reinterpret_cast<float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1] = make_float2(a.x, a.y);
+            }
+            if (n1 <= OPT_SB) break;
+        }
+    }
+    MieAccF32 A;
+    float sn1, cs1, sn2, cs2;
+    sincosf(s.x.x, &sn1, &cs1);
+    sincosf(s.x.y, &sn2, &cs2);
+    const v2f zero = v2f{0.f, 0.f};
+    A.p = v2f{sn1, sn2}; A.pm = v2f{cs1, cs2}; A.c = A.pm; A.cm = -A.p;
+    A.qs = zero; A.qe = zero; A.gs = zero; A.sgn = -1.f;
+    A.an1 = {zero, zero}; A.bn1 = {zero, zero}; A.xb = {zero, zero};
+    for (int j = 0; j < nck; ++j) {
+        const float4 cd = *reinterpret_cast<const float4 *>(&ck[(size_t)j * OPT_THREADS]);
+        const float2 ca = reinterpret_cast<const float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1];
+        for (int sub = 0; sub < OPT_SB / OPT_MB2; ++sub) {
+            const int nlo = j * OPT_SB + sub * OPT_MB2 + 1;      // first term of this block of OPT_MB2
+            if (nlo > nstopm) break;
+            cplx2 d = {v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};        // D_{SB (j+1)}
+            v2f a = v2f{ca.x, ca.y};
+            for (int n = (j + 1) * OPT_SB; n > nlo + OPT_MB2 - 1; --n) step(d, a, n);   // walk down to the block's top
+            cplx2 dd[OPT_MB2];
+            v2f aa[OPT_MB2];
+            dd[OPT_MB2 - 1] = d; aa[OPT_MB2 - 1] = a;
+#pragma unroll
+            for (int i = OPT_MB2 - 1; i >= 1; --i) {
+                dd[i - 1] = dd[i]; aa[i - 1] = aa[i];
+                step(dd[i - 1], aa[i - 1], nlo + i);
+            }
+#pragma unroll
+            for (int i = 0; i < OPT_MB2; ++i)
+                if (nlo + i <= nstopm) mie_term32_full(A, nlo + i, dd[i], aa[i], s);
+        }
+    }
+    const v2f x2inv = s.xinv * s.xinv;
+    qsca = 2.f * x2inv * A.qs;
+    qext = 2.f * x2inv * A.qe;
+    gasy = v2f{A.qs.x > 0.f ? 2.f * A.gs.x * rcpf(A.qs.x) : 0.f, A.qs.y > 0.f ? 2.f * A.gs.y * rcpf(A.qs.y) : 0.f};
+    qback = x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im);
+}
+
+// particle geometry of one section in fp32; false: the section is empty
+__device__ __forceinline__ bool bin_geometry32(const OpticsKernelArgs &a, int ib, size_t q, size_t sspec, int r4,
+                                               float *vol, float &vwet, float &dwet, float &num)
+{
+    const float pi = 3.14159265358979323846f;
+    float vdry = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+        const int id = a.idx[ib][sp];
+        const float mass = id >= 0 ? fmaxf((float)ldr(a.chem, (size_t)id * sspec + q, r4), 0.f) : 0.f;
+        vol[sp] = mass * rcpf((float)c_opt.dens[sp]);
+        if (sp != OS_WATER) vdry += vol[sp];
+    }
+    const int idn = a.idx[ib][OS_NUM];
+    num = idn >= 0 ? fmaxf((float)ldr(a.chem, (size_t)idn * sspec + q, r4), 0.f) : 0.f;
+    if (!(vdry > 1.e-25f)) return false;
+    vwet = vdry + vol[OS_WATER];
+    const float vpart = vdry * 1.e-6f * rcpf(fmaxf(num, 1.e-30f));   // cm3 per particle
+    float ddry = 1.e4f * cbrtf(vpart * (6.f / pi));
+    const float dlo = (float)c_opt.dlo_um[ib], dhi = (float)c_opt.dhi_um[ib];
+    if (ddry < dlo || ddry > dhi) {
+        ddry = ddry < dlo ? dlo : dhi;
+        const float dcm = ddry * 1.e-4f;
+        num = vdry * 1.e-6f * rcpf((pi / 6.f) * dcm * dcm * dcm);
+    }
+    dwet = ddry * cbrtf(vwet * rcpf(vdry));
+    return true;
+}
+
+__device__ __forceinline__ void optics_body_sw32(const OpticsKernelArgs &a, double2 *s_ck)
+{
+    constexpr int NW = OPT_NSW / 2;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, s = b >> 3;
+    const int gl = s / NW, slot = s - gl * NW;
+    const int w = 2 * slot, w2 = w + 1;
+    double2 *ck = s_ck + threadIdx.x;
+    const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
+    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
+    if (cell >= ncell) return;
+    if (!(a.tauaer[w] || a.extaer[w] || a.bscoef[w])) return;   // the groups are complete or absent
+    const int it = (int)(cell % a.ni_t);
+    const long r = cell / a.ni_t;
+    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
+    const int r4 = a.real4;
+    const float alt = (float)ldr(a.alt, q, r4), dz = (float)ldr(a.dz8w, q, r4);
+    const float pi = 3.14159265358979323846f;
+    const v2f rlam = v2f{rcpf((float)c_opt.wavelength_um[w]), rcpf((float)c_opt.wavelength_um[w2])};
+    const float ralt = rcpf(alt);
+    const v2f zero = v2f{0.f, 0.f};
+    v2f ext = zero, sca = zero, gsca = zero, bsc = zero;   // 1/cm (bsc: 1/(cm sr))
+    for (int ib = 0; ib < a.nbin; ++ib) {
+        float vol[OPT_NSPEC], vwet, dwet, num;
+        if (!bin_geometry32(a, ib, q, sspec, r4, vol, vwet, dwet, num)) continue;
+        const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
+        const float x1 = fminf(pi * dwet * rlam.x, (float)OPT_XMAX), x2 = fminf(pi * dwet * rlam.y, (float)OPT_XMAX);
+        const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
+        v2f qe, qs, g, qb;
+        mie_pair32_full(t12, ck, qe, qs, g, qb);
+        const float dcm = dwet * 1.e-4f;
+        const float cross = (num * ralt * 1.e-6f) * (0.25f * pi * dcm * dcm);   // #/cm3 * cm2
+        ext += cross * qe;
+        sca += cross * qs;
+        gsca += cross * qs * g;
+        bsc += (cross * (0.25f / pi)) * qb;
+    }
+    const float e2[2] = {ext.x, ext.y}, s2[2] = {sca.x, sca.y}, g2[2] = {gsca.x, gsca.y}, b2[2] = {bsc.x, bsc.y};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ww = w + u;
+        if (a.tauaer[ww]) {
+            str(a.tauaer[ww], q, r4, (double)(e2[u] * 100.f * dz));
+            str(a.waer[ww], q, r4, (double)(e2[u] > 0.f ? s2[u] * rcpf(e2[u]) : 0.f));
+            str(a.gaer[ww], q, r4, (double)(s2[u] > 0.f ? g2[u] * rcpf(s2[u]) : 0.f));
+        }
+        if (a.extaer[ww]) str(a.extaer[ww], q, r4, (double)(e2[u] * 1.e5f));
+        if (a.bscoef[ww]) str(a.bscoef[ww], q, r4, (double)(b2[u] * 1.e5f));
+    }
+}
+
 __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, double2 *s_ck)
 {
     constexpr int NW = OPT_NLW / 2;
@@ -635,7 +818,13 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_lw_kernel(const OpticsKern
     optics_body<true>(a, s_ck);
 }
 
-// the mixed-precision path: longwave band pairs in fp32
+// the mixed-precision path: shortwave wavelength pairs and longwave band pairs in fp32
+__global__ void __launch_bounds__(OPT_THREADS) optics_sw32_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
+    optics_body_sw32(a, s_ck);
+}
+
 __global__ void __launch_bounds__(OPT_THREADS) optics_lw32_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
@@ -669,7 +858,10 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
-    if (any_sw) hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
+    if (any_sw && precision == 1)
+        hipLaunchKernelGGL(optics_sw32_kernel, dim3((unsigned)(blocks / 2)), dim3(OPT_THREADS), 0, stream, a);
+    else if (any_sw)
+        hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
     if (any_lw && precision == 1)
         hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
     else if (any_lw)

@@ -110,7 +110,7 @@ CONTAINS
    END SUBROUTINE optical_averaging_hip_init
 
 !------------------------------------------------------------------
-!  mode 0: fp64 throughout (default); 1: "mixed" -- the 16 longwave bands in fp32
+!  mode 0: fp64 throughout (default); 1: "mixed" -- the optical averaging in fp32
    SUBROUTINE optical_averaging_hip_precision(mode)
       INTEGER, INTENT(IN) :: mode
       CHARACTER(kind=c_char) :: err(errlen)
