@@ -374,12 +374,13 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                 cap_cols = (int)(w.doubles / percol);
             }
             k.scratch = w.p;
-        }
-        k.scratch_stride = percol;
-        for (int c0 = 0; c0 < ncol_all; c0 += cap_cols) {
-            k.col0 = c0;
-            k.ncol = ncol_all - c0 < cap_cols ? ncol_all - c0 : cap_cols;
-            HIPCHK(sw_launch(k, stream));
+            // launched under the lock: another host thread on this stream may not resize the buffer in between
+            k.scratch_stride = percol;
+            for (int c0 = 0; c0 < ncol_all; c0 += cap_cols) {
+                k.col0 = c0;
+                k.ncol = ncol_all - c0 < cap_cols ? ncol_all - c0 : cap_cols;
+                HIPCHK(sw_launch(k, stream));
+            }
         }
     }
 

@@ -328,8 +328,10 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             w.doubles = percol * (size_t)cap_cols;
         }
         scratch = w.p;
+        // the gas and transfer kernels of one call hand their batch over through this buffer: host threads that
+        // share a stream enqueue their kernel sequences one call at a time
+        HIPCHK(lw_launch(k, ncol, scratch, cap_cols, stream));
     }
-    HIPCHK(lw_launch(k, ncol, scratch, cap_cols, stream));
 
     if (a->mem != 1) {
         for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
