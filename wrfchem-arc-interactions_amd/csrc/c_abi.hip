@@ -207,7 +207,8 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     }
     const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
     const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk = a->kte - a->kts + 1;
-    if (ni_t <= 0 || nj_t <= 0 || nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
+    if (ni_t <= 0 || nj_t <= 0) return 0;   // an empty tile: the reference's i/j loops do not execute
+    if (nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
         a->jte > a->jme || a->kts < a->kms || a->kte + 1 > a->kme)
         return fail(err, "rrtmg_hip_swrad: inconsistent tile / memory dimensions");
     if (nk + 2 > 64) return fail(err, "rrtmg_hip_swrad: more than 62 model layers are not supported");

@@ -127,7 +127,8 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
         return failo(err, "rrtmg_hip_optical_averaging: aer_op_opt must be 1..4 (5 = shell_exact is not implemented)");
     const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
     const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk_t = a->kte - a->kts + 1;
-    if (ni_t <= 0 || nj_t <= 0 || nk_t <= 0 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
+    if (ni_t <= 0 || nj_t <= 0) return 0;   // an empty tile: the reference's i/j loops do not execute
+    if (nk_t <= 0 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
         a->jte > a->jme || a->kts < a->kms || a->kte > a->kme)
         return failo(err, "rrtmg_hip_optical_averaging: inconsistent tile / memory dimensions");
     if (a->num_chem < 1) return failo(err, "rrtmg_hip_optical_averaging: num_chem must be positive");
