@@ -112,6 +112,9 @@ typedef struct rrtmg_hip_swrad_args {
     const void *lradius, *iradius;
 } rrtmg_hip_swrad_args;
 
+/* Returns 0, or non-zero with a message in err[RRTMG_HIP_ERRLEN].  An empty tile (ite < its or jte < jts) returns 0
+ * without touching any array, like the tile loops of RRTMG_SWRAD; the same holds for rrtmg_hip_lwrad and
+ * rrtmg_hip_optical_averaging.  Host threads may call concurrently (one call's kernels are enqueued at a time). */
 int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *args, char *err);
 
 /* mem = 1 calls do not synchronise; this does (hipDeviceSynchronize), and
