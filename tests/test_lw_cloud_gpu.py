@@ -35,7 +35,7 @@ def _init(wa, lw_table_file, nk):
 
 
 @pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 1, False), (5, 4, 50, 2, True), (4, 3, 28, 3, False),
-                                                 (3, 3, 60, 4, True)])
+                                                 (3, 3, 60, 4, True), (4, 3, 100, 5, True)])
 def test_cloudy_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed, radii):
     eng, nlay = _init(wa, lw_table_file, nk)
     st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260500 + seed)
@@ -47,7 +47,9 @@ def test_cloudy_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, 
     cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
     assert cloudy.any() and (~cloudy).any()
     # clouds trap longwave: OLR below its clear-sky value, positive cloud forcing; cloud-free columns untouched
-    assert (got["lwcf"][cloudy] >= 0).all() and got["lwcf"][cloudy].max() > 1.0
+    # (the 100-layer case reaches into the synthetic stratosphere, where a thin cloud sits in warmer air than the
+    # layers below it and the forcing may turn slightly negative)
+    assert (got["lwcf"][cloudy] >= (0 if nk <= 64 else -1.0)).all() and got["lwcf"][cloudy].max() > 1.0
     np.testing.assert_array_equal(got["lwupt"][~cloudy], got["lwuptc"][~cloudy])
     assert (got["lwcf"][~cloudy] == 0).all()
     assert (got["olr"] == got["lwupt"]).all() and (got["glw"] == got["lwdnb"]).all()

@@ -33,7 +33,7 @@ def _init(wa, lw_table_file, nk):
     return eng, eng.lw_nlayers(nk + 1, P_TOP)
 
 
-@pytest.mark.parametrize("ni,nj,nk,seed", [(8, 5, 40, 1), (4, 3, 50, 2), (3, 2, 28, 3), (3, 2, 60, 4)])
+@pytest.mark.parametrize("ni,nj,nk,seed", [(8, 5, 40, 1), (4, 3, 50, 2), (3, 2, 28, 3), (3, 2, 60, 4), (3, 2, 100, 5)])
 def test_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed):
     eng, nlay = _init(wa, lw_table_file, nk)
     assert nlay == nk + 13

@@ -20,7 +20,7 @@ def _init(wa, sw_table_file):
 
 
 @pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 1, False), (5, 4, 50, 2, True), (4, 3, 28, 3, False),
-                                                 (3, 3, 60, 4, True)])
+                                                 (3, 3, 60, 4, True), (4, 3, 100, 5, False)])
 def test_cloudy_swrad_matches_oracle(hip_lib, wa, sw_table_file, sw_oracle, ni, nj, nk, seed, radii):
     eng = _init(wa, sw_table_file)
     st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260400 + seed, night_fraction=0.1)

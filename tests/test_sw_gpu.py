@@ -31,7 +31,7 @@ def _check(got, ref):
     return worst
 
 
-@pytest.mark.parametrize("ni,nj,nk,seed", [(8, 6, 40, 1), (5, 3, 50, 2), (3, 2, 28, 3), (4, 2, 60, 4)])
+@pytest.mark.parametrize("ni,nj,nk,seed", [(8, 6, 40, 1), (5, 3, 50, 2), (3, 2, 28, 3), (4, 2, 60, 4), (3, 2, 100, 5)])
 def test_swrad_matches_oracle(eng, sw_oracle, wa, ni, nj, nk, seed):
     st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260100 + seed, night_fraction=0.15)
     got = run_hip_swrad(eng, st, device=True)

@@ -211,7 +211,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     if (nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
         a->jte > a->jme || a->kts < a->kms || a->kte + 1 > a->kme)
         return fail(err, "rrtmg_hip_swrad: inconsistent tile / memory dimensions");
-    if (nk + 2 > 64) return fail(err, "rrtmg_hip_swrad: more than 62 model layers are not supported");
+    if (nk + 1 > 128) return fail(err, "rrtmg_hip_swrad: more than 127 model layers are not supported");
     if (a->aer_ra_feedback == 1 &&
         !(a->tauaer300 && a->tauaer400 && a->tauaer600 && a->tauaer999 && a->gaer300 && a->gaer400 && a->gaer600 &&
           a->gaer999 && a->waer300 && a->waer400 && a->waer600 && a->waer999))

@@ -228,7 +228,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     k.status = static_cast<int *>(st.dStatus);
     k.icloud = a->icloud;
     if (a->icloud != 0) {
-        if (nk > 64) return failw(err, "rrtmg_hip_lwrad: icloud /= 0 supports at most 64 model layers");
+        if (nk > 128) return failw(err, "rrtmg_hip_lwrad: icloud /= 0 supports at most 128 model layers");
         if (nk < 4) return failw(err, "rrtmg_hip_lwrad: the McICA seeds need at least four layers");
         k.has_reqc = a->has_reqc; k.has_reqi = a->has_reqi; k.has_reqs = a->has_reqs;
         k.warm_rain = a->warm_rain; k.progn = a->progn; k.grav = a->g;

@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
 
 // Kernel 2 of 2: radiative transfer (rtrnmc) for the clean and the aerosol optical depths, lanes = g-points;
 // flux profiles, heating rate and the WRF output fields.
-__global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) lw_rt_kernel(const LwKernelArgs a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
@@ -928,8 +928,9 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     }
     // cloud part of the record: cldf clwp ciwp cswp fliq fice fsno iliq iice isno [nl] each, seeds[4]
     const double *cb = lds + lw_rec_base_doubles(nl);
-    __shared__ unsigned long long s_lmask;
-    if (tid == 0) s_lmask = 0ull;
+    __shared__ unsigned long long s_lmask[2];       // layers 0..63, 64..127
+    __shared__ unsigned long long s_cmhi[LW_THREADS];   // each lane's cloud bits of layers 64..127
+    if (tid == 0) { s_lmask[0] = 0ull; s_lmask[1] = 0ull; }
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
     const size_t i2 = j0 * a.ni_m + i0;
@@ -957,6 +958,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
     // model layers (the buffer layers above carry none); lmask = layers in which any sub-column is cloudy
     // (icldlyr, LW:3163-3186) -- those take the "cloudy layer" arithmetic for every g-point.
     uint64_t cmask = 0;
+    const bool deep = nk > 64;
     int iceflag = 3;
     if (a.icloud != 0) {
         if (a.has_reqi != 0) iceflag = 4;
@@ -965,23 +967,33 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
                         (uint32_t)(int)cb[10 * nl + 3]};
         kiss_jump(ks, a.jump + (size_t)g * KISS_JUMP_WORDS);
         double prev = 0.;
+        uint64_t cmhi = 0;
         for (int l = 0; l < nk; ++l) {
             double cur = kiss_next(ks);
             if (l > 0) {
                 const double cbl = cb[l - 1];
                 cur = prev > 1. - cbl ? prev : cur * (1. - cbl);
             }
-            if (cur >= 1. - cb[l]) cmask |= (uint64_t)1 << l;
+            if (cur >= 1. - cb[l]) {
+                if (l < 64) cmask |= (uint64_t)1 << l; else cmhi |= (uint64_t)1 << (l - 64);
+            }
             prev = cur;
         }
         uint64_t m = active ? cmask : 0;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
-        if (lane == 0 && m) atomicOr(&s_lmask, (unsigned long long)m);
+        if (lane == 0 && m) atomicOr(&s_lmask[0], (unsigned long long)m);
+        if (deep) {
+            s_cmhi[tid] = cmhi;
+            m = active ? cmhi : 0;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
+            if (lane == 0 && m) atomicOr(&s_lmask[1], (unsigned long long)m);
+        }
         __syncthreads();
     }
-    const uint64_t lmask = a.icloud != 0 ? (uint64_t)s_lmask : 0;
-    const bool col_cloudy = lmask != 0;
+    const uint64_t lmask = a.icloud != 0 ? (uint64_t)s_lmask[0] : 0;
+    const bool col_cloudy = lmask != 0 || (a.icloud != 0 && deep && s_lmask[1] != 0);
     int bad = 0;
 
     // ---- downward sweep (top -> surface), LW:3207-3312 ----
@@ -993,7 +1005,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
         const double taug = tnext, plfrac = fnext;
         if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-        const bool lay_cld = k < 64 && ((lmask >> k) & 1);
+        const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
             double at, bbd, bbu;
             layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
@@ -1006,7 +1018,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
             }
         } else {
             iclddn = true;
-            const bool cl = (cmask >> k) & 1;
+            const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
             const double cfm = cl ? 1. : 0.;
             double odcld = 0., efcl = 0.;
             if (cl) {
@@ -1052,7 +1064,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
         const double taug = tnext, plfrac = fnext;
         if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-        const bool lay_cld = k < 64 && ((lmask >> k) & 1);
+        const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
             double at, bbd, bbu;
             layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
@@ -1064,7 +1076,7 @@ __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a)
                 radlu_c = relax(radlu_c, bbu, at);
             }
         } else {
-            const bool cl = (cmask >> k) & 1;
+            const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
             const double cfm = cl ? 1. : 0.;
             double odcld = 0., efcl = 0.;
             if (cl) {

@@ -217,6 +217,7 @@ struct ColView {
     double *cldf, *clwp, *ciwp, *cswp, *fliq, *fice, *fsno;
     int *iliq, *iice, *isno;   // table indices (1-based as in cldprmc_sw), 0 = size out of bounds
     int *seeds;                // [4] KISS seeds of the column
+    uint64_t *cmhi;            // [NTHREADS] McICA cloud bits of layers 64.. of each lane's sub-column
     int nlp;            // padded layer count (multiple of BLK)
 };
 
@@ -235,6 +236,7 @@ __device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nle
     v.fluxc = p; p += 2 * nlev * 2;
     v.cldf = p; p += nlp; v.clwp = p; p += nlp; v.ciwp = p; p += nlp; v.cswp = p; p += nlp;
     v.fliq = p; p += nlp; v.fice = p; p += nlp; v.fsno = p; p += nlp;
+    v.cmhi = reinterpret_cast<uint64_t *>(p); p += NTHREADS;
     int *q = reinterpret_cast<int *>(p);
     v.rb0 = q; q += nlp; v.rb1 = q; q += nlp; v.inds = q; q += nlp; v.indf = q; q += nlp; v.jp = q; q += nlp + 1;
     v.iliq = q; q += nlp; v.iice = q; q += nlp; v.isno = q; q += nlp; v.seeds = q; q += 4;
@@ -842,7 +844,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
 
     // McICA: this lane's sub-column of binary cloud (generate_stochastic_clouds_sw, SW:1737-1772, icld = 2):
     // bit k of cmask = cloudy in layer k.  The lane jumps the column's KISS sequence to its own nlay draws.
-    uint64_t cmask = 0;
+    uint64_t cmask = 0, cmhi = 0;
     int iceflag = 3;
     if (a.icloud != 0) {
         if (a.has_reqi != 0) iceflag = 4;
@@ -856,11 +858,14 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                 const double cb = c.cldf[l - 1];
                 cur = prev > 1. - cb ? prev : cur * (1. - cb);
             }
-            if (cur >= 1. - c.cldf[l]) cmask |= (uint64_t)1 << l;
+            if (cur >= 1. - c.cldf[l]) {
+                if (l < 64) cmask |= (uint64_t)1 << l; else cmhi |= (uint64_t)1 << (l - 64);
+            }
             prev = cur;
         }
+        if (nlay > 64) c.cmhi[tid] = cmhi;
     }
-    const int col_cloudy = a.icloud != 0 ? __syncthreads_or(cmask != 0) : 0;
+    const int col_cloudy = a.icloud != 0 ? __syncthreads_or((cmask | cmhi) != 0) : 0;
 
     const double prmu0 = coszrs <= 1.e-10 ? 1.e-10 : coszrs;   // SW:9254-9255
     // solar source at the layer selected per band (SW:3363-3380, 3533-3538, 4297) -> incoming flux
@@ -913,7 +918,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
 
     // One spcvmc_sw pass of this wave's 56 sub-columns: aer_on = with aerosol optical depth, mask = the
     // sub-column's cloudy layers (0: clear sky).  Fluxes per level go to flux[2l], flux[2l+1].
-    auto run_pass = [&](const bool aer_on, const uint64_t mask, double *flux, const bool want_sfc) {
+    auto run_pass = [&](const bool aer_on, const bool cld_on, const uint64_t mask, double *flux, const bool want_sfc) {
         // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
         double rup = albp, rupd = albd;
         GasPre gp;
@@ -930,7 +935,8 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             }
             RT rt;
             double dnl = 1.;
-            layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dnl, gp, (mask >> k) & 1, iceflag, a.cldtab, &bad);
+            layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dnl, gp,
+                     k < 64 ? (mask >> k) & 1 : (cld_on ? (c.cmhi[tid] >> (k - 64)) & 1 : 0), iceflag, a.cldtab, &bad);
             gp = gn;
             {   // keep the layer's two-stream result for the way down
                 double *s = scr + (size_t)k * SW_SCR_VALS * 64;
@@ -1019,7 +1025,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     for (int r = 0; r < nround; ++r) {
         if (r == 1) __syncthreads();
         const bool run = r == 0 ? !(pass == 1 && a.clean <= 0) : pass == 0;
-        if (run) run_pass(r == 0 ? pass == 0 : true, r == 0 ? cmask : 0, r == 0 ? flux : c.fluxc + (size_t)wave * nlev * 2,
+        if (run) run_pass(r == 0 ? pass == 0 : true, r == 0 && a.icloud != 0 && nlay > 64, r == 0 ? cmask : 0, r == 0 ? flux : c.fluxc + (size_t)wave * nlev * 2,
                           r == 0 && pass == 0);
     }
     if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
@@ -1098,7 +1104,7 @@ size_t sw_lds_bytes(int nk)
 {
     const int nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
-    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)6 * nlev * 2 + 32;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)6 * nlev * 2 + 32 + NTHREADS;
     size_t ni = (size_t)nlp * 8 + 1 + 4;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
