@@ -911,7 +911,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
 
 // Kernel 2 of 2: radiative transfer (rtrnmc) for the clean and the aerosol optical depths, lanes = g-points;
 // flux profiles, heating rate and the WRF output fields.
-__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) lw_rt_kernel(const LwKernelArgs a)
+template <bool DEEP>   // DEEP: McICA clouds in more than 64 model layers (the bits of layers 64.. live in LDS)
+__device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
@@ -958,7 +959,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     // model layers (the buffer layers above carry none); lmask = layers in which any sub-column is cloudy
     // (icldlyr, LW:3163-3186) -- those take the "cloudy layer" arithmetic for every g-point.
     uint64_t cmask = 0;
-    const bool deep = nk > 64;
+    constexpr bool deep = DEEP;
     int iceflag = 3;
     if (a.icloud != 0) {
         if (a.has_reqi != 0) iceflag = 4;
@@ -1143,6 +1144,10 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+__global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a) { lw_rt_body<false>(a); }
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
+
 // ---------------------------------------------------------------------------
 size_t lw_gas_lds_bytes(int nl)
 {
@@ -1210,9 +1215,13 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
     if (lds_rt > attr_rt && lds_rt > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_deep_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
         if (e != hipSuccess) return e;
         attr_rt = lds_rt;
     }
+    const bool deep = a.icloud != 0 && a.nk > 64;
     if (!scratch || cap_cols <= 0) return hipErrorInvalidValue;
     a.taug = scratch;
     a.frac = a.taug + (size_t)cap_cols * nl * LW_NGPT;
@@ -1221,7 +1230,8 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         const int n = ncol - c0 < cap_cols ? ncol - c0 : cap_cols;
         a.col0 = c0;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
-        hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+        if (deep) hipLaunchKernelGGL(lw_rt_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+        else hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
     }
     return hipGetLastError();
 }
