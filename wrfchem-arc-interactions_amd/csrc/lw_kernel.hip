@@ -506,8 +506,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
     const size_t i2 = j0 * a.ni_m + i0;
-    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m, sjf = (size_t)a.ni_m * (a.nk_m + 2);
-    const size_t base3 = j0 * sj + k0 * sk + i0, base3f = j0 * sjf + k0 * sk + i0;
+    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
+    const size_t base3 = j0 * sj + k0 * sk + i0;
     const int r4 = a.real4;
     const double tbound = ldr(a.tsk, i2, r4);
     const double semiss = ldr(a.emiss, i2, r4);   // same emissivity in all 16 bands, LW:12296-12298
