@@ -1103,7 +1103,7 @@ size_t sw_scratch_doubles_per_column(int nk)
 size_t sw_lds_bytes(int nk)
 {
     const int nlay = nk + 1, nlev = nlay + 1;
-    const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
+    const int nlp = (nlay + BLK - 1) / BLK * BLK;
     size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)6 * nlev * 2 + 32 + NTHREADS;
     size_t ni = (size_t)nlp * 8 + 1 + 4;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
