@@ -252,9 +252,13 @@ int oracle_cloud_state(const OracleCloudWrf *w, double *cldfrac, double *clwp, d
         for (int k = 0; k < nk; ++k) {
             const double s3 = w->qs ? w->qs[k] : 0.;
             qi1d[k] = fmax(0., 0.1 * s3); qs1d[k] = 0.9 * s3;
+            qc1d[k] = w->qc ? fmax(0., w->qc[k]) : 0.;   /* qc1d = qc3d again, SW:10467 / LW:12009 */
         }
     if (w->fer_hires)   /* qi3d saves all frozen water, SW:10474-10492 (LW:12016-12034) */
-        for (int k = 0; k < nk; ++k) { qi1d[k] = w->qi ? fmax(0., w->qi[k]) : 0.; qs1d[k] = 0.0; }
+        for (int k = 0; k < nk; ++k) {
+            qi1d[k] = w->qi ? fmax(0., w->qi[k]) : 0.; qs1d[k] = 0.0;
+            qc1d[k] = w->qc ? fmax(0., w->qc[k]) : 0.;   /* SW:10487 / LW:12029 */
+        }
     int inflg = 2, iceflg = 3, liqflg = 1;
     for (int k = 0; k < nk; ++k) {
         const double cf3 = w->cldfra ? w->cldfra[k] : 0.;

@@ -39,6 +39,19 @@ def test_cloudy_swrad_matches_oracle(hip_lib, wa, sw_table_file, sw_oracle, ni, 
     assert (got["swcf"][clear] == 0).all() and (got["swcf"][cloudy] != 0).any()
 
 
+@pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 11, False), (5, 4, 50, 12, True), (4, 3, 100, 15, False)])
+def test_cloudy_swrad_without_profiles_matches_oracle(hip_lib, wa, sw_table_file, sw_oracle, ni, nj, nk, seed, radii):
+    """The call the driver makes (no layer-flux profiles): total-sky clean and clear-sky fluxes composed in the
+    upward sweeps instead of stored and swept down."""
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260400 + seed, night_fraction=0.1)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260410 + seed, cloudy_fraction=0.6, with_radii=radii)
+    got = run_hip_swrad(eng, st, cloud=cloud, profiles=False)
+    ref = run_oracle_swrad(sw_oracle, st, cloud=cloud, profiles=False)
+    worst = compare_sw(got, ref, RTOL, ATOL)
+    assert worst < 1e-8
+
+
 def test_cloudy_tile_subset_host_mode_and_no_clean(hip_lib, wa, sw_table_file, sw_oracle):
     eng = _init(wa, sw_table_file)
     st = wa.synth.make_wrf_state(9, 7, 40, seed=20260420)
@@ -85,7 +98,7 @@ def test_cloud_refusals_and_fatal_sizes(hip_lib, wa, sw_table_file):
 
 def test_cloudy_full_size_properties_200x200x40(hip_lib, wa, sw_table_file):
     """BASELINE size with cloud in a fifth of the columns: size-independent properties -- the clear-sky fluxes of a
-    cloudy run are the total-sky fluxes of the same state run without cloud (bitwise), cloud-free columns are
+    cloudy run are the total-sky fluxes of the same state run without cloud, cloud-free columns are
     untouched by icloud, and a permutation of the columns permutes the results (the McICA seeds depend on the column's
     own pressures only)."""
     eng = _init(wa, sw_table_file)
@@ -100,10 +113,14 @@ def test_cloudy_full_size_properties_200x200x40(hip_lib, wa, sw_table_file):
     for n in got:
         if got[n].ndim == 2:
             assert np.isfinite(got[n][day]).all(), n
+    # clear-sky fluxes of the cloudy run = total-sky fluxes of the cloud-free run, and cloud-free columns are untouched
+    # by icloud -- to rounding, not bitwise: icloud = 0 and icloud /= 0 are two kernel instantiations (FMA contraction
+    # differs), and in cloudy columns the clear-sky fluxes are composed in the upward sweep
     for c, t in (("swuptc", "swupt"), ("swdnbc", "swdnb"), ("swupbc", "swupb")):
-        np.testing.assert_array_equal(got[c][day], base[t][day], err_msg=c)
+        np.testing.assert_allclose(got[c][day], base[t][day], rtol=1e-11, atol=1e-11, err_msg=c)
+        np.testing.assert_array_equal(got[c][clear], got[t][clear], err_msg=c)      # a copy in cloud-free columns
     for n in ("swupt", "swdnb", "swuptcln", "gsw"):
-        np.testing.assert_array_equal(got[n][clear], base[n][clear], err_msg=n)
+        np.testing.assert_allclose(got[n][clear], base[n][clear], rtol=1e-11, atol=1e-11, err_msg=n)
     assert (got["swcf"][clear] == 0).all()
     # cloud reflects: more upward flux at the top and less sunlight at the surface in most cloudy columns (McICA
     # samples one cloud state per g-point, so single columns may go either way)
@@ -143,3 +160,13 @@ def test_cloud_microphysics_variants(hip_lib, wa, sw_table_file, sw_oracle, vari
     base = run_hip_swrad(eng, st, cloud=plain)
     day = st.a2["xcoszen"] > 0
     assert np.abs(got["swupt"] - base["swupt"])[day].max() > 1e-3     # the variant matters
+    if variant in ("f_ice_phy", "fer_hires"):
+        # both blocks read the cloud water again (qc1d = qc3d, SW:10467 / 10487), which undoes the "T < 273.15: all
+        # condensate is ice" rule for supercooled liquid: the fixture has such cells and they must count
+        cold = (st.a3["t3d"] < 273.15) & (st.a3["qc3d"] > 0) & (st.a3["cldfra3d"] > 0)
+        assert cold.sum() > 5
+        keep = st.a3["qc3d"].copy()
+        st.a3["qc3d"] = np.where(cold, 0.0, keep)
+        dry = run_hip_swrad(eng, st, cloud=cloud)
+        st.a3["qc3d"] = keep
+        assert np.abs(got["swupt"] - dry["swupt"])[day].max() > 1e-3

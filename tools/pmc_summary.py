@@ -34,7 +34,11 @@ def main():
                 k = r["Kernel_Name"]
                 if "rrtmg::" not in k:
                     continue
-                k = k.replace("(anonymous namespace)::", "").split("(")[0]
+                # "void rrtmg::sw_column_kernel<false, false>(rrtmg::SwKernelArgs)" -> "rrtmg::sw_column_kernel":
+                # the instantiations of one kernel (icloud, profile outputs) are reported under one name
+                k = k.replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+                if k.startswith("void "):
+                    k = k[5:]
                 sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnts[k][r["Counter_Name"]] += 1
                 meta[k] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],

@@ -689,9 +689,11 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (a.f_ice_phy) {        // "MP option 5": one frozen species carried as snow, LW:12003-12014
                     const double s3 = a.qs3d ? ldr(a.qs3d, q, r4) : 0.;
                     qi = fmax(0., 0.1 * s3); qs = 0.9 * s3;
+                    qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;   // qc1d = qc3d again, LW:12009
                 }
                 if (a.fer_hires) {        // Ferrier-Aligo: qi3d holds all frozen water, LW:12016-12034
                     qi = a.qi3d ? fmax(0., ldr(a.qi3d, q, r4)) : 0.; qs = 0.0;
+                    qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;   // LW:12029
                 }
                 cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
                 const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;

@@ -7,27 +7,37 @@
 // SW:7922-8046, rrtmg_sw post-processing SW:9391-9486, outputs SW:11125-11197.
 //
 // Mapping (MI355X-first, not the reference's loop nest):
-//   * one 256-thread workgroup per daylit column; blockIdx is remapped so that
-//     the workgroups of one XCD walk consecutive i (they share the 64-B sectors
-//     of the (i,k,j) state in that XCD's L2).
+//   * one 128-thread workgroup (two wavefronts) per daylit column; blockIdx is
+//     remapped so that the workgroups of one XCD walk consecutive i (they share
+//     the 64-B sectors of the (i,k,j) state in that XCD's L2).
 //   * prologue: lanes = layers.  Gathers the column, builds the 1-D profile,
 //     O3 climatology, column amounts and the setcoef interpolation factors once
 //     and leaves them in LDS; aerosol wavelength->band mapping into LDS.
-//   * main phase: lanes = g-points.  Wave w handles g-chunk (w&1) of pass
-//     (w>>1): pass 0 = with aerosol, pass 1 = clean sky.  Gas optics are
-//     evaluated by one data-driven formula (per-g descriptor) so the 14 bands
-//     never diverge; its table reads are issued one layer ahead.  The vertical
-//     adding recurrence is sequential in k per lane.  The upward sweep writes
-//     each layer's two-stream result (5-6 doubles per lane) and every 4th level
-//     of the recurrence to the column's scratch slice in HBM (coalesced 512-B
-//     rows, 590 KB per column at 41 layers); the downward sweep reads them back
-//     block by block instead of evaluating the layers a second time.  That
-//     trades 37 GB of streaming per 40 000 columns for 45 % of the fp64
-//     instructions and frees the LDS the checkpoints took, so three workgroups
-//     fit on a CU (measured: 15.5 -> 12.0 ms).
-//   * per-level spectral sums (SW:8629-8634) are wave reductions; the two
-//     chunk waves of a pass meet in LDS; the epilogue (lanes = levels) forms
-//     net fluxes, heating rates and writes the WRF arrays.
+//   * main phase: lanes = g-points, wave w = g-chunk w (56 g-points).  A lane
+//     carries BOTH calls of its g-point through one upward sweep: the gas
+//     optics (one data-driven formula per g-point descriptor, so the 14 bands
+//     never diverge; table reads issued one layer ahead) are evaluated once and
+//     feed two streams:
+//       P  the call with aerosol.  Its fluxes are needed at every level
+//          (heating rates), so each layer's two-stream result (5 doubles per
+//          lane) and every 4th level of the upward recurrence go to the
+//          column's scratch slice in HBM (coalesced 512-B rows) and the
+//          downward sweep reads them back block by block (vrtqdr_sw as the
+//          reference orders it).
+//       S  the clean-sky call.  RRTMG_SWRAD uses only its TOA and surface
+//          fluxes (SW:11140-11150; the layer-flux profiles are optional
+//          arguments the patched radiation_driver does not receive), and those
+//          follow from the two-stream properties of the whole atmosphere.  The
+//          adding step is associative, so the same upward sweep composes them
+//          layer by layer (reflectance from above and below, total / diffuse /
+//          direct transmittance): no second sweep, nothing stored.
+//     A cloudy column runs a second, S-only sweep for the clear-sky fluxes of
+//     the aerosol call.  When the optional flux profiles are requested every
+//     call runs as a P stream (kernel instantiation PROF).
+//   * per-level spectral sums (SW:8629-8634) are wave reductions of eight
+//     values at a time (v_permlane32_swap / v_permlane16_swap butterflies, then
+//     DPP row steps); the two chunk waves meet in LDS; the epilogue (lanes =
+//     levels) forms net fluxes, heating rates and writes the WRF arrays.
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
@@ -41,10 +51,12 @@ namespace rrtmg {
 
 namespace {
 
-constexpr int SW_SCR_VALS = 6;     // ref, refd, tra, trad, dbt, dbt_nodel per (layer, lane)
+constexpr int SW_SCR_VALS = 5;     // ref, refd, tra, trad, dbt per (layer, lane)
 constexpr int BLK = 4;            // levels between checkpoints of the upward sweep = layers per block on the way down
 constexpr int CHUNK = 56;         // g-points per wave (112 = 2 x 56)
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS = 128;     // two waves: g-chunks 0 and 1
+constexpr int NWAVE = NTHREADS / 64;
+constexpr int SW_WAVES_PER_SIMD = 3; // register budget: 12 waves per CU
 
 // reference atmosphere, SW:3019-3045 (preflog is 6.96 - 0.2*i)
 __constant__ double c_tref[59] = {
@@ -81,54 +93,101 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
     else reinterpret_cast<double *>(p)[idx] = v;
 }
 
-// One step of a wave reduction in the VALU (data-parallel primitive, no LDS round trip): v + v moved by `ctrl`;
-// rows not selected by row_mask receive 0.
-template <int CTRL, int ROW_MASK>
+// ---- wave reductions in the VALU (data-parallel primitives, no LDS round trip) ----
+// gfx950 lane-swap instructions: after swap32(a, b) a = [a.lanes0-31, b.lanes0-31], b = [a.lanes32-63, b.lanes32-63];
+// after swap16(a, b) a = rows [a0, b0, a2, b2], b = rows [a1, b1, a3, b3] (row = 16 lanes).  a + b then holds the
+// pairwise-folded partial sums of BOTH inputs: two values are folded for the price of one.
+typedef unsigned sw_uint2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fold32(double a, double b)
+{
+    const sw_uint2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const sw_uint2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+__device__ __forceinline__ double fold16(double a, double b)
+{
+    const sw_uint2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const sw_uint2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v)
 {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int mlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-    const int mhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    const int mlo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int mhi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
     return v + __hiloint2double(mhi, mlo);
 }
-// sum over the 64 lanes, valid in lane 63: pairs inside quads, quads inside half rows, half rows, rows
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror, row_bcast15, row_bcast31)
-__device__ __forceinline__ double wave_sum_l63(double v)
+// sum inside each row of 16 lanes, valid in every lane (row_mirror, row_half_mirror, quad_perm [2,3,0,1], [1,0,3,2])
+__device__ __forceinline__ double row_sum(double v)
 {
-    v = dpp_add<0xB1, 0xF>(v);
-    v = dpp_add<0x4E, 0xF>(v);
-    v = dpp_add<0x141, 0xF>(v);
-    v = dpp_add<0x140, 0xF>(v);
-    v = dpp_add<0x142, 0xA>(v);
-    v = dpp_add<0x143, 0xC>(v);
+    v = dpp_add<0x140>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0xB1>(v);
     return v;
 }
+// wave sums of four values: the result's row r (lanes 16r..16r+15) holds the sum of v[WSUM_ROW(r)]
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3)
+{
+    return row_sum(fold16(fold32(v0, v1), fold32(v2, v3)));   // rows: v0, v2, v1, v3
+}
+__device__ __forceinline__ int wsum_index(int row) { return ((row & 1) << 1) | (row >> 1); }
 
 // Reciprocal / quotient without the IEEE special-case scaffolding of the compiler's fp64 division
-// (v_div_scale x2, v_div_fmas, v_div_fixup): v_rcp_f64 seed, two Newton steps, one residual
-// correction.  Operands on this path are normal-range and non-zero (the reference guards its own
-// denominators with max(.,1e-30)); the result agrees with IEEE division to <= 1 ulp.
-__device__ __forceinline__ double frcp(double b)
+// (v_div_scale x2, v_div_fmas, v_div_fixup).  Operands on this path are normal-range and non-zero (the reference
+// guards its own denominators with max(.,1e-30)).  Measured on MI355X over 4 M random operand pairs
+// (tools/probes/rcp_probe.hip): v_rcp_f64 is good to 2^-24.4; one Newton step brings the reciprocal to 2.2e-15 and
+// the quotient with its residual correction to the correctly rounded result in every case.
+// frcp: two Newton steps (1.1e-16).  frcp1: one step (2.2e-15), for factors of physical quantities only.
+// fdiv: reciprocal with one step + residual correction -- used wherever an integer is cut from the quotient (table
+// indices), so that the index is the reference's.
+__device__ __forceinline__ double frcp1(double b)
 {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = frcp1(b);
+    double e = __builtin_fma(-b, r, 1.0);
     return __builtin_fma(r, e, r);
 }
 __device__ __forceinline__ double fdiv(double a, double b)
 {
-    double r = frcp(b);
+    double r = frcp1(b);
     double q = a * r;
     double rem = __builtin_fma(-b, q, a);
     return __builtin_fma(rem, r, q);
 }
+// square root of a positive normal-range number: v_rsq_f64 seed, two coupled Newton steps (Goldschmidt form) and a
+// residual correction; correctly rounded in all but rare cases (<= 1 ulp), without the scaling scaffolding of the
+// compiler's expansion
+__device__ __forceinline__ double fsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
 
-// transmittance by lookup table or small-argument expansion (SW:8459-8466, 2575-2581)
+// transmittance by lookup table or small-argument expansion (SW:8459-8466, 2575-2581).  The index arithmetic is kept
+// out of FMA contraction: the reference rounds 1e4*tblind before it adds 0.5.
 __device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze1)
 {
-    double tblind = fdiv(ze1, tb.bpade + ze1);
-    int itind = (int)(10000.0 * tblind + 0.5);
+    int itind;
+    {
+#pragma clang fp contract(off)
+        const double tblind = fdiv(ze1, tb.bpade + ze1);
+        const double x = 10000.0 * tblind;
+        itind = (int)(x + 0.5);
+    }
     itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
     double tv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.exp_tbl) + (uint32_t)itind * 8u);
     double sv = 1. - ze1 + 0.5 * ze1 * ze1;
@@ -161,7 +220,7 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
         double za = zgamma1 * prmuz;
         double za1 = za - zgamma3;
         double zgt = zgamma1 * zto1;
-        double rg = frcp(1. + zgt);
+        double rg = frcp1(1. + zgt);
         double r = (zgt - za1 * (1. - zem2)) * rg;
         double rd = zgt * rg;
         bool one = (zem2 == 1.0);
@@ -172,7 +231,7 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
     } else {
         double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
         double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
-        double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        double zrk = fsqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
         double zrp = zrk * prmuz;
         double zrp1 = 1. + zrp;
         double zrm1 = 1. - zrp;
@@ -190,18 +249,17 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
         double zem1 = exp_lookup(tb, fmin(zrk * zto1, 500.));
         double zemm = zem1 * zem1;
         double D = zr4 + zr5 * zemm;                 // zdenr * zem1
-        double rD = frcp(D);
+        double rD = frcp1(D);
         bool small = fabs(D) <= eps * zem1;          // |zdenr| <= eps, SW:2679
         double r = zw * (zr1 - zr2 * zemm - zr3 * (zem2 * zem1)) * rD;
         double t = zem2 - zw * (zem2 * (zt1 - zt2 * zemm) - zt3 * zem1) * rD;
         o.ref = small ? eps : r;
         o.tra = small ? zem2 : t;
-        double zdend = frcp(zrkg - (zgamma1 - zrk) * zemm);
+        double zdend = frcp1(zrkg - (zgamma1 - zrk) * zemm);
         o.refd = zgamma2 * (1. - zemm) * zdend;
         o.trad = zrk2 * zem1 * zdend;
     }
 }
-
 // LDS image of one column (all arrays indexed by 0-based layer, bottom -> top)
 struct ColView {
     double *fac00, *fac01, *fac10, *fac11;
@@ -210,18 +268,22 @@ struct ColView {
     double *colmol, *pdp;
     double *taer, *waer, *gaer;   // [14][nlp]
     int *rb0, *rb1, *inds, *indf, *jp;   // row bases (0-based), continuum rows, jp
-    double *flux;       // [4 waves][nlev][2]
-    double *sfc;        // [4 waves][8] surface-only sums
-    double *fluxc;      // [2 waves][nlev][2] clear-sky (aerosol) fluxes of a cloudy column
-    // in-cloud state per layer (icloud != 0): cloud fraction, liquid / ice / snow water path, table fractions
+    double *flux;       // [NWAVE][nlp + 1][2] level fluxes of the P stream (call with aerosol)
+    double *sums;       // [NWAVE][SUMS_N] surface / TOA sums of the waves (SUM_* slots)
+    double *fluxc;      // PROF: [NWAVE][nlp + 1][2] clean-sky profile
+    double *fluxk;      // PROF and CLOUD: [NWAVE][nlp + 1][2] clear-sky profile of a cloudy column
+    // in-cloud state per layer (CLOUD): cloud fraction, liquid / ice / snow water path, table fractions
     double *cldf, *clwp, *ciwp, *cswp, *fliq, *fice, *fsno;
     int *iliq, *iice, *isno;   // table indices (1-based as in cldprmc_sw), 0 = size out of bounds
     int *seeds;                // [4] KISS seeds of the column
     uint64_t *cmhi;            // [NTHREADS] McICA cloud bits of layers 64.. of each lane's sub-column
     int nlp;            // padded layer count (multiple of BLK)
 };
+// slots of ColView::sums: surface direct / UV-visible / near-IR sums of the call with aerosol, the P stream's surface
+// level, then {TOA up, TOA down, surface up, surface down} of the clean-sky (S) and clear-sky (K) streams
+enum : int { SUM_DIRBB = 0, SUM_UVFD, SUM_UVDIR, SUM_NIFD, SUM_NIDIR, SUM_S = 8, SUM_K = 12, SUMS_N = 16 };
 
-__device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nlev)
+__device__ __forceinline__ ColView carve(double *base, int nlp, bool cloud, bool prof)
 {
     ColView v;
     v.nlp = nlp;
@@ -231,15 +293,24 @@ __device__ __forceinline__ ColView carve(double *base, int nlp, int nck, int nle
     v.col = p; p += SP_COUNT * nlp;
     v.colmol = p; p += nlp; v.pdp = p; p += nlp;
     v.taer = p; p += SW_NBND * nlp; v.waer = p; p += SW_NBND * nlp; v.gaer = p; p += SW_NBND * nlp;
-    v.flux = p; p += 4 * nlev * 2;
-    v.sfc = p; p += 4 * 8;
-    v.fluxc = p; p += 2 * nlev * 2;
-    v.cldf = p; p += nlp; v.clwp = p; p += nlp; v.ciwp = p; p += nlp; v.cswp = p; p += nlp;
-    v.fliq = p; p += nlp; v.fice = p; p += nlp; v.fsno = p; p += nlp;
-    v.cmhi = reinterpret_cast<uint64_t *>(p); p += NTHREADS;
+    v.flux = p; p += NWAVE * (nlp + 1) * 2;
+    v.sums = p; p += NWAVE * SUMS_N;
+    v.fluxc = v.fluxk = nullptr;
+    if (prof) {
+        v.fluxc = p; p += NWAVE * (nlp + 1) * 2;
+        if (cloud) { v.fluxk = p; p += NWAVE * (nlp + 1) * 2; }
+    }
+    v.cldf = v.clwp = v.ciwp = v.cswp = v.fliq = v.fice = v.fsno = nullptr;
+    v.cmhi = nullptr;
+    if (cloud) {
+        v.cldf = p; p += nlp; v.clwp = p; p += nlp; v.ciwp = p; p += nlp; v.cswp = p; p += nlp;
+        v.fliq = p; p += nlp; v.fice = p; p += nlp; v.fsno = p; p += nlp;
+        v.cmhi = reinterpret_cast<uint64_t *>(p); p += NTHREADS;
+    }
     int *q = reinterpret_cast<int *>(p);
     v.rb0 = q; q += nlp; v.rb1 = q; q += nlp; v.inds = q; q += nlp; v.indf = q; q += nlp; v.jp = q; q += nlp + 1;
-    v.iliq = q; q += nlp; v.iice = q; q += nlp; v.isno = q; q += nlp; v.seeds = q; q += 4;
+    v.iliq = v.iice = v.isno = v.seeds = nullptr;
+    if (cloud) { v.iliq = q; q += nlp; v.iice = q; q += nlp; v.isno = q; q += nlp; v.seeds = q; q += 4; }
     return v;
 }
 
@@ -404,67 +475,144 @@ __device__ __forceinline__ void cloud_optics(const double *T, const ColView &c, 
     const double gi = scatice * fdiv(gice - forwice, 1.0 - forwice);
     if (iceflag < 5) {
         ssacmc = fdiv(scatliq + scatice, taucmc);
-        asmcmc = frcp(scatliq + scatice) * (gl + gi);
+        asmcmc = frcp1(scatliq + scatice) * (gl + gi);
     } else {
         ssacmc = fdiv(scatliq + scatice + scatsno, taucmc);
-        asmcmc = frcp(scatliq + scatice + scatsno) * (gl + gi + scatsno * fdiv(gsno - forwsno, 1.0 - forwsno));
+        asmcmc = frcp1(scatliq + scatice + scatsno) * (gl + gi + scatsno * fdiv(gsno - forwsno, 1.0 - forwsno));
+    }
+}
+// reftra_sw for a layer without asymmetry (zg = 0: the clean-sky call outside cloud, where the only scatterer is
+// Rayleigh): zgamma3 = zgamma4 = 1/2, za1 = za2, zq = 0, denom = 1.  Same operations as reftra_fast otherwise.
+__device__ __forceinline__ void reftra_clean(const SwDeviceTables &tb, double zto1, double zw, double prmuz, double zem2,
+                                             RT &o)
+{
+    const double eps = 1.e-08, zwcrit = 0.9999995;
+    const double zgamma1 = (8. - zw * 5.) * 0.25;
+    const double zgamma2 = 3. * zw * 0.25;
+    if (zw >= zwcrit) {
+        const double za1 = zgamma1 * prmuz - 0.5;
+        const double zgt = zgamma1 * zto1;
+        const double rg = frcp1(1. + zgt);
+        const double r = (zgt - za1 * (1. - zem2)) * rg;
+        const double rd = zgt * rg;
+        const bool one = (zem2 == 1.0);
+        o.ref = one ? 0.0 : r;
+        o.tra = one ? 1.0 : 1. - r;
+        o.refd = one ? 0.0 : rd;
+        o.trad = one ? 1.0 : 1. - rd;
+    } else {
+        const double za = 0.5 * (zgamma1 + zgamma2);
+        const double zrk = fsqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        const double zrp = zrk * prmuz;
+        const double zrp1 = 1. + zrp, zrm1 = 1. - zrp;
+        const double zrk2 = 2. * zrk;
+        const double zrpp = 1. - zrp * zrp;
+        const double zrkg = zrk + zgamma1;
+        const double hp = za + 0.5 * zrk, hm = za - 0.5 * zrk;
+        const double zr1 = zrm1 * hp, zr2 = zrp1 * hm, zr3 = zrk2 * (0.5 - za * prmuz);
+        const double zr4 = zrpp * zrkg, zr5 = zrpp * (zrk - zgamma1);
+        const double zt1 = zrp1 * hp, zt2 = zrm1 * hm, zt3 = zrk2 * (0.5 + za * prmuz);
+        const double zem1 = exp_lookup(tb, fmin(zrk * zto1, 500.));
+        const double zemm = zem1 * zem1;
+        const double D = zr4 + zr5 * zemm;
+        const double rD = frcp1(D);
+        const bool small = fabs(D) <= eps * zem1;
+        const double r = zw * (zr1 - zr2 * zemm - zr3 * (zem2 * zem1)) * rD;
+        const double t = zem2 - zw * (zem2 * (zt1 - zt2 * zemm) - zt3 * zem1) * rD;
+        o.ref = small ? eps : r;
+        o.tra = small ? zem2 : t;
+        const double zdend = frcp1(zrkg - (zgamma1 - zrk) * zemm);
+        o.refd = zgamma2 * (1. - zemm) * zdend;
+        o.trad = zrk2 * zem1 * zdend;
     }
 }
 
-// optical properties of layer k as seen by the two-stream solver (spcvmc_sw
-// layer preparation, SW:8443-8501) followed by reftra and the delta-scaled
-// direct-beam transmittance (SW:8568-8578).  dbt_nodel: unscaled direct beam
-// (SW:8459-8469), only requested by the aerosol pass on its way down.
-// cloudy: this sub-column (lane) has cloud in layer k -- total-sky properties per SW:8505-8510, 8476-8486.
-__device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables &tb, const ColView &c, const LaneG &L, int k,
-                                         bool lower, bool aer_on, double prmu0, RT &o, double &dbt_nodel,
-                                         const GasPre &gp, bool cloudy = false, int iceflag = 3,
-                                         const double *cldtab = nullptr, int *bad = nullptr)
+// cloud optical properties of one cloudy sub-column layer, as the solver needs them
+struct CldLayer {
+    double tc, oc, gc, taor;
+};
+
+// optical properties of layer k as seen by the two-stream solver (spcvmc_sw layer preparation, SW:8443-8501)
+// followed by reftra and the delta-scaled direct-beam transmittance (SW:8568-8578).  ta, wa, ga: aerosol optical
+// depth (0 in the clean call: ztauacln, SW:9346), single-scattering albedo, asymmetry.  dbt_nodel: unscaled direct
+// beam (SW:8459-8469), requested by the call with aerosol only.  cloudy: this sub-column (lane) has cloud in the
+// layer -- total-sky properties per SW:8505-8510, 8476-8486.
+__device__ __forceinline__ void layer_rt(const bool NODEL, const SwDeviceTables &tb, double taug, double taur, double ta,
+                                         double wa, double ga, double prmu0, double rprmu0, bool cloudy,
+                                         const CldLayer &cl, RT &o, double &dbt_nodel)
 {
-    double taug, taur;
-    gas_finish(tb, c, L, k, lower, gp, taug, taur);
-    const int ia = L.band * c.nlp + k;
-    const double ta = aer_on ? c.taer[ia] : 0.0;   // clean call: ztauacln = 0 (SW:9346), omega/g unchanged
-    const double wa = c.waer[ia], ga = c.gaer[ia];
-    const double rprmu0 = 1.0 / prmu0;   // loop-invariant: hoisted by the compiler
+    // the four quotients of SW:8476-8501 over two reciprocals (each of a product of the two denominators)
     double ztauc = taur + taug + ta;
     double zomcc = taur * 1.0 + ta * wa;
-    double zgcc = fdiv(ga * wa * ta, zomcc);
-    zomcc = fdiv(zomcc, ztauc);
+    const double r1 = frcp1(zomcc * ztauc);
+    double zgcc = (ga * wa * ta) * (r1 * ztauc);
+    zomcc = zomcc * (r1 * zomcc);
     const double ztau_un = ztauc;
-    double zf = zgcc * zgcc;
-    double zwf = zomcc * zf;
+    const double zf = zgcc * zgcc;
+    const double zwf = zomcc * zf;
     ztauc = (1.0 - zwf) * ztauc;
-    zomcc = fdiv(zomcc - zwf, fmax((1.0 - zwf), 1.0E-30));
-    zgcc = fdiv(zgcc - zf, fmax((1.0 - zf), 1.0E-30));
+    const double d1 = fmax((1.0 - zwf), 1.0E-30), d2 = fmax((1.0 - zf), 1.0E-30);
+    const double r2 = frcp1(d1 * d2);
+    zomcc = (zomcc - zwf) * (r2 * d2);
+    zgcc = (zgcc - zf) * (r2 * d1);
     double taor = 0.;
     if (cloudy) {
-        double tc, oc, gc;
-        int b = 0;
-        cloud_optics(cldtab, c, L.band, k, iceflag, tc, oc, gc, taor, b);
-        if (b) *bad = b;
-        const double ztauo = ztauc + tc;
-        double zomco = ztauc * zomcc + tc * oc;
-        zgcc = fdiv(tc * oc * gc + ztauc * zomcc * zgcc, zomco);
+        const double ztauo = ztauc + cl.tc;
+        const double zomco = ztauc * zomcc + cl.tc * cl.oc;
+        zgcc = fdiv(cl.tc * cl.oc * cl.gc + ztauc * zomcc * zgcc, zomco);
         zomcc = fdiv(zomco, ztauo);
         ztauc = ztauo;
+        taor = cl.taor;
     }
     if (NODEL) dbt_nodel = exp_lookup(tb, (ztau_un + taor) * rprmu0);
     o.dbt = exp_lookup(tb, ztauc * rprmu0);
     reftra_fast(tb, ztauc, zomcc, zgcc, prmu0, o.dbt, o);
 }
 
+// the same with ta = 0 and no cloud: zgcc = 0, no delta scaling (zf = zwf = 0), one division left
+__device__ __forceinline__ void layer_rt_clean(const SwDeviceTables &tb, double taug, double taur, double prmu0,
+                                               double rprmu0, RT &o)
+{
+    const double ztauc = taur + taug;
+    const double zomcc = fdiv(taur, ztauc);
+    o.dbt = exp_lookup(tb, ztauc * rprmu0);
+    reftra_clean(tb, ztauc, zomcc, prmu0, o.dbt, o);
+}
+
+// Two-stream properties of a stack of layers under a direct beam from above: reflectance to the beam (ref) and to
+// diffuse light from above (refd), total (tra), diffuse (trad) and direct-beam (dbt) transmittance, reflectance to
+// diffuse light from below (rb).  add_on_top() puts one homogeneous layer on top of the stack: the adding step of
+// vrtqdr_sw (SW:7997-8034) written for a composite lower part -- ref/refd follow the reference's upward recurrence
+// (SW:8003-8013), tra/rb its downward one (SW:8026-8034) with the roles of "above" and "layer" taken by the new
+// layer and the stack.  The diffuse transmittance of a stack is the same in both directions (reciprocity).
+struct Stack {
+    double ref, refd, tra, trad, rb, dbt;
+};
+__device__ __forceinline__ void add_on_top(Stack &s, const RT &b)
+{
+    const double z = frcp1(1. - s.refd * b.refd);
+    const double dif = b.tra - b.dbt;                       // diffuse part of the layer's transmitted beam
+    const double nref = b.ref + (b.trad * (dif * s.refd + b.dbt * s.ref)) * z;
+    const double nrefd = b.refd + b.trad * b.trad * s.refd * z;
+    const double ntra = b.dbt * s.tra + (s.trad * (dif + b.dbt * s.ref * b.refd)) * z;
+    const double nrb = s.rb + s.trad * s.trad * b.refd * z;
+    const double ntrad = s.trad * b.trad * z;
+    s.ref = nref; s.refd = nrefd; s.tra = ntra; s.trad = ntrad; s.rb = nrb;
+    s.dbt = b.dbt * s.dbt;
+}
+
 }  // namespace
 
-// One column: vb = position of the column in the XCD-interleaved order, scr = this workgroup's slice of the
-// layer scratch (SW_SCR_VALS values per wave, layer and lane).
+// One column: vb = position of the column in the XCD-interleaved order, scr_block = this workgroup's slice of the
+// layer scratch.  CLOUD: icloud /= 0 (McICA sub-columns); PROF: the optional layer-flux profiles are requested.
+template <bool CLOUD, bool PROF>
 __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, double *lds, double *scr_block)
 {
     const SwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
-    ColView c = carve(lds, nlp, nblk, nlev);
+    ColView c = carve(lds, nlp, CLOUD, PROF);
 
     // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
     int col;
@@ -613,7 +761,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             c.rb1[k] = lowerp ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
             c.inds[k] = indself - 1;
             c.indf[k] = indfor - 1;
-            if (a.icloud != 0) {
+            if (CLOUD) {
                 // hydrometeors -> in-cloud water paths and effective sizes, SW:10371-10618 and 10743-10947
                 double cf = 0., clwp = 0., ciwp = 0., cswp = 0., reliq = 10., reice = 10., resno = 10.;
                 if (!top) {
@@ -624,12 +772,15 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     if (!a.qi3d && !a.warm_rain && tavel < 273.15) { qi = qc; qs = qr; qc = 0.; qr = 0.; }
                     if (a.qi3d) qi = fmax(0., ldr(a.qi3d, q, r4));
                     if (a.qs3d) qs = fmax(0., ldr(a.qs3d, q, r4));
-                    if (a.f_ice_phy) {        // "MP option 5": one frozen species carried as snow, SW:10461-10472
+                    if (a.f_ice_phy) {        // "MP option 5": one frozen species carried as snow, SW:10461-10472;
+                        // the cloud water the T < 273.15 rule above moved to ice comes back (qc1d = qc3d, SW:10467)
                         const double s3 = a.qs3d ? ldr(a.qs3d, q, r4) : 0.;
                         qi = fmax(0., 0.1 * s3); qs = 0.9 * s3;
+                        qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;
                     }
                     if (a.fer_hires) {        // Ferrier-Aligo: qi3d holds all frozen water, SW:10474-10492
                         qi = a.qi3d ? fmax(0., ldr(a.qi3d, q, r4)) : 0.; qs = 0.0;
+                        qc = a.qc3d ? fmax(0., ldr(a.qc3d, q, r4)) : 0.;
                     }
                     cf = a.cldfra3d ? ldr(a.cldfra3d, q, r4) : 0.;
                     const double xland = a.xland ? ldr(a.xland, i2, r4) : 1.;
@@ -834,7 +985,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     }
 
     // ======================= main phase: lanes = g-points =======================
-    const int chunk = wave & 1, pass = wave >> 1;
+    const int chunk = wave;
     const bool active = lane < CHUNK;
     const int g = chunk * CHUNK + (active ? lane : CHUNK - 1);
     const GDesc gd = tb.gdesc[g];
@@ -846,7 +997,8 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     // bit k of cmask = cloudy in layer k.  The lane jumps the column's KISS sequence to its own nlay draws.
     uint64_t cmask = 0, cmhi = 0;
     int iceflag = 3;
-    if (a.icloud != 0) {
+    int col_cloudy = 0;
+    if (CLOUD) {
         if (a.has_reqi != 0) iceflag = 4;
         if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
         KissState ks = {(uint32_t)c.seeds[0], (uint32_t)c.seeds[1], (uint32_t)c.seeds[2], (uint32_t)c.seeds[3]};
@@ -864,10 +1016,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             prev = cur;
         }
         if (nlay > 64) c.cmhi[tid] = cmhi;
+        col_cloudy = __syncthreads_or((cmask | cmhi) != 0);
     }
-    const int col_cloudy = a.icloud != 0 ? __syncthreads_or((cmask | cmhi) != 0) : 0;
 
     const double prmu0 = coszrs <= 1.e-10 ? 1.e-10 : coszrs;   // SW:9254-9255
+    const double rprmu0 = 1.0 / prmu0;
     // solar source at the layer selected per band (SW:3363-3380, 3533-3538, 4297) -> incoming flux
     double sfluxzen;
     {
@@ -912,136 +1065,190 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
         albp = gd.uvband ? ldr(a.alswvisdir, i2, r4) : ldr(a.alswnirdir, i2, r4);
         albd = gd.uvband ? ldr(a.alswvisdif, i2, r4) : ldr(a.alswnirdif, i2, r4);
     }
-    double *ck = scr_block + (size_t)4 * nlay * SW_SCR_VALS * 64 + (size_t)wave * nblk * 2 * 64;
+    double *ck = scr_block + (size_t)NWAVE * nlay * SW_SCR_VALS * 64 + (size_t)wave * nblk * 2 * 64 + lane;
     double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * 64 + lane;
     int bad = 0;
+    // the lanes that store wave sums: lane 16r holds row r, i.e. value wsum_index(r) of a wave_sum4
+    const bool writer = (lane & 15) == 0;
+    const int wrow = wsum_index(lane >> 4);
+    double *wsums = c.sums + wave * SUMS_N;
 
-    // One spcvmc_sw pass of this wave's 56 sub-columns: aer_on = with aerosol optical depth, mask = the
-    // sub-column's cloudy layers (0: clear sky).  Fluxes per level go to flux[2l], flux[2l+1].
-    auto run_pass = [&](const bool aer_on, const bool cld_on, const uint64_t mask, double *flux, const bool want_sfc) {
-        // ---- upward sweep: reflectance of everything below each level; keep every BLK-th level ----
-        double rup = albp, rupd = albd;
+    // One upward sweep of this wave's 56 sub-columns carrying up to two calls on the same gas optics:
+    //   P (hasP): fluxes at every level -> pflux[2l], pflux[2l+1]; p_aer = with aerosol optical depth, p_mask = the
+    //     sub-column's cloudy layers are in (0: clear sky); want_sfc: the surface direct / UV / near-IR sums too.
+    //   S (hasS): TOA and surface fluxes only -> wsums[sdst .. sdst+3]; s_aer, s_mask alike.
+    auto sweep = [&](const bool hasP, const bool p_aer, const bool p_mask, const bool want_sfc, double *pflux,
+                     const bool hasS, const bool s_aer, const bool s_mask, const int sdst) {
+        // ---- upward sweep ----
+        double rup = albp, rupd = albd, tdbt_nodel = 1.;
+        Stack st = {0., 0., 1., 1., 0., 1.};
         GasPre gp;
         gas_fetch(tb, c, L, 0, 0 < laytrop, gp);
         for (int k = 0; k < nlay; ++k) {
-            GasPre gn;   // next layer's table reads go out before this layer's arithmetic
-            {
-                const int kn = k + 1 < nlay ? k + 1 : k;
-                gas_fetch(tb, c, L, kn, kn < laytrop, gn);
+            double taug, taur;
+            gas_finish(tb, c, L, k, k < laytrop, gp, taug, taur);
+            // The table values of the next layer are read ahead of the arithmetic.  gp is dead from here on, so the
+            // reads land in the same registers (no copies): behind the P stream when an S stream follows (its
+            // arithmetic covers the latency and the P stream runs with fewer live registers), else right away.
+            const int kn = k + 1 < nlay ? k + 1 : k;
+            if (!hasS) gas_fetch(tb, c, L, kn, kn < laytrop, gp);
+            const int ia = L.band * nlp + k;
+            const double ta = c.taer[ia], wa = c.waer[ia], ga = c.gaer[ia];
+            bool cloudy = false;
+            CldLayer cl = {0., 1., 0., 0.};
+            if (CLOUD) {
+                cloudy = k < 64 ? (cmask >> k) & 1 : (nlay > 64 ? (c.cmhi[tid] >> (k - 64)) & 1 : 0);
+                if (cloudy && ((hasP && p_mask) || (hasS && s_mask))) {
+                    int b = 0;
+                    cloud_optics(a.cldtab, c, L.band, k, iceflag, cl.tc, cl.oc, cl.gc, cl.taor, b);
+                    if (b) bad = b;
+                }
             }
-            if ((k & (BLK - 1)) == 0) {
-                ck[((k / BLK) * 2 + 0) * 64 + lane] = rup;
-                ck[((k / BLK) * 2 + 1) * 64 + lane] = rupd;
+            if (hasP) {
+                if ((k & (BLK - 1)) == 0) {
+                    ck[((k / BLK) * 2 + 0) * 64] = rup;
+                    ck[((k / BLK) * 2 + 1) * 64] = rupd;
+                }
+                RT rt;
+                double dnl = 1.;
+                layer_rt(want_sfc, tb, taug, taur, p_aer ? ta : 0.0, wa, ga, prmu0, rprmu0, cloudy && p_mask, cl, rt, dnl);
+                {   // keep the layer's two-stream result for the way down
+                    double *s = scr + (size_t)k * SW_SCR_VALS * 64;
+                    s[0] = rt.ref; s[64] = rt.refd; s[128] = rt.tra; s[192] = rt.trad; s[256] = rt.dbt;
+                }
+                tdbt_nodel = dnl * tdbt_nodel;
+                // vrtqdr_sw, SW:7997-8015
+                const double zreflect = frcp1(1. - rupd * rt.refd);
+                const double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
+                const double nrupd = rt.refd + rt.trad * rt.trad * rupd * zreflect;
+                rup = nrup; rupd = nrupd;
             }
-            RT rt;
-            double dnl = 1.;
-            layer_rt(want_sfc, tb, c, L, k, k < laytrop, aer_on, prmu0, rt, dnl, gp,
-                     k < 64 ? (mask >> k) & 1 : (cld_on ? (c.cmhi[tid] >> (k - 64)) & 1 : 0), iceflag, a.cldtab, &bad);
-            gp = gn;
-            {   // keep the layer's two-stream result for the way down
-                double *s = scr + (size_t)k * SW_SCR_VALS * 64;
-                s[0] = rt.ref; s[64] = rt.refd; s[128] = rt.tra; s[192] = rt.trad; s[256] = rt.dbt;
-                if (want_sfc) s[320] = dnl;
+            if (hasS) {
+                gas_fetch(tb, c, L, kn, kn < laytrop, gp);
+                RT rt;
+                // the cheap form needs ta = 0 and no cloudy lane in this layer (wave-uniform choice)
+                const bool general = s_aer || (CLOUD && s_mask && __any(cloudy));
+                if (general) {
+                    double dnl;
+                    layer_rt(false, tb, taug, taur, s_aer ? ta : 0.0, wa, ga, prmu0, rprmu0, cloudy && s_mask, cl, rt, dnl);
+                } else {
+                    layer_rt_clean(tb, taug, taur, prmu0, rprmu0, rt);
+                }
+                add_on_top(st, rt);
             }
-            // vrtqdr_sw, SW:7997-8015
-            double zreflect = frcp(1. -rupd * rt.refd);
-            double nrup = rt.ref + (rt.trad * ((rt.tra - rt.dbt) * rupd + rt.dbt * rup)) * zreflect;
-            double nrupd = rt.refd + rt.trad * rt.trad * rupd * zreflect;
-            rup = nrup; rupd = nrupd;
         }
+        if (hasS) {
+            // the surface under the stack (SW:8038-8044 at the lowest level, SW:8003-8006 for the top)
+            const double zreflect = frcp1(1. - st.rb * albd);
+            const double fu0 = (st.dbt * albp + (st.tra - st.dbt) * albd) * zreflect;
+            const double fd0 = st.dbt + (st.tra - st.dbt + st.dbt * albp * st.rb) * zreflect;
+            const double futop = st.ref + st.trad * fu0;
+            const double q = wave_sum4(zincflx * futop, zincflx, zincflx * fu0, zincflx * fd0);
+            if (writer) wsums[sdst + wrow] = q;
+        }
+        if (!hasP) return;
 
         // ---- downward sweep by blocks: read the block's layers back, rebuild its upward reflectances, descend ----
-        double tdn = 1., rdnd = 0., tdbt = 1., tdbt_nodel = 1.;
+        double tdn = 1., rdnd = 0., tdbt = 1.;
         for (int b = nblk - 1; b >= 0; --b) {
             RT rt[BLK];
-            double dn[BLK], ru[BLK + 1], rud[BLK + 1];
-            ru[0] = ck[(b * 2 + 0) * 64 + lane];
-            rud[0] = ck[(b * 2 + 1) * 64 + lane];
+            double ru[BLK + 1], rud[BLK + 1];
+            ru[0] = ck[(b * 2 + 0) * 64];
+            rud[0] = ck[(b * 2 + 1) * 64];
 #pragma unroll
             for (int j = 0; j < BLK; ++j) {
                 const int k = b * BLK + j;
                 if (k < nlay) {
                     const double *s = scr + (size_t)k * SW_SCR_VALS * 64;
                     rt[j].ref = s[0]; rt[j].refd = s[64]; rt[j].tra = s[128]; rt[j].trad = s[192]; rt[j].dbt = s[256];
-                    dn[j] = want_sfc ? s[320] : 1.;
                 } else {
-                    rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.; dn[j] = 1.;
+                    rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.;
                 }
-                double zreflect = frcp(1. -rud[j] * rt[j].refd);
+                const double zreflect = frcp1(1. - rud[j] * rt[j].refd);
                 ru[j + 1] = rt[j].ref + (rt[j].trad * ((rt[j].tra - rt[j].dbt) * rud[j] + rt[j].dbt * ru[j])) * zreflect;
                 rud[j + 1] = rt[j].refd + rt[j].trad * rt[j].trad * rud[j] * zreflect;
             }
+            double fu[BLK], fd[BLK];
 #pragma unroll
             for (int j = BLK - 1; j >= 0; --j) {
-                const int l = b * BLK + j + 1;   // level at the top of layer k = b*BLK + j
-                if (l <= nlay) {
-                    // fluxes at level l, SW:8038-8044
-                    double zreflect = frcp(1. -rdnd * rud[j + 1]);
-                    double fu = (tdbt * ru[j + 1] + (tdn - tdbt) * rud[j + 1]) * zreflect;
-                    double fd = tdbt + (tdn - tdbt + tdbt * ru[j + 1] * rdnd) * zreflect;
-                    // two independent reductions (their steps interleave); lane 63 holds both sums
-                    const double su = wave_sum_l63(zincflx * fu), sd = wave_sum_l63(zincflx * fd);
-                    if (lane == 63) { flux[2 * l] = su; flux[2 * l + 1] = sd; }
+                {   // fluxes at level l = b*BLK + j + 1 (top of layer k = b*BLK + j), SW:8038-8044
+                    const double zreflect = frcp1(1. - rdnd * rud[j + 1]);
+                    fu[j] = zincflx * ((tdbt * ru[j + 1] + (tdn - tdbt) * rud[j + 1]) * zreflect);
+                    fd[j] = zincflx * (tdbt + (tdn - tdbt + tdbt * ru[j + 1] * rdnd) * zreflect);
                 }
                 // through layer k, SW:8026-8034 and SW:8578
-                double zreflect = frcp(1. -rt[j].refd * rdnd);
-                double ntdn = tdbt * rt[j].tra + (rt[j].trad * ((tdn - tdbt) + tdbt * rt[j].ref * rdnd)) * zreflect;
-                double nrdnd = rt[j].refd + rt[j].trad * rt[j].trad * rdnd * zreflect;
+                const double zreflect = frcp1(1. - rt[j].refd * rdnd);
+                const double ntdn = tdbt * rt[j].tra + (rt[j].trad * ((tdn - tdbt) + tdbt * rt[j].ref * rdnd)) * zreflect;
+                const double nrdnd = rt[j].refd + rt[j].trad * rt[j].trad * rdnd * zreflect;
                 tdn = ntdn; rdnd = nrdnd;
                 tdbt = rt[j].dbt * tdbt;
-                tdbt_nodel = dn[j] * tdbt_nodel;
+            }
+            // spectral sums of the block's eight values (SW:8629-8634); levels above the real top (identity padding)
+            // land in the padded tail of the flux array
+            static_assert(BLK == 4, "two wave_sum4 per block");
+            const double q0 = wave_sum4(fu[0], fd[0], fu[1], fd[1]);
+            const double q1 = wave_sum4(fu[2], fd[2], fu[3], fd[3]);
+            if (writer) {
+                double *f = pflux + 2 * (b * BLK + 1) + wrow;
+                f[0] = q0; f[4] = q1;
             }
         }
         {   // surface level
-            double zreflect = frcp(1. -rdnd * albd);
-            double fu = (tdbt * albp + (tdn - tdbt) * albd) * zreflect;
-            double fd = tdbt + (tdn - tdbt + tdbt * albp * rdnd) * zreflect;
-            double su = wave_sum_l63(zincflx * fu), sd = wave_sum_l63(zincflx * fd);
-            if (lane == 63) { flux[0] = su; flux[1] = sd; }
+            const double zreflect = frcp1(1. - rdnd * albd);
+            const double fu = (tdbt * albp + (tdn - tdbt) * albd) * zreflect;
+            const double fd = tdbt + (tdn - tdbt + tdbt * albp * rdnd) * zreflect;
             if (want_sfc) {
-                // surface-only direct / UV-visible / near-IR sums of the total-sky call (SW:8633-8647 at ikl = 1)
+                // with the surface-only direct / UV-visible / near-IR sums of the total-sky call (SW:8633-8647, ikl = 1)
                 const double uv = gd.uvband ? zincflx : 0., ni = gd.uvband ? 0. : zincflx;
-                double dirbb = wave_sum_l63(zincflx * tdbt_nodel);
-                double uvfd = wave_sum_l63(uv * fd), uvdir = wave_sum_l63(uv * tdbt_nodel);
-                double nifd = wave_sum_l63(ni * fd), nidir = wave_sum_l63(ni * tdbt_nodel);
-                if (lane == 63) {
-                    double *s = c.sfc + wave * 8;
-                    s[0] = dirbb; s[1] = uvfd; s[2] = uvdir; s[3] = nifd; s[4] = nidir;
+                const double q0 = wave_sum4(zincflx * fu, zincflx * fd, zincflx * tdbt_nodel, uv * fd);
+                const double q1 = wave_sum4(uv * tdbt_nodel, ni * fd, ni * tdbt_nodel, 0.);
+                if (writer) {
+                    if (wrow < 2) pflux[wrow] = q0; else wsums[wrow == 2 ? SUM_DIRBB : SUM_UVFD] = q0;
+                    if (wrow < 3) wsums[wrow == 0 ? SUM_UVDIR : (wrow == 1 ? SUM_NIFD : SUM_NIDIR)] = q1;
                 }
+            } else {
+                const double q0 = wave_sum4(zincflx * fu, zincflx * fd, 0., 0.);
+                if (writer && wrow < 2) pflux[wrow] = q0;
             }
         }
     };
 
-    double *flux = c.flux + (size_t)wave * nlev * 2;
-    if (pass == 1 && a.clean <= 0) {
-        // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
-        for (int l = lane; l < nlev; l += 64) { flux[2 * l] = 0.; flux[2 * l + 1] = 0.; }
+    double *flux = c.flux + (size_t)wave * (nlp + 1) * 2;
+    const bool do_cln = a.clean > 0;
+    if (lane < SUMS_N) wsums[lane] = 0.;   // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
+    if (PROF) {
+        // every call as a P stream: with aerosol; clean sky (call #2, SW:9439-9467); clear sky of a cloudy column
+        // (zbbcu / zbbcd of call #1, SW:8405-8416, 8590-8593).  One call site keeps one copy of the sweep.
+        double *fc = c.fluxc + (size_t)wave * (nlp + 1) * 2;
+        if (!do_cln) for (int l = lane; l < 2 * nlev; l += 64) fc[l] = 0.;
+        const int nround = CLOUD && col_cloudy ? 3 : 2;
+        for (int r = 0; r < nround; ++r) {
+            if (r == 1 && !do_cln) continue;
+            sweep(true, r != 1, r != 2, r == 0, r == 0 ? flux : (r == 1 ? fc : c.fluxk + (size_t)wave * (nlp + 1) * 2),
+                  false, false, false, 0);
+        }
+    } else {
+        // round 0: P = total sky with aerosol (call #1), S = total sky without aerosol (call #2); round 1, cloudy
+        // columns only: S = the clear-sky fluxes of call #1.  Cloud-free columns reuse the total-sky result.
+        const int nround = CLOUD && col_cloudy ? 2 : 1;
+        for (int r = 0; r < nround; ++r)
+            sweep(r == 0, true, true, true, flux, r == 0 ? do_cln : true, r == 1, r == 0, r == 0 ? SUM_S : SUM_K);
     }
-    // Round 0 -- waves 0,1: total sky with aerosol (call #1); waves 2,3: total sky without aerosol (call #2,
-    // SW:9439-9467).  Round 1, cloudy columns only -- the clear-sky fluxes of call #1 (zbbcu / zbbcd, SW:8405-8416,
-    // 8590-8593): a pass without cloud on the two aerosol waves; cloud-free columns reuse the total-sky result.
-    // One call site inside the loop keeps a single copy of the pass in the instruction cache.
-    const int nround = col_cloudy ? 2 : 1;
-    for (int r = 0; r < nround; ++r) {
-        if (r == 1) __syncthreads();
-        const bool run = r == 0 ? !(pass == 1 && a.clean <= 0) : pass == 0;
-        if (run) run_pass(r == 0 ? pass == 0 : true, r == 0 && a.icloud != 0 && nlay > 64, r == 0 ? cmask : 0, r == 0 ? flux : c.fluxc + (size_t)wave * nlev * 2,
-                          r == 0 && pass == 0);
-    }
-    if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
+    if (CLOUD && bad) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
 
     // ======================= epilogue: lanes = levels =======================
-    const double *fA0 = c.flux, *fA1 = c.flux + (size_t)nlev * 2, *fC0 = c.flux + (size_t)2 * nlev * 2,
-                 *fC1 = c.flux + (size_t)3 * nlev * 2;
-    if (tid < nlev) {
-        const int l = tid;
+    const int fstride = (nlp + 1) * 2;
+    const double *fA0 = c.flux, *fA1 = c.flux + fstride;
+    const double *s0 = c.sums, *s1 = c.sums + SUMS_N;
+    for (int l = tid; l < nlev; l += NTHREADS) {
         const double up = fA0[2 * l] + fA1[2 * l], dn = fA0[2 * l + 1] + fA1[2 * l + 1];
-        const double upc = fC0[2 * l] + fC1[2 * l], dnc = fC0[2 * l + 1] + fC1[2 * l + 1];
-        // clear sky: third pass of a cloudy column, else identical to the total-sky result (SW:8428, 8556)
-        const double *fK0 = col_cloudy ? c.fluxc : fA0, *fK1 = col_cloudy ? c.fluxc + (size_t)nlev * 2 : fA1;
-        const double upk = fK0[2 * l] + fK1[2 * l], dnk = fK0[2 * l + 1] + fK1[2 * l + 1];
-        if (a.swupflx) {   // (i, kts:kte+2, j), SW:11156-11165
+        if (PROF && a.swupflx) {   // (i, kts:kte+2, j), SW:11156-11165
+            const double *fC0 = c.fluxc, *fC1 = c.fluxc + fstride;
+            const double upc = fC0[2 * l] + fC1[2 * l], dnc = fC0[2 * l + 1] + fC1[2 * l + 1];
+            // clear sky: third sweep of a cloudy column, else identical to the total-sky result (SW:8428, 8556)
+            const double *fK0 = CLOUD && col_cloudy ? c.fluxk : fA0, *fK1 = CLOUD && col_cloudy ? c.fluxk + fstride : fA1;
+            const double upk = fK0[2 * l] + fK1[2 * l], dnk = fK0[2 * l + 1] + fK1[2 * l + 1];
             const size_t q = base3f + (size_t)l * sk;
             str(a.swupflx, q, r4, up); str(a.swupflxc, q, r4, upk); str(a.swupflxcln, q, r4, upc);
             str(a.swdnflx, q, r4, dn); str(a.swdnflxc, q, r4, dnk); str(a.swdnflxcln, q, r4, dnc);
@@ -1055,57 +1262,78 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             const double tten = swhr / 86400.;
             str(a.rthratensw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
         }
-        if (l == 0) {
-            if (a.gsw) str(a.gsw, i2, r4, dn - up);
-            if (a.swupt) {
-                str(a.swupb, i2, r4, up); str(a.swupbc, i2, r4, upk); str(a.swupbcln, i2, r4, upc);
-                str(a.swdnb, i2, r4, dn); str(a.swdnbc, i2, r4, dnk); str(a.swdnbcln, i2, r4, dnc);
+        if (l == 0 || l == nlay) {
+            // clean sky and clear sky at the surface (l = 0) / the top (l = nlay)
+            double upc, dnc, upk, dnk;
+            if (PROF) {
+                const double *fC0 = c.fluxc, *fC1 = c.fluxc + fstride;
+                upc = fC0[2 * l] + fC1[2 * l]; dnc = fC0[2 * l + 1] + fC1[2 * l + 1];
+                const double *fK0 = CLOUD && col_cloudy ? c.fluxk : fA0, *fK1 = CLOUD && col_cloudy ? c.fluxk + fstride : fA1;
+                upk = fK0[2 * l] + fK1[2 * l]; dnk = fK0[2 * l + 1] + fK1[2 * l + 1];
+            } else {
+                const int o = l == 0 ? 2 : 0;
+                upc = s0[SUM_S + o] + s1[SUM_S + o]; dnc = s0[SUM_S + o + 1] + s1[SUM_S + o + 1];
+                if (CLOUD && col_cloudy) {
+                    upk = s0[SUM_K + o] + s1[SUM_K + o]; dnk = s0[SUM_K + o + 1] + s1[SUM_K + o + 1];
+                } else {
+                    upk = up; dnk = dn;
+                }
             }
-            const double *s0 = c.sfc, *s1 = c.sfc + 8;
-            const double dirbb = s0[0] + s1[0], uvfd = s0[1] + s1[1], uvdir = s0[2] + s1[2], nifd = s0[3] + s1[3],
-                         nidir = s0[4] + s1[4];
-            if (a.swupt && a.swvisdir) {
-                str(a.swvisdir, i2, r4, uvdir); str(a.swvisdif, i2, r4, uvfd - uvdir);
-                str(a.swnirdir, i2, r4, nidir); str(a.swnirdif, i2, r4, nifd - nidir);
+            if (l == 0) {
+                if (a.gsw) str(a.gsw, i2, r4, dn - up);
+                if (a.swupt) {
+                    str(a.swupb, i2, r4, up); str(a.swupbc, i2, r4, upk); str(a.swupbcln, i2, r4, upc);
+                    str(a.swdnb, i2, r4, dn); str(a.swdnbc, i2, r4, dnk); str(a.swdnbcln, i2, r4, dnc);
+                }
+                const double dirbb = s0[SUM_DIRBB] + s1[SUM_DIRBB], uvfd = s0[SUM_UVFD] + s1[SUM_UVFD],
+                             uvdir = s0[SUM_UVDIR] + s1[SUM_UVDIR], nifd = s0[SUM_NIFD] + s1[SUM_NIFD],
+                             nidir = s0[SUM_NIDIR] + s1[SUM_NIDIR];
+                if (a.swupt && a.swvisdir) {
+                    str(a.swvisdir, i2, r4, uvdir); str(a.swvisdif, i2, r4, uvfd - uvdir);
+                    str(a.swnirdir, i2, r4, nidir); str(a.swnirdif, i2, r4, nifd - nidir);
+                }
+                if (a.swddir) {
+                    str(a.swddir, i2, r4, dirbb);
+                    str(a.swddni, i2, r4, dirbb / coszrs);
+                    str(a.swddif, i2, r4, dn - dirbb);
+                }
             }
-            if (a.swddir) {
-                str(a.swddir, i2, r4, dirbb);
-                str(a.swddni, i2, r4, dirbb / coszrs);
-                str(a.swddif, i2, r4, dn - dirbb);
-            }
-        }
-        if (l == nlay) {
-            if (a.swcf) str(a.swcf, i2, r4, (dn - up) - (dnk - upk));   // SW:11126
-            if (a.swupt) {
-                str(a.swupt, i2, r4, up); str(a.swuptc, i2, r4, upk); str(a.swuptcln, i2, r4, upc);
-                str(a.swdnt, i2, r4, dn); str(a.swdntc, i2, r4, dnk); str(a.swdntcln, i2, r4, dnc);
+            if (l == nlay) {
+                if (a.swcf) str(a.swcf, i2, r4, (dn - up) - (dnk - upk));   // SW:11126
+                if (a.swupt) {
+                    str(a.swupt, i2, r4, up); str(a.swuptc, i2, r4, upk); str(a.swuptcln, i2, r4, upc);
+                    str(a.swdnt, i2, r4, dn); str(a.swdntc, i2, r4, dnk); str(a.swdntcln, i2, r4, dnc);
+                }
             }
         }
     }
 }
 
-// One workgroup per column of the launch; its scratch slice: the layers' two-stream results [4 waves][nlay][6][64]
-// and the upward sweep's checkpoints [4 waves][nblk][2][64].
-__global__ void __launch_bounds__(NTHREADS, 3) sw_column_kernel(const SwKernelArgs a)
+// One workgroup per column of the launch; its scratch slice: the layers' two-stream results [2 waves][nlay][5][64]
+// and the upward sweep's checkpoints [2 waves][nblk][2][64].
+template <bool CLOUD, bool PROF>
+__global__ void __launch_bounds__(NTHREADS, SW_WAVES_PER_SIMD) sw_column_kernel(const SwKernelArgs a)
 {
     extern __shared__ double lds[];
     double *scr = a.scratch + (size_t)blockIdx.x * a.scratch_stride;
-    sw_column(a, blockIdx.x, lds, scr);
+    sw_column<CLOUD, PROF>(a, blockIdx.x, lds, scr);
 }
 
 size_t sw_scratch_doubles_per_column(int nk)
 {
     const size_t nlay = nk + 1, nblk = (nlay + BLK - 1) / BLK;
-    return 4 * nlay * SW_SCR_VALS * 64 + 4 * nblk * 2 * 64;
+    return NWAVE * nlay * SW_SCR_VALS * 64 + NWAVE * nblk * 2 * 64;
 }
 
 // ---------------------------------------------------------------------------
-size_t sw_lds_bytes(int nk)
+size_t sw_lds_bytes(int nk, bool cloud, bool prof)
 {
-    const int nlay = nk + 1, nlev = nlay + 1;
+    const int nlay = nk + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK;
-    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND + 7) + (size_t)6 * nlev * 2 + 32 + NTHREADS;
-    size_t ni = (size_t)nlp * 8 + 1 + 4;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND) + (size_t)NWAVE * (nlp + 1) * 2 + NWAVE * SUMS_N;
+    if (prof) nd += (size_t)NWAVE * (nlp + 1) * 2 * (cloud ? 2 : 1);
+    if (cloud) nd += (size_t)nlp * 7 + NTHREADS;
+    size_t ni = (size_t)nlp * 5 + 1 + (cloud ? (size_t)nlp * 3 + 4 : 0);
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
 
@@ -1163,15 +1391,26 @@ hipError_t sw_upload_retab()
 
 hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream)
 {
-    const size_t lds = sw_lds_bytes(a.nk);
-    static size_t attr_bytes = 0;   // grow-only opt-in for > 64 KB of dynamic LDS
-    if (lds > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sw_column_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool cloud = a.icloud != 0, prof = a.swupflx != nullptr;
+    const size_t lds = sw_lds_bytes(a.nk, cloud, prof);
+    const void *fn = cloud ? (prof ? reinterpret_cast<const void *>(sw_column_kernel<true, true>)
+                                   : reinterpret_cast<const void *>(sw_column_kernel<true, false>))
+                           : (prof ? reinterpret_cast<const void *>(sw_column_kernel<false, true>)
+                                   : reinterpret_cast<const void *>(sw_column_kernel<false, false>));
+    static size_t attr_bytes[4] = {0, 0, 0, 0};   // grow-only opt-in for > 64 KB of dynamic LDS, per instantiation
+    size_t &ab = attr_bytes[(cloud ? 2 : 0) + (prof ? 1 : 0)];
+    if (lds > ab) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_bytes = lds;
+        ab = lds;
     }
-    hipLaunchKernelGGL(sw_column_kernel, dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
+    if (cloud) {
+        if (prof) hipLaunchKernelGGL((sw_column_kernel<true, true>), dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
+        else hipLaunchKernelGGL((sw_column_kernel<true, false>), dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
+    } else {
+        if (prof) hipLaunchKernelGGL((sw_column_kernel<false, true>), dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
+        else hipLaunchKernelGGL((sw_column_kernel<false, false>), dim3(a.ncol), dim3(NTHREADS), lds, stream, a);
+    }
     return hipGetLastError();
 }
 
