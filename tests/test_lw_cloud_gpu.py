@@ -55,6 +55,21 @@ def test_cloudy_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, 
     assert (got["olr"] == got["lwupt"]).all() and (got["glw"] == got["lwdnb"]).all()
 
 
+@pytest.mark.parametrize("ni,nj,nk,seed,radii", [(8, 6, 40, 11, False), (5, 4, 50, 12, True), (4, 3, 100, 15, True)])
+def test_cloudy_lwrad_without_profiles_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed, radii):
+    """The call the driver makes (no layer-flux profiles): clean-sky and clear-sky fluxes at the surface and the top
+    from the downward sweep alone."""
+    eng, nlay = _init(wa, lw_table_file, nk)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260500 + seed)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260510 + seed, cloudy_fraction=0.6, with_radii=radii)
+    got = run_hip_lwrad(eng, st, cloud=cloud, profiles=False)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, cloud=cloud, profiles=False)
+    assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+    cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
+    np.testing.assert_array_equal(got["lwupt"][~cloudy], got["lwuptc"][~cloudy])
+    assert (got["lwcf"][~cloudy] == 0).all()
+
+
 def test_cloudy_lw_tile_subset_host_mode_and_no_clean(hip_lib, wa, lw_table_file, lw_oracle):
     eng, nlay = _init(wa, lw_table_file, 40)
     st = wa.synth.make_wrf_state(9, 7, 40, seed=20260520)
@@ -153,3 +168,12 @@ def test_lw_cloud_microphysics_variants(hip_lib, wa, lw_table_file, lw_oracle, v
     plain = {k: v for k, v in cloud.items() if k not in ("f_ice_phy", "mp_physics", "is_cammgmp_used", "absent")}
     base = run_hip_lwrad(eng, st, cloud=plain)
     assert np.abs(got["lwupt"] - base["lwupt"]).max() > 1e-3
+    if variant in ("f_ice_phy", "fer_hires"):
+        # both blocks read the cloud water again (qc1d = qc3d, LW:12009 / 12029): supercooled liquid counts
+        cold = (st.a3["t3d"] < 273.15) & (st.a3["qc3d"] > 0) & (st.a3["cldfra3d"] > 0)
+        assert cold.sum() > 5
+        keep = st.a3["qc3d"].copy()
+        st.a3["qc3d"] = np.where(cold, 0.0, keep)
+        dry = run_hip_lwrad(eng, st, cloud=cloud)
+        st.a3["qc3d"] = keep
+        assert np.abs(got["lwupt"] - dry["lwupt"]).max() > 1e-3

@@ -47,6 +47,27 @@ def test_lwrad_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk,
     assert (got["olr"] == got["lwupt"]).all() and (got["glw"] == got["lwdnb"]).all()
 
 
+@pytest.mark.parametrize("ni,nj,nk,seed,clean,aer", [(8, 5, 40, 11, 1, 1), (4, 3, 50, 12, 1, 1), (3, 2, 27, 13, 1, 1),
+                                                     (3, 2, 60, 14, 0, 1), (3, 2, 100, 15, 1, 1), (4, 2, 40, 16, 1, 0)])
+def test_lwrad_without_profiles_matches_oracle(hip_lib, wa, lw_table_file, lw_oracle, ni, nj, nk, seed, clean, aer):
+    """The call the patched radiation_driver makes (DRV:1528-1577 passes LWUPFLX.. only if it received them, and
+    first_rk_step_part1 does not): no layer-flux profiles.  The clean-sky fluxes at the surface and at the top then
+    come out of the downward sweep alone -- same tolerance as the profile path."""
+    eng, nlay = _init(wa, lw_table_file, nk)
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260200 + seed)
+    got = run_hip_lwrad(eng, st, profiles=False, clean=clean, aer=aer)
+    ref = run_oracle_lwrad(lw_oracle, st, nlay, profiles=False, clean=clean, aer=aer)
+    assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+    full = run_hip_lwrad(eng, st, profiles=True, clean=clean, aer=aer)
+    compare_sw(got, full, 1e-11, 1e-11, names=list(got))
+    np.testing.assert_array_equal(got["lwuptc"], got["lwupt"])      # cloud-free: clear == all-sky
+    if not aer:   # no aerosol: the clean-sky call is the same call
+        np.testing.assert_array_equal(got["lwuptcln"], got["lwupt"])
+        np.testing.assert_array_equal(got["lwdnbcln"], got["lwdnb"])
+    if not clean:
+        assert (got["lwuptcln"] == 0).all() and (got["lwdnbcln"] == 0).all()
+
+
 def test_lw_host_pointer_mode_equals_device_mode(hip_lib, wa, lw_table_file):
     eng, _ = _init(wa, lw_table_file, 40)
     st = wa.synth.make_wrf_state(5, 3, 40, seed=20260211)

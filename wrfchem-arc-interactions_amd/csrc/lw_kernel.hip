@@ -61,18 +61,24 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
     else reinterpret_cast<double *>(p)[idx] = v;
 }
 
-// reciprocal / quotient without the compiler's IEEE special-case scaffolding (see sw_kernel.hip)
-__device__ __forceinline__ double frcp(double b)
+// reciprocal / quotient without the compiler's IEEE special-case scaffolding (see sw_kernel.hip: v_rcp_f64 is good to
+// 2^-24.4; one Newton step gives 2.2e-15, two 1.1e-16; the quotient built on the one-step reciprocal with its residual
+// correction is the correctly rounded one -- it is used wherever a table index is cut from the quotient)
+__device__ __forceinline__ double frcp1(double b)
 {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = frcp1(b);
+    double e = __builtin_fma(-b, r, 1.0);
     return __builtin_fma(r, e, r);
 }
 __device__ __forceinline__ double fdiv(double a, double b)
 {
-    double r = frcp(b);
+    double r = frcp1(b);
     double q = a * r;
     double rem = __builtin_fma(-b, q, a);
     return __builtin_fma(rem, r, q);
@@ -123,6 +129,39 @@ __device__ __forceinline__ double wave_sum2(double a, double b, int lane)
     for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+
+// ---- wave sums of four values at a time (gfx950 lane swaps, then DPP row steps; see sw_kernel.hip) ----
+typedef unsigned lw_uint2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fold32(double a, double b)
+{
+    const lw_uint2 lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const lw_uint2 hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+__device__ __forceinline__ double fold16(double a, double b)
+{
+    const lw_uint2 lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const lw_uint2 hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int mlo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int mhi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return v + __hiloint2double(mhi, mlo);
+}
+// the result's row r (lanes 16r..16r+15) holds the wave sum of v[wsum_index(r)]
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3)
+{
+    double v = fold16(fold32(v0, v1), fold32(v2, v3));   // rows: v0, v2, v1, v3
+    v = dpp_add<0x140>(v);   // row_mirror
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    return v;
+}
+__device__ __forceinline__ int wsum_index(int row) { return ((row & 1) << 1) | (row >> 1); }
 
 struct LCol {   // LDS image of the column
     double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac, *minorfrac, *pavel;
@@ -199,9 +238,13 @@ struct LaneL {
     int ng, off_self, off_for;
 };
 
-// gaseous optical depth and Planck fraction of layer k for this lane's g-point
+// gaseous optical depth and Planck fraction of NLY layers (same regime) for this lane's g-point.  Every step is
+// taken for all NLY layers before the next one, so that the table reads of the layers are in flight together: the
+// kernel waits on dependent gathers (LDS -> index arithmetic -> table rows -> sums), and two layers side by side
+// double the reads outstanding per wave.
+template <int NLY>
 __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol &c, const LwRegime &R,
-                                           const LaneL &L, int k, double &taug, double &frac)
+                                           const LaneL &L, const int (&ks)[NLY], double (&taug)[NLY], double (&frac)[NLY])
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ng = L.ng;
@@ -210,96 +253,140 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
     const int nsp = (cf >> LC_NSP_SHIFT) & 15;
     const bool binary = type == 2, edges = cf & LC_EDGES;
     const double mult = (cf & LC_MULT4) ? 4. : 8.;
-    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
-    const double fT[2] = {c.fac00[k], c.fac01[k]}, fT1[2] = {c.fac10[k], c.fac11[k]};
-    const int rb[2] = {c.rb0[k], c.rb1[k]};
     const int ts = (binary ? nsp : 1) * ng;
-    double maj[2], sc[2];
+    double colA[NLY], colB[NLY], tau[NLY];
+#pragma unroll
+    for (int q = 0; q < NLY; ++q) { colA[q] = c.mul[spa * nl + ks[q]]; colB[q] = c.mul[spb * nl + ks[q]]; tau[q] = 0.; }
+    double maj[NLY][2], sc[NLY][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        double speccomb, specparm, fs;
-        int jsi;
-        spec_idx(colA, c.rat[(rs * 2 + m) * nl + k], colB, mult, tb.oneminus, speccomb, specparm, jsi, fs);
-        double wm1 = 0., w0 = 1. - fs, w1 = fs, w2 = 0.;
-        if (edges) {   // LW:5231-5290
-            const bool lo = specparm < 0.125, hi = specparm > 0.875;
-            double p = lo ? fs - 1 : -fs;
-            double p4 = (p * p) * (p * p);
-            double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-            wm1 = hi ? fk2 : 0.;
-            w0 = lo ? fk0 : (hi ? fk1 : w0);
-            w1 = lo ? fk1 : (hi ? fk0 : w1);
-            w2 = lo ? fk2 : 0.;
+        double wm1[NLY], w0[NLY], w1[NLY], w2[NLY], fTa[NLY], fTb[NLY];
+        const double *Kp[NLY];
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) {
+            const int k = ks[q];
+            double speccomb, specparm, fs;
+            int jsi;
+            spec_idx(colA[q], c.rat[(rs * 2 + m) * nl + k], colB[q], mult, tb.oneminus, speccomb, specparm, jsi, fs);
+            wm1[q] = 0.; w0[q] = 1. - fs; w1[q] = fs; w2[q] = 0.;
+            if (edges) {   // LW:5231-5290
+                const bool lo = specparm < 0.125, hi = specparm > 0.875;
+                double p = lo ? fs - 1 : -fs;
+                double p4 = (p * p) * (p * p);
+                double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+                wm1[q] = hi ? fk2 : 0.;
+                w0[q] = lo ? fk0 : (hi ? fk1 : w0[q]);
+                w1[q] = lo ? fk1 : (hi ? fk0 : w1[q]);
+                w2[q] = lo ? fk2 : 0.;
+            }
+            if (!binary) { wm1[q] = 0.; w0[q] = 1.; w1[q] = 0.; w2[q] = 0.; jsi = 0; speccomb = colA[q]; }
+            const int rb = m == 0 ? c.rb0[k] : c.rb1[k];
+            Kp[q] = tb.K + R.off_major + (size_t)(rb * nsp + jsi) * ng;
+            fTa[q] = m == 0 ? c.fac00[k] : c.fac01[k];
+            fTb[q] = m == 0 ? c.fac10[k] : c.fac11[k];
+            sc[q][m] = speccomb;
         }
-        if (!binary) { wm1 = 0.; w0 = 1.; w1 = 0.; w2 = 0.; jsi = 0; speccomb = colA; }
-        const double *Kp = tb.K + R.off_major + (size_t)(rb[m] * nsp + jsi) * ng;
+        double v[NLY][4];
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) { v[q][0] = Kp[q][0]; v[q][1] = Kp[q][ng]; v[q][2] = Kp[q][ts]; v[q][3] = Kp[q][ts + ng]; }
         // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
         // their weights are exact zeros and the products drop out
-        double em0 = 0., em1 = 0., ep0 = 0., ep1 = 0.;
-        if (wm1 != 0.) { em0 = Kp[-ng]; em1 = Kp[ts - ng]; }
-        if (w2 != 0.) { ep0 = Kp[2 * ng]; ep1 = Kp[ts + 2 * ng]; }
-        double s = (wm1 * fT[m]) * em0 + (w0 * fT[m]) * Kp[0] + (w1 * fT[m]) * Kp[ng] + (w2 * fT[m]) * ep0 +
-                   (wm1 * fT1[m]) * em1 + (w0 * fT1[m]) * Kp[ts] + (w1 * fT1[m]) * Kp[ts + ng] + (w2 * fT1[m]) * ep1;
-        maj[m] = s;
-        sc[m] = speccomb;
+        double e[NLY][4];
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) {
+            e[q][0] = e[q][1] = e[q][2] = e[q][3] = 0.;
+            if (wm1[q] != 0.) { e[q][0] = Kp[q][-ng]; e[q][1] = Kp[q][ts - ng]; }
+            if (w2[q] != 0.) { e[q][2] = Kp[q][2 * ng]; e[q][3] = Kp[q][ts + 2 * ng]; }
+        }
+#pragma unroll
+        for (int q = 0; q < NLY; ++q)
+            maj[q][m] = (wm1[q] * fTa[q]) * e[q][0] + (w0[q] * fTa[q]) * v[q][0] + (w1[q] * fTa[q]) * v[q][1] +
+                        (w2[q] * fTa[q]) * e[q][2] + (wm1[q] * fTb[q]) * e[q][1] + (w0[q] * fTb[q]) * v[q][2] +
+                        (w1[q] * fTb[q]) * v[q][3] + (w2[q] * fTb[q]) * e[q][3];
     }
-    double tau = 0.;
-    if (type == 2) tau = sc[0] * maj[0] + sc[1] * maj[1];
-    else if (type == 1) tau = colA * (maj[0] + maj[1]);
+#pragma unroll
+    for (int q = 0; q < NLY; ++q) {
+        if (type == 2) tau[q] = sc[q][0] * maj[q][0] + sc[q][1] * maj[q][1];
+        else if (type == 1) tau[q] = colA[q] * (maj[q][0] + maj[q][1]);
+    }
     // continua (selffac / forfac already carry colh2o, LW:3806-3807)
     if (cf & (LC_SELF | LC_FOR)) {
-        const double *Sf = tb.K + L.off_self + (size_t)c.inds[k] * ng;
-        const double *Ff = tb.K + L.off_for + (size_t)c.indf[k] * ng;
-        double s0 = Sf[0], s1 = Sf[ng], f0 = Ff[0], f1 = Ff[ng];
-        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
-        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
-        tau = tau + tauself + taufor;
+        double s0[NLY], s1[NLY], f0[NLY], f1[NLY];
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) {
+            const double *Sf = tb.K + L.off_self + (size_t)c.inds[ks[q]] * ng;
+            const double *Ff = tb.K + L.off_for + (size_t)c.indf[ks[q]] * ng;
+            s0[q] = Sf[0]; s1[q] = Sf[ng]; f0[q] = Ff[0]; f1[q] = Ff[ng];
+        }
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) {
+            const int k = ks[q];
+            double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0[q] + c.selffrac[k] * (s1[q] - s0[q])) : 0.;
+            double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0[q] + c.forfrac[k] * (f1[q] - f0[q])) : 0.;
+            tau[q] = tau[q] + tauself + taufor;
+        }
     }
     // minor species, e.g. LW:5297-5301, 5877-5878
-    const double mf = c.minorfrac[k];
-    const int im = c.indm[k];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
         if (__any(M.slot != LS_ZERO)) {
-            int jm = 0;
-            double fm = 0.;
-            if (M.nsp > 1) {
-                double scb, spp;
-                spec_idx(colA, M.refrat, colB, mult, tb.oneminus, scb, spp, jm, fm);
-            }
-            const double *Kp = tb.K + M.off + (size_t)(im * M.nsp + jm) * ng;
+            double a0[NLY], a1[NLY], b0[NLY], b1[NLY], fm[NLY];
             const int tm = M.nsp * ng;
-            double a0 = Kp[0], a1 = Kp[ng], b0 = Kp[tm], b1 = Kp[tm + ng];
-            double m1 = a0 + fm * (a1 - a0);
-            double m2 = b0 + fm * (b1 - b0);
-            double absm = m1 + mf * (m2 - m1);
-            tau = tau + c.mul[M.slot * nl + k] * absm;
+#pragma unroll
+            for (int q = 0; q < NLY; ++q) {
+                int jm = 0;
+                fm[q] = 0.;
+                if (M.nsp > 1) {
+                    double scb, spp;
+                    spec_idx(colA[q], M.refrat, colB[q], mult, tb.oneminus, scb, spp, jm, fm[q]);
+                }
+                const double *Kp = tb.K + M.off + (size_t)(c.indm[ks[q]] * M.nsp + jm) * ng;
+                a0[q] = Kp[0]; a1[q] = Kp[ng]; b0[q] = Kp[tm]; b1[q] = Kp[tm + ng];
+            }
+#pragma unroll
+            for (int q = 0; q < NLY; ++q) {
+                const double m1 = a0[q] + fm[q] * (a1[q] - a0[q]);
+                const double m2 = b0[q] + fm[q] * (b1[q] - b0[q]);
+                const double absm = m1 + c.minorfrac[ks[q]] * (m2 - m1);
+                tau[q] = tau[q] + c.mul[M.slot * nl + ks[q]] * absm;
+            }
         }
     }
-    tau = tau + c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
-    // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
     const int corr = (cf >> LC_CORR_SHIFT) & 3;
-    if (corr) {
-        const double pp = c.pavel[k];
-        double corradj = 1.;
-        if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
-        else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
-        else corradj = 1. - .05 * (pp - 100.) / 900.;
-        tau = corradj * tau;
-    }
-    taug = tau * R.postscale;
     const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
-    double fr = fmode == 1 ? R.fracconst : 0.;
+    double fr[NLY];
+#pragma unroll
+    for (int q = 0; q < NLY; ++q) fr[q] = fmode == 1 ? R.fracconst : 0.;
     if (fmode == 2) {   // LW:5354-5355
-        double scb, spp, fpl;
-        int jpl;
-        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
-        const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
-        double f0 = Fp[0], f1 = Fp[ng];
-        fr = f0 + fpl * (f1 - f0);
+        double f0[NLY], f1[NLY], fpl[NLY];
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) {
+            double scb, spp;
+            int jpl;
+            spec_idx(colA[q], R.planck_ratio, colB[q], mult, tb.oneminus, scb, spp, jpl, fpl[q]);
+            const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
+            f0[q] = Fp[0]; f1[q] = Fp[ng];
+        }
+#pragma unroll
+        for (int q = 0; q < NLY; ++q) fr[q] = f0[q] + fpl[q] * (f1[q] - f0[q]);
     }
-    frac = fr;
+#pragma unroll
+    for (int q = 0; q < NLY; ++q) {
+        const int k = ks[q];
+        double t = tau[q] + c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
+        // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
+        if (corr) {
+            const double pp = c.pavel[k];
+            double corradj = 1.;
+            if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
+            else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
+            else corradj = 1. - .05 * (pp - 100.) / 900.;
+            t = corradj * t;
+        }
+        taug[q] = t * R.postscale;
+        frac[q] = fr[q];
+    }
 }
 
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
@@ -323,7 +410,7 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, 
     const double tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
     double transc = fmax(exp_neg(tau_t), 1.e-20);
     const double omt = 1. - transc;
-    double tausfac_t = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp(tau_t * omt));
+    double tausfac_t = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp1(tau_t * omt));
     transc = last ? 1.e-20 : transc;
     tausfac_t = last ? 1.0 : tausfac_t;
     atrans = small ? odepth - 0.5 * odepth * odepth : 1. - transc;
@@ -345,7 +432,7 @@ __device__ __forceinline__ void lw_tbl_entry(const LwDeviceTables &tb, double od
     tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
     transc = fmax(exp_neg(tau_t), 1.e-20);
     const double omt = 1. - transc;
-    tfn = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp(tau_t * omt));
+    tfn = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp1(tau_t * omt));
     tau_t = last ? 1.e10 : tau_t;
     transc = last ? 1.e-20 : transc;
     tfn = last ? 1.0 : tfn;
@@ -893,21 +980,23 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     LaneL L;
     L.ng = gd->stride; L.off_self = gd->off_self; L.off_for = gd->off_for;   // row stride (padded ng)
     double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    // one layer at a time: two layers side by side (gas_optics<2>) need more registers than three waves per SIMD
+    // leave (measured: 492 bytes of spills per lane, 2.4x slower)
+    auto run = [&](const LwRegime &R, int kbeg, int kend) {
+        for (int k = kbeg; k < kend; ++k) {
+            const int ks[1] = {k};
+            double taug[1], plfrac[1];
+            gas_optics<1>(tb, c, R, L, ks, taug, plfrac);
+            if (active) { tg[(size_t)k * LW_NGPT] = taug[0]; fr[(size_t)k * LW_NGPT] = plfrac[0]; }
+        }
+    };
     {
         const LwRegime R = gd->lo;
-        for (int k = 0; k < ltrop; ++k) {
-            double taug, plfrac;
-            gas_optics(tb, c, R, L, k, taug, plfrac);
-            if (active) { tg[(size_t)k * LW_NGPT] = taug; fr[(size_t)k * LW_NGPT] = plfrac; }
-        }
+        run(R, 0, ltrop);
     }
     {
         const LwRegime R = gd->up;
-        for (int k = ltrop; k < nl; ++k) {
-            double taug, plfrac;
-            gas_optics(tb, c, R, L, k, taug, plfrac);
-            if (active) { tg[(size_t)k * LW_NGPT] = taug; fr[(size_t)k * LW_NGPT] = plfrac; }
-        }
+        run(R, ltrop, nl);
     }
 }
 
@@ -1146,7 +1235,262 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     }
 }
 
+// The transfer kernel as the patched radiation_driver calls it: no layer-flux profiles (LWUPFLX.. are optional
+// arguments the driver does not receive, DRV:1528-1577).  Then only the call with aerosol needs fluxes at the model
+// levels (heating rates); the clean-sky call and, in cloudy columns, the clear-sky stream are used at the surface and
+// at the top only.  Their downward recurrences are carried along anyway; their upward flux at the top follows in the
+// SAME top-down sweep from the linearity of the upward recurrence (LW:3331-3356):
+//     radlu(top) = radlu(0) * prod_k (1 - A_k) + sum_k S_k * prod_{j > k} (1 - A_j)
+// with (A_k, S_k) = (atrans, bbugas*atrans) of a clear layer or (atrans + efclfrac*(1 - atrans), gassrc +
+// cldfmc*(bbutot*atot - gassrc)) of a cloudy one.  The upward sweep is left with one stream, and the spectral sums
+// (LW:3366-3377) are taken four levels at a time.
+template <bool DEEP>
+__device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
+{
+    extern __shared__ double lds[];
+    const LwDeviceTables &tb = a.tab;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nk = a.nk, nl = a.nlayers;
+    const int slot = batch_slot();
+    const int col = a.col0 + slot;
+    const bool cloud = a.icloud != 0;
+    LCol c = carve_rt(lds, nl, cloud);
+    {
+        const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
+        const int n = (int)(cloud ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
+        for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
+    }
+    const double *cb = lds + lw_rec_base_doubles(nl);
+    __shared__ unsigned long long s_lmask[2];
+    __shared__ unsigned long long s_cmhi[LW_THREADS];
+    if (tid == 0) { s_lmask[0] = 0ull; s_lmask[1] = 0ull; }
+    const int it = col % a.ni_t, jt = col / a.ni_t;
+    const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
+    const size_t i2 = j0 * a.ni_m + i0;
+    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
+    const size_t base3 = j0 * sj + k0 * sk + i0;
+    const int r4 = a.real4;
+    const double semiss = ldr(a.emiss, i2, r4);
+
+    const int gbeg = wave * LW_CHUNK;
+    const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
+    const bool active = lane < gcnt;
+    const int g = gbeg + (active ? lane : gcnt - 1);
+    const LwGDesc *gd = tb.gdesc + g;
+    const int band = gd->band;
+    const double wgt = active ? 0.5 * gd->delwave : 0.;
+    // the clean-sky call differs from the one with aerosol only if there is aerosol; without it the reference's
+    // two calls are the same arithmetic on the same numbers, and the outputs are copies
+    const bool clean_on = a.clean > 0, clean_own = clean_on && a.aer_ra_feedback == 1;
+    const int nlev = nl + 1;
+    const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    __syncthreads();
+    const double secdiff = c.secdiff[band];
+    // per wave: downward and upward flux of the call with aerosol at every level, then the small sums
+    // [0..2] clean sky: surface down, surface up, top up; [4..6] clear sky alike
+    double *fl = c.flux + (size_t)wave * (2 * nlev + 8);
+    double *fsum = fl + 2 * nlev;
+    const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
+
+    uint64_t cmask = 0;
+    constexpr bool deep = DEEP;
+    int iceflag = 3;
+    if (cloud) {
+        if (a.has_reqi != 0) iceflag = 4;
+        if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
+        KissState ks = {(uint32_t)(int)cb[10 * nl + 0], (uint32_t)(int)cb[10 * nl + 1], (uint32_t)(int)cb[10 * nl + 2],
+                        (uint32_t)(int)cb[10 * nl + 3]};
+        kiss_jump(ks, a.jump + (size_t)g * KISS_JUMP_WORDS);
+        double prev = 0.;
+        uint64_t cmhi = 0;
+        for (int l = 0; l < nk; ++l) {
+            double cur = kiss_next(ks);
+            if (l > 0) {
+                const double cbl = cb[l - 1];
+                cur = prev > 1. - cbl ? prev : cur * (1. - cbl);
+            }
+            if (cur >= 1. - cb[l]) {
+                if (l < 64) cmask |= (uint64_t)1 << l; else cmhi |= (uint64_t)1 << (l - 64);
+            }
+            prev = cur;
+        }
+        uint64_t m = active ? cmask : 0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
+        if (lane == 0 && m) atomicOr(&s_lmask[0], (unsigned long long)m);
+        if (deep) {
+            s_cmhi[tid] = cmhi;
+            m = active ? cmhi : 0;
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
+            if (lane == 0 && m) atomicOr(&s_lmask[1], (unsigned long long)m);
+        }
+        __syncthreads();
+    }
+    const uint64_t lmask = cloud ? (uint64_t)s_lmask[0] : 0;
+    const bool col_cloudy = lmask != 0 || (cloud && deep && s_lmask[1] != 0);
+    int bad = 0;
+    const bool writer = (lane & 15) == 0;
+    const int wrow = wsum_index(lane >> 4);
+
+    // ---- downward sweep (top -> surface), LW:3207-3312, in blocks of four layers ----
+    double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
+    double ec = 0., trc = 1., ek = 0., trk = 1.;   // upward flux at the top of the clean / clear stream, see above
+    bool iclddn = false;
+    if (lane == 0) fl[nl] = 0.;
+    const int nblk = (nl + 3) >> 2;
+    double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
+    for (int b = nblk - 1; b >= 0; --b) {
+        double v[4] = {0., 0., 0., 0.};
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const int k = b * 4 + j;
+            if (k < nl) {
+                const double taug = tnext, plfrac = fnext;
+                if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
+                const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+                const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
+                if (!lay_cld) {
+                    double at, bbd, bbu;
+                    layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                    radld_t = relax(radld_t, bbd, at);
+                    if (col_cloudy) {
+                        radclr = iclddn ? relax(radclr, bbd, at) : radld_t;   // LW:3304-3311
+                        ek = __builtin_fma(bbu * at, trk, ek);
+                        trk = __builtin_fma(-trk, at, trk);
+                    }
+                    if (clean_own) {
+                        // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
+                        if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                        radld_c = relax(radld_c, bbd, at);
+                        ec = __builtin_fma(bbu * at, trc, ec);
+                        trc = __builtin_fma(-trc, at, trc);
+                    }
+                } else {
+                    iclddn = true;
+                    const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
+                    const double cfm = cl ? 1. : 0.;
+                    double odcld = 0., efcl = 0.;
+                    if (cl) {
+                        odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);   // LW:3172-3176
+                        efcl = 1. - exp_neg(odcld);
+                    }
+                    LwCldSrc s;
+                    layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                    double gassrc = s.bbd * s.atrans;
+                    radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+                    radclr = radclr + (s.bbd - radclr) * s.atrans;
+                    ek = __builtin_fma(s.bbugas * s.atrans, trk, ek);
+                    trk = __builtin_fma(-trk, s.atrans, trk);
+                    if (clean_own) {
+                        layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                        gassrc = s.bbd * s.atrans;
+                        const double A = s.atrans + efcl * (1. - s.atrans);
+                        radld_c = radld_c - radld_c * A + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+                        const double gasu = s.bbugas * s.atrans;
+                        ec = __builtin_fma(gasu + cfm * (s.bbutot * s.atot - gasu), trc, ec);
+                        trc = __builtin_fma(-trc, A, trc);
+                    }
+                }
+                v[j] = wgt * radld_t;
+                frac0 = plfrac;
+            }
+        }
+        // downward flux at the bottom of the block's layers = levels 4b .. 4b+3
+        const double q = wave_sum4(v[0], v[1], v[2], v[3]);
+        if (writer && b * 4 + wrow < nl) fl[b * 4 + wrow] = q;
+    }
+    // ---- surface: emission + reflection, LW:3320-3324 ----
+    const double rad0 = frac0 * c.plankbnd[band];
+    const double reflect = 1. - semiss;
+    double radlu_t = __builtin_fma(reflect, radld_t, rad0);
+    {
+        const double radlu_c = __builtin_fma(reflect, radld_c, rad0), radclru = __builtin_fma(reflect, radclr, rad0);
+        const double topc = __builtin_fma(trc, radlu_c, ec), topk = __builtin_fma(trk, radclru, ek);
+        const double q0 = wave_sum4(wgt * radld_c, wgt * radlu_c, wgt * topc, wgt * radlu_t);
+        const double q1 = wave_sum4(wgt * radclr, wgt * radclru, wgt * topk, 0.);
+        if (writer) {
+            if (wrow < 3) { fsum[wrow] = q0; fsum[4 + wrow] = q1; }
+            else fl[nlev] = q0;   // upward flux of the call with aerosol at the surface
+        }
+    }
+    // ---- upward sweep (surface -> top), LW:3331-3356: the call with aerosol ----
+    for (int b = 0; b < nblk; ++b) {   // tnext / fnext hold layer 0 after the downward sweep
+        double v[4] = {0., 0., 0., 0.};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = b * 4 + j;
+            if (k < nl) {
+                const double taug = tnext, plfrac = fnext;
+                if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
+                const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+                const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
+                if (!lay_cld) {
+                    double at, bbd, bbu;
+                    layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                    radlu_t = relax(radlu_t, bbu, at);
+                } else {
+                    const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
+                    const double cfm = cl ? 1. : 0.;
+                    double odcld = 0., efcl = 0.;
+                    if (cl) {
+                        odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);
+                        efcl = 1. - exp_neg(odcld);
+                    }
+                    LwCldSrc s;
+                    layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                    const double gassrc = s.bbugas * s.atrans;
+                    radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
+                }
+                v[j] = wgt * radlu_t;
+            }
+        }
+        // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
+        const double q = wave_sum4(v[0], v[1], v[2], v[3]);
+        if (writer && b * 4 + wrow < nl) fl[nlev + b * 4 + 1 + wrow] = q;
+    }
+    if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
+    __syncthreads();
+
+    // ======================= epilogue: lanes = levels =======================
+    const size_t ws = 2 * nlev + 8;
+    const double *f0 = c.flux, *f1 = c.flux + ws, *f2 = c.flux + 2 * ws;
+    auto dnl = [&](int lev) { return (f0[lev] + f1[lev] + f2[lev]) * tb.fluxfac; };
+    auto upl = [&](int lev) { return (f0[nlev + lev] + f1[nlev + lev] + f2[nlev + lev]) * tb.fluxfac; };
+    auto sm = [&](int q) { return (f0[2 * nlev + q] + f1[2 * nlev + q] + f2[2 * nlev + q]) * tb.fluxfac; };
+    for (int l = tid; l < nk; l += LW_THREADS) {
+        if (a.rthratenlw) {
+            // htr(l) = heatfac*(fnet(l)-fnet(l+1))/(pz(l)-pz(l+1)), LW:3402; then LW:12687-12690
+            const double fnet0 = upl(l) - dnl(l), fnet1 = upl(l + 1) - dnl(l + 1);
+            const double htr = tb.heatfac * (fnet0 - fnet1) / (c.pz[l] - c.pz[l + 1]);
+            const double tten = htr / 86400.;
+            str(a.rthratenlw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
+        }
+    }
+    if (tid == 0) {
+        const double dnb = dnl(0), upb = upl(0), upt = upl(nl), dnt = dnl(nl);
+        // clean sky: own stream, a copy of the call with aerosol when there is no aerosol, zero when switched off
+        const double dnbc = clean_own ? sm(0) : (clean_on ? dnb : 0.), upbc = clean_own ? sm(1) : (clean_on ? upb : 0.),
+                     uptc = clean_own ? sm(2) : (clean_on ? upt : 0.), dntc = clean_on ? dnt : 0.;
+        // clear sky (aerosol call): own stream in a cloudy column, else the total-sky values (LW:3304-3311)
+        const double dnbk = col_cloudy ? sm(4) : dnb, upbk = col_cloudy ? sm(5) : upb, uptk = col_cloudy ? sm(6) : upt;
+        if (a.glw) str(a.glw, i2, r4, dnb);
+        if (a.olr) str(a.olr, i2, r4, upt);
+        if (a.lwcf) str(a.lwcf, i2, r4, uptk - upt);   // LW:12658
+        if (a.lwupt) {
+            str(a.lwupb, i2, r4, upb); str(a.lwupbc, i2, r4, upbk); str(a.lwdnb, i2, r4, dnb); str(a.lwdnbc, i2, r4, dnbk);
+            str(a.lwupbcln, i2, r4, upbc); str(a.lwdnbcln, i2, r4, dnbc);
+            str(a.lwupt, i2, r4, upt); str(a.lwuptc, i2, r4, uptk); str(a.lwdnt, i2, r4, dnt); str(a.lwdntc, i2, r4, dnt);
+            str(a.lwuptcln, i2, r4, uptc); str(a.lwdntcln, i2, r4, dntc);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a) { lw_rt_body<false>(a); }
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false>(a); }
+__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true>(a); }
 __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
 
@@ -1220,6 +1564,12 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_deep_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_deep_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
         if (e != hipSuccess) return e;
         attr_rt = lds_rt;
     }
@@ -1232,7 +1582,10 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         const int n = ncol - c0 < cap_cols ? ncol - c0 : cap_cols;
         a.col0 = c0;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
-        if (deep) hipLaunchKernelGGL(lw_rt_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+        if (!a.lwupflx) {   // no layer-flux profiles requested: what the radiation driver calls
+            if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+            else hipLaunchKernelGGL(lw_rt_fast_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+        } else if (deep) hipLaunchKernelGGL(lw_rt_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
         else hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
     }
     return hipGetLastError();
