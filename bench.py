@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: aerosol + clean-sky RRTMG SW+LW double call on MI355X.
 
-A "step" is one pass of the HIP path -- MOSAIC 4-bin optical averaging, then
-RRTMG_SWRAD + RRTMG_LWRAD, each with its aerosol and clean-sky call -- over one
-batch of synthetic WRF columns resident in HBM.  Workload at N=1: 200x200x40
-synthetic columns, fp64 = BASELINE.json configs[2] (`--mode full`, default).
-`--mode swlw` skips the optics stage (aerosol optics supplied in the WRF-Chem
-compact form, 12 SW + 16 LW arrays); `--mode sw` runs configs[1] (SW double
-call only).  With --gpus N each rank owns its own 200x200 slab of
-(i,j) columns (weak scaling, no data-path collective); the only exchange is an
-all-reduce of the per-tile flux sums (32 doubles) over RCCL.
+A "step" is one pass of the HIP path -- MOSAIC optical averaging, then RRTMG_SWRAD + RRTMG_LWRAD, each with its
+aerosol and its clean-sky call -- over one synthetic domain resident in HBM.  The default workload is the domain the
+north-star target is quoted on, BASELINE.json configs[3]: 500x500x50, MOSAIC 8-bin optics, SW+LW, fp64.
+`--config 1|2|4` select the other BASELINE configurations (1: 200x200x40 SW only, 2: 200x200x40 4-bin SW+LW,
+4: 1000x1000x60 mixed-precision optics); `--ni/--nj/--nk/--nbin/--mode/--optics-precision` override single items.
+
+With --gpus N (one rank per GPU, launched by torch.distributed.run) the SAME domain is cut into N j-slabs
+(tiles.slab_bounds, weighted by daylit columns when --night > 0; reference tile model DRV:975-982): every rank builds
+only its slab, there is no data-path collective, and the one exchange is an all-reduce (RCCL) of the 32 per-tile flux
+sums -- "scaling": "strong".  `--scaling weak` gives every rank its own full domain instead.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -26,11 +29,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6        # fp64 vector peak: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
 P_TOP = 5000.0                 # Pa, model top of the synthetic atmosphere
+
+CONFIGS = {
+    1: dict(ni=200, nj=200, nk=40, mode="sw", nbin=4, prec="f64"),
+    2: dict(ni=200, nj=200, nk=40, mode="full", nbin=4, prec="f64"),
+    3: dict(ni=500, nj=500, nk=50, mode="full", nbin=8, prec="f64"),
+    4: dict(ni=1000, nj=1000, nk=60, mode="full", nbin=4, prec="mixed"),
+}
+
+# argument names of the two radiation entry points (the reference's dummy-argument names, SW:9901-9945, LW:11451-11486)
+SW_IN2 = ["xcoszen", "albedo", "tsk"]
+ST_IN3 = ["t3d", "t8w", "p3d", "p8w", "pi3d", "qv3d"]
+SW_AER = ["tauaer300", "tauaer400", "tauaer600", "tauaer999", "gaer300", "gaer400", "gaer600", "gaer999",
+          "waer300", "waer400", "waer600", "waer999"]
+SW_OUT2 = ["coszr", "gsw", "swcf", "swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
+           "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln",
+           "swvisdir", "swvisdif", "swnirdir", "swnirdif", "swddir", "swddni", "swddif"]
+LW_IN2 = ["emiss", "tsk"]
+LW_AER = [f"tauaerlw{b}" for b in range(1, 17)]
+LW_OUT2 = ["glw", "olr", "lwcf", "lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
+           "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
+SW12 = ["swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
+        "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln"]
+LW12 = ["lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
+        "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
+CLD3 = ["cldfra3d", "qc3d", "qr3d", "qi3d", "qs3d"]
+CLD2 = ["xland", "xice", "snow"]
 
 
 def algorithmic_bytes_per_column(nk, mode, real_bytes=8):
-    """Compulsory boundary traffic with the WRF-Chem compact aerosol form (DESIGN.md 'Measurement').
+    """Compulsory boundary traffic with the WRF-Chem compact aerosol form.
     SW: reads p3d,t3d,qv3d,pi3d (4K), p8w,t8w (2(K+1)), 12 aerosol arrays (12K), 3 surface scalars;
         writes rthratensw (K) and 22 two-dimensional fields.
     LW: reads the same 6 state arrays again (second launch), 16 aerosol arrays (16K), 2 scalars;
@@ -48,111 +78,223 @@ def optics_bytes_per_column(nk, nbin, real_bytes=8, part="all"):
         return (rd + 12) * nk * real_bytes
     if part == "lw":
         return (rd + 16) * nk * real_bytes
-    return (rd + 12 + 16) * nk * real_bytes
+    return (2 * rd + 12 + 16) * nk * real_bytes
 
 
-def cpu_optics_seconds_per_column(wa, st, ms, ncol_sample):
-    """The optical-averaging stage has no reference arithmetic: timed from the C port, one thread."""
-    from oracle import oracle_optics as oo
-    from tests.helpers_optics import oracle_tables
-    lib = oo._lib()
-    lib.omp_set_num_threads(1)
-    nj = max(1, min(st.nj, ncol_sample // st.ni))
-    d = dict(ims=1, ime=st.ni, jms=1, jme=st.nj, kms=1, kme=st.nk + 1, its=1, ite=st.ni, jts=1, jte=nj, kts=1, kte=st.nk)
+def dims_of(ni, nj, nk, tile=None):
+    d = dict(ims=1, ime=ni, jms=1, jme=nj, kms=1, kme=nk + 1, its=1, ite=ni, jts=1, jte=nj, kts=1, kte=nk)
+    if tile:
+        d.update(tile)
+    return d
+
+
+def night_rows(ni, nj, seed, frac):
+    """Per-row night mask of the global domain (any rank can evaluate any row): True = night column."""
+    if frac <= 0.0:
+        return np.zeros((nj, ni), dtype=bool)
+    return np.stack([np.random.default_rng(seed + 104729 * j).uniform(size=ni) < frac for j in range(nj)])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU-baseline leg: the only part of bench.py that touches oracle/ (and oracle/_ref, the reference Fortran compiled
+# from /root/reference by oracle/build_ref.sh; the binaries travel, the sources do not).
+# ----------------------------------------------------------------------------------------------------------------
+def _ref_seconds(run, tab, cols, nproc):
+    """Runs the reference harness on `cols` split over nproc processes; returns (solver seconds of the slowest
+    process, wall seconds)."""
+    n = len(next(iter(cols.values())))
+    cuts = [n * p // nproc for p in range(nproc + 1)]
+    parts = [{k: v[cuts[p]:cuts[p + 1]] for k, v in cols.items()} for p in range(nproc) if cuts[p + 1] > cuts[p]]
     t0 = time.perf_counter()
-    oo.tile(oracle_tables(wa, ms.nbin), ms.chem, ms.alt, ms.dz8w, ms.idx, d)
-    secs = time.perf_counter() - t0
-    return secs / (nj * st.ni), nj * st.ni
+    with ThreadPoolExecutor(max_workers=len(parts)) as ex:
+        outs = list(ex.map(lambda c: run(tab, c, clean=1)[1], parts))
+    wall = time.perf_counter() - t0
+    return max(float(o.split("seconds=")[1].split()[0]) for o in outs), wall
 
 
-def cpu_baseline(tab_sw, tab_lw, st, ncol_sample, mode):
-    """Reference Fortran (oracle/_ref, built from /root/reference by oracle/build_ref.sh) timed on one host
-    core over a bounded sample of the same workload; falls back to the C port if the binaries are absent."""
+def cpu_baseline(wa, tab_sw, tab_lw, st, ms, mode, ncol_1t, ncol_per_core, ncol_optics):
+    """Reference Fortran rrtmg_sw + rrtmg_lw (oracle/_ref, flang -O2, fp64) on a bounded sample of the bench
+    workload: once on one core, once with one process per host core (columns are independent -- the reference's own
+    parallelism is MPI patches / OpenMP tiles of columns, DRV:975-982).  The optical-averaging stage has no reference
+    arithmetic: its CPU time comes from the C port of the engine's own specification (OpenMP over
+    columns)."""
     from tools.make_golden import sw_columns_from_state, run_ref_sw
     from tools.make_golden_lw import lw_columns_from_state, run_ref_lw
-    have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_sw")) and \
-        os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_lw"))
-    cols = {k: v[:ncol_sample] for k, v in sw_columns_from_state(st).items()}
-    if have_ref:
-        _, so = run_ref_sw(tab_sw, cols, clean=1)
-        secs_sw = float(so.split("seconds=")[1].split()[0])
-        secs_lw = 0.0
-        if mode != "sw":
-            lcols = {k: v[:ncol_sample] for k, v in lw_columns_from_state(st).items()}
-            _, lo = run_ref_lw(tab_lw, lcols, clean=1)
-            secs_lw = float(lo.split("seconds=")[1].split()[0])
-        secs = secs_sw + secs_lw
-        return {"value": ncol_sample / secs, "unit": "columns/s", "cores": 1, "kind": "reference",
-                "sample": f"{ncol_sample} columns of the bench workload through the reference rrtmg_sw"
-                          f"{' + rrtmg_lw' if mode != 'sw' else ''} (flang -O2, fp64, 1 core): "
-                          f"SW {secs_sw:.2f} s, LW {secs_lw:.2f} s solver time",
-                "seconds_per_column": secs / ncol_sample}
-    from oracle import oracle as orc
-    o = orc.SwOracle(tab_sw)
-    n = min(ncol_sample, 256)
-    t0 = time.perf_counter()
-    o.rrtmg_sw({k: v[:n] for k, v in cols.items()}, clean=1)
-    secs = time.perf_counter() - t0
-    return {"value": n / secs, "unit": "columns/s", "cores": 1, "kind": "port",
-            "sample": f"{n} columns through the C restatement of rrtmg_sw only (gcc -O2), {secs:.2f} s"}
+    have_ref = all(os.path.exists(os.path.join(ROOT, "oracle", "_ref", b)) for b in ("ref_sw", "ref_lw"))
+    if not have_ref:
+        raise RuntimeError("oracle/_ref/ref_sw, ref_lw not built (oracle/build_ref.sh needs /root/reference)")
+    host_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(host_cpus, 64)      # processes / threads actually used (a GPU box shares its host; 64 bounds the load)
+    # the sample: the first rows of the slab (the column lists are built for those rows only)
+    import copy
+    rows = min(st.nj, -(-max(ncol_1t, ncol_per_core * cores) // st.ni))
+    sub = copy.copy(st)
+    sub.nj = rows
+    sub.a2 = {n: v[:rows] for n, v in st.a2.items()}
+    sub.a3 = {n: v[:rows] for n, v in st.a3.items()}
+    ncol = sub.ncol
+    swc = sw_columns_from_state(sub)
+    lwc = lw_columns_from_state(sub) if mode != "sw" else None
+
+    def rate(n, nproc):
+        n = min(n, ncol)
+        s_sw, _ = _ref_seconds(run_ref_sw, tab_sw, {k: v[:n] for k, v in swc.items()}, nproc)
+        s_lw = 0.0
+        if lwc is not None:
+            s_lw, _ = _ref_seconds(run_ref_lw, tab_lw, {k: v[:n] for k, v in lwc.items()}, nproc)
+        return n, s_sw, s_lw
+
+    n1, sw1, lw1 = rate(ncol_1t, 1)
+    nall, swa, lwa = rate(ncol_per_core * cores, cores)
+    spc1, spca = (sw1 + lw1) / n1, (swa + lwa) / nall
+    res = {"unit": "columns/s", "cores": cores, "host_cpus": host_cpus, "kind": "reference",
+           "threads_1": {"columns": n1, "sw_s": sw1, "lw_s": lw1},
+           "threads_all": {"columns": nall, "processes": cores, "sw_s": swa, "lw_s": lwa}}
+    sample = (f"reference rrtmg_sw{' + rrtmg_lw' if lwc is not None else ''} (oracle/_ref, flang -O2, fp64), solver time: "
+              f"{n1} columns on 1 core (SW {sw1:.2f} s, LW {lw1:.2f} s); {nall} columns over {cores} processes, one "
+              f"per host core (SW {swa:.2f} s, LW {lwa:.2f} s)")
+    if ms is not None:
+        from oracle import oracle_optics as oo
+        lib = oo._lib()
+        wl, ref, den = wa.engine_optics.table_info()
+        tabs = oo.make_tables(ms.nbin, wa.engine_optics.MOSAIC_DLO_UM, wa.engine_optics.MOSAIC_DHI_UM, wl, ref, den)
+
+        def opt_rate(nthreads, ncols):
+            lib.omp_set_num_threads(nthreads)
+            nj = max(1, min(st.nj, ncols // st.ni))
+            t0 = time.perf_counter()
+            oo.tile(tabs, ms.chem, ms.alt, ms.dz8w, ms.idx, dims_of(st.ni, st.nj, st.nk, dict(jte=nj)))
+            return (time.perf_counter() - t0) / (nj * st.ni), nj * st.ni
+        o1, no1 = opt_rate(1, ncol_optics)
+        oa, noa = opt_rate(cores, ncol_optics * min(cores, 8))
+        lib.omp_set_num_threads(1)
+        spc1 += o1
+        spca += oa
+        res["threads_1"]["optics_s_per_column"] = o1
+        res["threads_all"]["optics_s_per_column"] = oa
+        sample += (f"; optical averaging through the C port of the engine's own specification (no reference arithmetic "
+                   f"exists): {no1} columns on 1 thread, {noa} columns on {cores} OpenMP threads")
+    res["value"] = 1.0 / spca
+    res["value_1_thread"] = 1.0 / spc1
+    res["sample"] = sample
+    return res
 
 
-def flux_rmse(tab_sw, tab_lw, st, sw_out, lw_out, nrows, mode):
-    """The second half of the metric: root-mean-square difference between the device's fluxes / heating rates and
-    the CPU restatement of the reference (bit-exact with the reference solvers on the golden fixtures) over the
-    first `nrows` rows of the tile.  Part of the CPU-baseline leg (the only place bench.py touches oracle/)."""
-    from oracle import oracle as orc, oracle_lw
-    from tests.helpers import run_oracle_swrad
-    from tests.helpers_lw import run_oracle_lwrad
+def flux_rmse(wa, tab_sw, tab_lw, st, ms, sw_out, lw_out, nrows, mode):
+    """The second half of the metric: root-mean-square difference between the device's fluxes / heating rates and the
+    CPU restatement of the reference (pinned bit for bit on the reference solvers) over the first `nrows` rows of the
+    rank-0 slab.  The CPU leg is independent of the device from the tracers on: its optical averaging is the oracle's
+    own, so an error of the device's optics (either precision) shows up in the flux error."""
+    from oracle import oracle as orc, oracle_lw, oracle_optics as oo
     tile = dict(jts=1, jte=nrows)
-    res = {"columns": nrows * st.ni, "against": "oracle/ (C restatement, pinned bit for bit on the reference solvers)"}
+    a3 = dict(st.a3)
+    against = "oracle/ (C restatement, pinned bit for bit on the reference solvers)"
+    if ms is not None:
+        wl, ref, den = wa.engine_optics.table_info()
+        tabs = oo.make_tables(ms.nbin, wa.engine_optics.MOSAIC_DLO_UM, wa.engine_optics.MOSAIC_DHI_UM, wl, ref, den)
+        oo._lib().omp_set_num_threads(len(os.sched_getaffinity(0)))
+        opt = oo.tile(tabs, ms.chem, ms.alt, ms.dz8w, ms.idx, dims_of(st.ni, st.nj, st.nk, tile))
+        oo._lib().omp_set_num_threads(1)
+        for w, nm in enumerate(("300", "400", "600", "999"), start=1):
+            for stem in ("tauaer", "waer", "gaer"):
+                a = opt[f"{stem}{w}"].copy()
+                a[a == -7777.0] = 0.0
+                a3[stem + nm] = a
+        for b in range(1, 17):
+            a = opt[f"tauaerlw{b}"].copy()
+            a[a == -7777.0] = 0.0
+            a3[f"tauaerlw{b}"] = a
+        against += "; optical averaging by the oracle's own Mie code from the same tracers (fp64)"
+    res = {"columns": nrows * st.ni, "against": against}
+    d = dims_of(st.ni, st.nj, st.nk, tile)
+
+    def alloc(names2, name3):
+        out = {name3: np.full((st.nj, st.nk + 1, st.ni), -7777.0)}
+        out.update({n: np.full((st.nj, st.ni), -7777.0) for n in names2})
+        return out
 
     def rms(got, ref, names, rows3=False):
-        d = []
+        dd = []
         for n in names:
             g = got[n].cpu().numpy()
-            d.append((g[:nrows] - ref[n][:nrows]).ravel() if not rows3 else (g[:nrows, :st.nk] - ref[n][:nrows, :st.nk]).ravel())
-        d = np.concatenate(d)
-        return float(np.sqrt(np.mean(d * d))), float(np.abs(d).max())
+            dd.append((g[:nrows] - ref[n][:nrows]).ravel() if not rows3 else (g[:nrows, :st.nk] - ref[n][:nrows, :st.nk]).ravel())
+        dd = np.concatenate(dd)
+        return float(np.sqrt(np.mean(dd * dd))), float(np.abs(dd).max())
 
-    ref = run_oracle_swrad(orc.SwOracle(tab_sw), st, tile=tile, profiles=False)
-    sw2 = [n for n in ref if n.startswith(("swup", "swdn")) and ref[n].ndim == 2]
-    res["sw_flux_rmse_Wm2"], res["sw_flux_maxabs_Wm2"] = rms(sw_out, ref, sw2)
-    res["sw_heating_rmse_K_per_day"] = rms(sw_out, ref, ["rthratensw"], rows3=True)[0] * 86400.0
+    ref = alloc(SW_OUT2, "rthratensw")
+    arrays = {n: st.a2[n] for n in SW_IN2}
+    arrays.update({n: a3[n] for n in ST_IN3 + SW_AER})
+    orc.swrad_tile(orc.SwOracle(tab_sw), d, arrays, 1370.0, 1, 1, ref)
+    day = st.a2["xcoszen"][:nrows] > 0
+    for n in SW12:   # night columns: both sides write zeros
+        ref[n][:nrows][~day] = 0.0
+    res["sw_flux_rmse_Wm2"], res["sw_flux_maxabs_Wm2"] = rms(sw_out, ref, SW12)
+    hr_g = sw_out["rthratensw"].cpu().numpy()[:nrows, :st.nk][np.broadcast_to(day[:, None, :], (nrows, st.nk, st.ni))]
+    hr_r = ref["rthratensw"][:nrows, :st.nk][np.broadcast_to(day[:, None, :], (nrows, st.nk, st.ni))]
+    res["sw_heating_rmse_K_per_day"] = float(np.sqrt(np.mean((hr_g - hr_r) ** 2))) * 86400.0
+    res["sw_forcing_rmse_Wm2"] = float(np.sqrt(np.mean(
+        ((sw_out["swuptcln"] - sw_out["swupt"]).cpu().numpy()[:nrows] - (ref["swuptcln"] - ref["swupt"])[:nrows]) ** 2)))
     if mode != "sw":
         nlay = oracle_lw.nlayers(st.nk + 1, P_TOP)
-        refl = run_oracle_lwrad(oracle_lw.LwOracle(tab_lw), st, nlay, tile=tile, profiles=False)
-        lw2 = [n for n in refl if n.startswith(("lwup", "lwdn")) and refl[n].ndim == 2]
-        res["lw_flux_rmse_Wm2"], res["lw_flux_maxabs_Wm2"] = rms(lw_out, refl, lw2)
+        refl = alloc(LW_OUT2, "rthratenlw")
+        arrays = {n: st.a2[n] for n in LW_IN2}
+        arrays.update({n: a3[n] for n in ST_IN3 + LW_AER})
+        oracle_lw.lwrad_tile(oracle_lw.LwOracle(tab_lw), d, nlay, arrays, 1, 1, refl)
+        res["lw_flux_rmse_Wm2"], res["lw_flux_maxabs_Wm2"] = rms(lw_out, refl, LW12)
         res["lw_heating_rmse_K_per_day"] = rms(lw_out, refl, ["rthratenlw"], rows3=True)[0] * 86400.0
+        res["lw_forcing_rmse_Wm2"] = float(np.sqrt(np.mean(
+            ((lw_out["lwuptcln"] - lw_out["lwupt"]).cpu().numpy()[:nrows] - (refl["lwuptcln"] - refl["lwupt"])[:nrows]) ** 2)))
     return res
+
+
+def algorithmic_flops(wa, tab_sw, tab_lw, st, ms, mode, ncols=16):
+    """Exact fp64 operation count of the CPU restatement per column of THIS workload (oracle built with
+    -DORACLE_COUNT_FLOPS: every arithmetic operation of the column solvers goes through a counting type).
+    Returns None when the counting build is not present."""
+    try:
+        from oracle import flopcount
+    except Exception:
+        return None
+    return flopcount.per_column(wa, tab_sw, tab_lw, st, ms, mode, ncols)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ni", type=int, default=200)
-    ap.add_argument("--nj", type=int, default=200)
-    ap.add_argument("--nk", type=int, default=40)
-    ap.add_argument("--mode", choices=["full", "swlw", "sw"], default="full")
-    ap.add_argument("--nbin", type=int, default=4, help="MOSAIC sections of the optics stage (4 or 8)")
-    ap.add_argument("--optics-precision", choices=["f64", "mixed"], default="f64",
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="BASELINE.json configs[n]; 3 = the north-star domain (500x500x50, 8-bin, SW+LW, fp64)")
+    ap.add_argument("--ni", type=int)
+    ap.add_argument("--nj", type=int)
+    ap.add_argument("--nk", type=int)
+    ap.add_argument("--mode", choices=["full", "swlw", "sw"])
+    ap.add_argument("--nbin", type=int, help="MOSAIC sections of the optics stage (4 or 8)")
+    ap.add_argument("--optics-precision", choices=["f64", "mixed"],
                     help="mixed: the Mie series of the optical averaging in packed fp32 (BASELINE configs[4])")
-    ap.add_argument("--cpu-optics-sample", type=int, default=400)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = one domain cut into j-slabs (default), weak = one domain per rank")
     ap.add_argument("--night", type=float, default=0.0, help="fraction of night columns (0 for kernel timing)")
-    ap.add_argument("--cpu-sample", type=int, default=6000)
-    ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--clouds", type=float, default=0.0,
                     help="fraction of columns with 1-3 cloud decks (McICA path; 0 = cloud-free headline workload)")
+    ap.add_argument("--cpu-sample", type=int, default=4000, help="columns of the 1-core reference run")
+    ap.add_argument("--cpu-sample-per-core", type=int, default=2000, help="columns per process of the all-core run")
+    ap.add_argument("--cpu-optics-sample", type=int, default=500)
+    ap.add_argument("--host-path-rows", type=int, default=40,
+                    help="rows of the domain pushed through the mem = 0 (host pointer) entry points; 0 = skip")
+    ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k, a in (("ni", args.ni), ("nj", args.nj), ("nk", args.nk), ("mode", args.mode), ("nbin", args.nbin),
+                 ("prec", args.optics_precision)):
+        if a is not None:
+            cfg[k] = a
+    ni, nj, nk, mode, nbin, prec = cfg["ni"], cfg["nj"], cfg["nk"], cfg["mode"], cfg["nbin"], cfg["prec"]
+    is_config = all(cfg[k] == v for k, v in CONFIGS[args.config].items())
 
     import torch
     import torch.distributed as dist
     import wrfchem_arc_amd as wa
-    from tests.helpers import AER, IN2, IN3, OUT2, dims_of
-    from tests import helpers_lw as hl
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,35 +317,51 @@ def main():
     wa.synth.write_sw_data(tab, seed=20260001, real_bytes=8)
     wa.synth.write_lw_data(tabl, seed=20260003, real_bytes=8)
     eng.rrtmg_swinit(tab, 8, device=local_rank)
-    do_lw = args.mode != "sw"
-    do_opt = args.mode == "full"
+    do_lw = mode != "sw"
+    do_opt = mode == "full"
     if do_opt:
-        wa.engine_optics.optics_init(args.nbin, device=local_rank)
-        wa.engine_optics.optics_precision(args.optics_precision)
+        wa.engine_optics.optics_init(nbin, device=local_rank)
+        wa.engine_optics.optics_precision(prec)
     if do_lw:
-        engl.rrtmg_lwinit(P_TOP, tabl, kme=args.nk + 1, device=local_rank)
+        engl.rrtmg_lwinit(P_TOP, tabl, kme=nk + 1, device=local_rank)
 
-    # each rank: its own (i,j) slab of the domain
-    st = wa.synth.make_wrf_state(args.ni, args.nj, args.nk, seed=20260002 + 1000 * rank, night_fraction=args.night)
+    # ---- this rank's slab of the domain ----
+    strong = args.scaling == "strong" or world == 1
+    wseed, mseed, nseed, cseed = 20260002, 20260005, 20260009, 20260007
+    if strong:
+        night = night_rows(ni, nj, nseed, args.night)                   # cheap: any rank evaluates every row
+        weights = (~night).sum(axis=1) if args.night > 0 else None
+        js, je = wa.tiles.slab_bounds(1, nj, world, rank, weights=weights)   # WRF indices, inclusive
+        j0, j1 = js - 1, je
+    else:
+        wseed += 1000003 * rank
+        mseed += 1000003 * rank
+        night = night_rows(ni, nj, nseed + 1000003 * rank, args.night)
+        j0, j1 = 0, nj
+    if do_opt:
+        st, ms = wa.synth_mosaic.make_mosaic_rows(ni, nj, nk, j0, j1, nbin=nbin, seed=mseed, wrf_seed=wseed)
+    else:
+        st, ms = wa.synth.make_wrf_rows(ni, nj, nk, j0, j1, seed=wseed), None
+    if args.night > 0:
+        st.a2["xcoszen"] = np.where(night[j0:j1], -0.3, st.a2["xcoszen"])
     ncol = st.ncol
-    d = dims_of(st)
+    ncol_job = ni * nj if strong else world * ni * nj
+    d = dims_of(ni, st.nj, nk)
 
     def dev(a):
         return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
-    sw_in = {n: dev(st.a2[n]) for n in IN2}
-    sw_in.update({n: dev(st.a3[n]) for n in IN3 + AER})
-    sw_out = {"rthratensw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
-    sw_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in OUT2})
-    lw_in = {n: dev(st.a2[n]) for n in hl.IN2}
-    lw_in.update({n: sw_in[n] for n in hl.IN3})            # the same state arrays, not copies
-    lw_in.update({n: dev(st.a3[n]) for n in hl.AER})
-    lw_out = {"rthratenlw": torch.zeros((st.nj, st.nk + 1, st.ni), dtype=torch.float64, device="cuda")}
-    lw_out.update({n: torch.zeros((st.nj, st.ni), dtype=torch.float64, device="cuda") for n in hl.OUT2})
-    ms = None
+    sw_in = {n: dev(st.a2[n]) for n in SW_IN2}
+    sw_in.update({n: dev(st.a3[n]) for n in ST_IN3 + SW_AER})
+    sw_out = {"rthratensw": torch.zeros((st.nj, nk + 1, ni), dtype=torch.float64, device="cuda")}
+    sw_out.update({n: torch.zeros((st.nj, ni), dtype=torch.float64, device="cuda") for n in SW_OUT2})
+    lw_in = {n: dev(st.a2[n]) for n in LW_IN2}
+    lw_in.update({n: sw_in[n] for n in ST_IN3})              # the same state arrays, not copies
+    lw_in.update({n: dev(st.a3[n]) for n in LW_AER})
+    lw_out = {"rthratenlw": torch.zeros((st.nj, nk + 1, ni), dtype=torch.float64, device="cuda")}
+    lw_out.update({n: torch.zeros((st.nj, ni), dtype=torch.float64, device="cuda") for n in LW_OUT2})
     if do_opt:
         # MOSAIC tracers -> the aerosol inputs of the two radiation calls (written in place every step)
-        ms = wa.synth_mosaic.make_mosaic_state(st, nbin=args.nbin, seed=20260005 + 1000 * rank)
         opt_in = dict(chem=dev(ms.chem), alt=dev(ms.alt), dz8w=dev(ms.dz8w))
         opt_out = {}
         for w, nm in enumerate(("300", "400", "600", "999"), start=1):
@@ -214,32 +372,33 @@ def main():
         for t in opt_out.values():
             t.zero_()
     sums = torch.zeros(32, dtype=torch.float64, device="cuda")
-    sw12 = ["swupt", "swuptc", "swuptcln", "swdnt", "swdntc", "swdntcln",
-            "swupb", "swupbc", "swupbcln", "swdnb", "swdnbc", "swdnbcln"]
-    lw12 = ["lwupt", "lwuptc", "lwuptcln", "lwdnt", "lwdntc", "lwdntcln",
-            "lwupb", "lwupbc", "lwupbcln", "lwdnb", "lwdnbc", "lwdnbcln"]
 
     cld_flags, cld_in = dict(icloud=0), {}
     if args.clouds > 0.0:
-        from tests.helpers import cloud_arrays
-        cld_flags = wa.synth_clouds.add_clouds(st, seed=20260007 + 1000 * rank, cloudy_fraction=args.clouds)
-        cld_in = {n: dev(v) for n, v in cloud_arrays(st, cld_flags).items()}
+        cld_flags = wa.synth_clouds.add_clouds(st, seed=cseed + 1000003 * rank, cloudy_fraction=args.clouds)
+        cld_in = {n: dev(st.a3[n]) for n in CLD3}
+        cld_in.update({n: dev(st.a2[n]) for n in CLD2})
+
+    empty = ncol == 0
 
     def sw_call():
-        eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **sw_in, **cld_in, **sw_out)
+        if not empty:
+            eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **sw_in, **cld_in, **sw_out)
 
     def lw_call():
-        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **lw_in, **cld_in, **lw_out)
+        if not empty:
+            engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, **cld_flags, **d, **lw_in, **cld_in, **lw_out)
 
     def gather_sums():
         # the only exchange on the path: per-tile flux / forcing sums for the domain means
-        wa.tiles.tile_sums_device(sw_out, sw12, d, sums[:16])          # native deterministic reduction
+        wa.tiles.tile_sums_device(sw_out, SW12, d, sums[:16])          # native deterministic reduction
         if do_lw:
-            wa.tiles.tile_sums_device(lw_out, lw12, d, sums[16:])
+            wa.tiles.tile_sums_device(lw_out, LW12, d, sums[16:])
         wa.tiles.allreduce_sums(sums)
 
-    def opt_call():
-        wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **opt_out)
+    def opt_call(outs=None):
+        if not empty:
+            wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **(outs or opt_out))
 
     def step(ev=None):
         if ev:
@@ -289,72 +448,68 @@ def main():
     lw_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events])) if do_lw else 0.0
     opt_ms = float(np.mean([e[3].elapsed_time(e[0]) for e in events])) if do_opt else 0.0
     opt_part_ms = {}
-    if do_opt:
+    if do_opt and not empty:
         # the stage is two kernels (shortwave wavelengths, longwave band pairs): time each one on its own, outside
         # the timed region, by asking for one output group only
         for part, outs in (("sw", {n: t for n, t in opt_out.items() if not n.startswith("tauaerlw")}),
                            ("lw", {n: t for n, t in opt_out.items() if n.startswith("tauaerlw")})):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **outs)
+            opt_call(outs)
             e0.record()
-            for _ in range(3):
-                wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, **opt_in, **outs)
+            for _ in range(2):
+                opt_call(outs)
             e1.record()
             torch.cuda.synchronize()
-            opt_part_ms[part] = e0.elapsed_time(e1) / 3
+            opt_part_ms[part] = e0.elapsed_time(e1) / 2
 
     if rank == 0:
-        value = world * ncol * args.steps / elapsed
-        bpc, bpc_sw, bpc_lw = algorithmic_bytes_per_column(args.nk, args.mode)
-        # dominant kernel by measured duration: the SW column kernel or one of the two optics kernels (the two
-        # LW kernels are shorter than the SW kernel; the events bracket them together)
-        obpc = optics_bytes_per_column(args.nk, args.nbin) if do_opt else 0
+        value = ncol_job * args.steps / elapsed
+        bpc, bpc_sw, bpc_lw = algorithmic_bytes_per_column(nk, mode)
+        obpc = optics_bytes_per_column(nk, nbin) if do_opt else 0
+        # dominant kernel by measured duration: the SW column kernel or one of the two optics kernels (the two LW
+        # kernels are each shorter than the SW kernel; the events bracket them together)
         cand = [("sw_column_kernel", sw_ms, bpc_sw)]
         if do_opt:
-            cand.append(("optics_kernel", opt_part_ms["sw"], optics_bytes_per_column(args.nk, args.nbin, part="sw")))
-            cand.append(("optics_lw_kernel", opt_part_ms["lw"], optics_bytes_per_column(args.nk, args.nbin, part="lw")))
+            cand.append(("optics_kernel", opt_part_ms["sw"], optics_bytes_per_column(nk, nbin, part="sw")))
+            cand.append(("optics_lw_kernel", opt_part_ms["lw"], optics_bytes_per_column(nk, nbin, part="lw")))
         dom_name, dom_ms, dom_bpc = max(cand, key=lambda c: c[1])
         achieved = ncol * dom_bpc / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        valu = {}
+        traffic, valu = None, {}
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                traffic = tj.get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
                 kd = tj.get("kernels", {}).get(dom_name, {})
-                if kd.get("valu_issue_frac") is not None:   # what actually binds this kernel
+                if kd.get("hbm_bytes_per_launch") is not None and kd.get("columns_per_dispatch"):
+                    # PMC bytes per dispatch of the profiled run scaled to the columns of one step here (same kernel)
+                    traffic = kd["hbm_bytes_per_launch"] * ncol / kd["columns_per_dispatch"]
+                if kd.get("valu_issue_frac") is not None and kd.get("columns_per_dispatch"):   # what binds this kernel
                     valu = {"fp64_valu_issue_frac": kd["valu_issue_frac"],
-                            "valu_wave_instructions": kd["valu_wave_instructions"],
+                            "valu_wave_instructions_per_column": kd["valu_wave_instructions"] / kd["columns_per_dispatch"],
                             "source": tj.get("source")}
-                if traffic is None and dom_name == "sw_column_kernel":
-                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        what = "SW+LW" if do_lw else "RRTMG-SW"
+        tag = f" (BASELINE configs[{args.config}])" if is_config else ""
+        cloudtxt = f"McICA clouds in {100 * args.clouds:.0f} % of the columns" if args.clouds > 0 else "cloud-free"
         if do_opt:
-            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic columns per GPU, MOSAIC {args.nbin}-bin optical "
-                        "averaging + SW+LW aerosol+clean double-call, fp64, "
-                        + (f"McICA clouds in {100 * args.clouds:.0f} % of the columns" if args.clouds > 0 else "cloud-free")
-                        + (" (BASELINE configs[2])" if (args.ni, args.nj, args.nk, args.nbin) == (200, 200, 40, 4) else
-                           " (the domain and optics of BASELINE configs[3] on one GPU)"
-                           if (args.ni, args.nj, args.nk, args.nbin) == (500, 500, 50, 8) else ""))
+            workload = (f"{ni}x{nj}x{nk} synthetic domain, MOSAIC {nbin}-bin optical averaging + SW+LW aerosol+clean "
+                        f"double-call, {'fp64' if prec == 'f64' else 'fp64 radiation, packed-fp32 Mie'}, {cloudtxt}{tag}")
         elif do_lw:
-            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, SW+LW aerosol+clean "
-                        "double-call, fp64, cloud-free; aerosol optics supplied in the WRF-Chem compact form "
-                        "(BASELINE configs[2] without the optical-averaging stage)")
+            workload = (f"{ni}x{nj}x{nk} synthetic domain, SW+LW aerosol+clean double-call, fp64, {cloudtxt}; aerosol "
+                        f"optics supplied in the WRF-Chem compact form (no optical-averaging stage){tag}")
         else:
-            workload = (f"{args.ni}x{args.nj}x{args.nk} synthetic column batch per GPU, RRTMG-SW aerosol+clean "
-                        "double-call only, fp64 (BASELINE configs[1])")
+            workload = f"{ni}x{nj}x{nk} synthetic domain, RRTMG-SW aerosol+clean double-call only, fp64, {cloudtxt}{tag}"
         line = {
             "metric": "columns/sec, aerosol+clean RRTMG SW+LW double-call; flux RMSE vs reference",
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.optics_precision == "f64" or not do_opt else "f64 (optical averaging f32)",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f64" if prec == "f64" or not do_opt else "f64 (optical averaging f32)",
             "data": "synthetic",
-            "config": {"workload": workload,
-                       "columns_per_gpu": ncol, "layers": args.nk, "night_fraction": args.night,
-                       "parallelism": f"(i,j) slabs over {world} GPU(s), RCCL all-reduce of 32 flux sums"},
+            "config": {"workload": workload, "columns": ncol_job, "columns_rank0": ncol, "layers": nk,
+                       "night_fraction": args.night,
+                       "parallelism": (f"one domain in {world} j-slab(s), one per GPU" if strong else
+                                       f"{world} domains, one per GPU") + "; RCCL all-reduce of 32 flux sums"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": dom_name, "kernel_ms": dom_ms,
@@ -365,25 +520,58 @@ def main():
                          "optics_lw_kernel_ms": opt_part_ms.get("lw", 0.0), "optics_algorithmic_bytes_per_column": obpc,
                          "step_algorithmic_GBs": ncol * (bpc + obpc) / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
                          "valu": valu,
-                         "note": "fp64-VALU-bound path (SURVEY 8d); see DESIGN.md for the instruction-issue ceiling"},
+                         "note": "fp64-VALU-bound path (SURVEY 8d): see roofline.fp64 and DESIGN.md 4.4"},
         }
+        if world == 1 and not args.no_cpu:
+            try:
+                fl = algorithmic_flops(wa, tab, tabl, st, ms, mode)
+                if fl:
+                    tf64 = value * fl["flops_per_column"] / 1e12
+                    line["roofline"]["fp64"] = dict(fl, achieved_TFLOPs=tf64, peak_TFLOPs=FP64_PEAK_TFLOPS,
+                                                    frac=tf64 / FP64_PEAK_TFLOPS)
+            except Exception as e:
+                line["roofline"]["fp64"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu and args.clouds <= 0.0:
             try:
-                if do_opt:   # the CPU leg runs the radiation on the optics the device produced
-                    for n, t in list(sw_in.items()) + list(lw_in.items()):
-                        if n.startswith(("tauaer", "waer", "gaer")):
-                            st.a3[n] = t.cpu().numpy()
-                cb = cpu_baseline(tab, tabl, st, min(args.cpu_sample, ncol), args.mode)
-                if do_opt and cb.get("seconds_per_column"):
-                    spc_opt, n_opt = cpu_optics_seconds_per_column(wa, st, ms, min(args.cpu_optics_sample, ncol))
-                    cb["value"] = 1.0 / (cb["seconds_per_column"] + spc_opt)
-                    cb["sample"] += (f"; optical averaging: {n_opt} columns through the C port of the engine's own "
-                                     f"specification (no reference arithmetic exists), {spc_opt * n_opt:.2f} s, 1 thread")
-                line["cpu_baseline"] = cb
-                line["flux_rmse"] = flux_rmse(tab, tabl, st, sw_out, lw_out, max(1, min(st.nj, 400 // st.ni)), args.mode)
+                line["cpu_baseline"] = cpu_baseline(wa, tab, tabl, st, ms, mode, args.cpu_sample,
+                                                    args.cpu_sample_per_core, args.cpu_optics_sample)
             except Exception as e:   # never let the baseline leg kill the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "reference",
                                         "sample": f"failed: {e!r}"}
+            try:
+                line["flux_rmse"] = flux_rmse(wa, tab, tabl, st, ms, sw_out, lw_out, max(1, min(st.nj, 500 // ni)), mode)
+            except Exception as e:
+                line["flux_rmse"] = {"error": repr(e)}
+        if world == 1 and args.host_path_rows > 0 and args.clouds <= 0.0:
+            # the call a WRF build makes (mem = 0: host arrays through the Fortran shim's entry points), PCIe included
+            try:
+                rows = min(args.host_path_rows, st.nj)
+                dh = dims_of(ni, st.nj, nk, dict(jte=rows))
+                hin = {n: np.ascontiguousarray(st.a2[n]) for n in SW_IN2}
+                hin.update({n: np.ascontiguousarray(st.a3[n]) for n in ST_IN3 + SW_AER})
+                hout = {"rthratensw": np.zeros((st.nj, nk + 1, ni))}
+                hout.update({n: np.zeros((st.nj, ni)) for n in SW_OUT2})
+                lin = {n: np.ascontiguousarray(st.a2[n]) for n in LW_IN2}
+                lin.update({n: hin[n] for n in ST_IN3})
+                lin.update({n: np.ascontiguousarray(st.a3[n]) for n in LW_AER})
+                lout = {"rthratenlw": np.zeros((st.nj, nk + 1, ni))}
+                lout.update({n: np.zeros((st.nj, ni)) for n in LW_OUT2})
+
+                def host_step():
+                    eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **dh, **hin, **hout)
+                    if do_lw:
+                        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **dh, **lin, **lout)
+                host_step()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    host_step()
+                hs = (time.perf_counter() - t1) / 2
+                line["host_path"] = {"columns_per_s": rows * ni / hs, "columns": rows * ni, "seconds_per_call_pair": hs,
+                                     "what": "rrtmg_hip_swrad" + (" + rrtmg_hip_lwrad" if do_lw else "") +
+                                             " with mem = 0 (host arrays, staged over PCIe per call: the call the "
+                                             "Fortran shim makes); radiation only, never `value`"}
+            except Exception as e:
+                line["host_path"] = {"error": repr(e)}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -12,6 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBNAME = "liboracle.so"    # oracle/flopcount.py swaps in the operation-counting build for a moment
 dp = C.POINTER(C.c_double)
 
 
@@ -22,9 +23,12 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.path.join(HERE, _LIBNAME)
         if not os.path.exists(path):
-            build()
+            if _LIBNAME == "liboracle.so":
+                build()
+            else:
+                subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "count")])
         _LIB = C.CDLL(path)
         _LIB.sw_oracle_load.restype = C.c_void_p
         _LIB.sw_oracle_load.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_char_p, C.c_int]

@@ -52,17 +52,20 @@ def test_swrad_matches_oracle(eng, sw_oracle, wa, ni, nj, nk, seed):
     assert (got["swdnbcln"][day] > got["swdnb"][day]).all()
 
 
-@pytest.mark.parametrize("ni,nj,nk,seed,clean", [(8, 6, 40, 11, 1), (5, 3, 50, 12, 1), (3, 2, 27, 13, 1), (4, 2, 60, 14, 0),
-                                                 (3, 2, 100, 15, 1)])
-def test_swrad_without_profiles_matches_oracle(eng, sw_oracle, wa, ni, nj, nk, seed, clean):
+@pytest.mark.parametrize("ni,nj,nk,seed,clean,aer", [(8, 6, 40, 11, 1, 1), (5, 3, 50, 12, 1, 1), (3, 2, 27, 13, 1, 1),
+                                                     (4, 2, 60, 14, 0, 1), (3, 2, 100, 15, 1, 1), (4, 2, 40, 16, 1, 0)])
+def test_swrad_without_profiles_matches_oracle(eng, sw_oracle, wa, ni, nj, nk, seed, clean, aer):
     """What the patched radiation_driver actually calls (DRV:1944-2001 passes SWUPFLX.. only if it received them, and
     first_rk_step_part1 does not pass them): no layer-flux profiles.  The clean-sky call then needs TOA and surface
     fluxes only, which the kernel composes in the upward sweep -- same tolerance as the profile path."""
     st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260100 + seed, night_fraction=0.15)
-    got = run_hip_swrad(eng, st, device=True, profiles=False, clean=clean)
-    ref = run_oracle_swrad(sw_oracle, st, profiles=False, clean=clean)
+    got = run_hip_swrad(eng, st, device=True, profiles=False, clean=clean, aer=aer)
+    ref = run_oracle_swrad(sw_oracle, st, profiles=False, clean=clean, aer=aer)
     _check(got, ref)
-    full = run_hip_swrad(eng, st, device=True, profiles=True, clean=clean)
+    if not aer:   # no aerosol: the clean-sky call is the same call (NCLX:27-32 takes the one for the other)
+        np.testing.assert_array_equal(got["swuptcln"], got["swupt"])
+        np.testing.assert_array_equal(got["swdnbcln"], got["swdnb"])
+    full = run_hip_swrad(eng, st, device=True, profiles=True, clean=clean, aer=aer)
     # the two kernel instantiations agree to rounding (not bitwise: the compiler contracts different FMAs)
     compare_sw(got, full, 1e-11, 1e-11, names=list(got))
 

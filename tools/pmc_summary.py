@@ -69,7 +69,22 @@ def main():
         fh.write("\n".join(lines) + "\n")
     if traffic:
         sw = traffic.get("sw_column_kernel", {})
-        out = {"source": f"profiles/{tag}_pmc.txt", "kernels": traffic,
+        cols = None
+        try:   # the un-profiled run of the same command: how many columns one step covered, and how many steps ran
+            bj = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+            cols = bj["config"]["columns_rank0"]
+            calls = bj["steps"] + bj["warmup"]
+            shutil.copy(os.path.join(src, "bench.json"), os.path.join(root, f"{tag}_bench.json"))
+            for k, v in traffic.items():
+                # large tiles run in several column batches per step (scratch caps): columns per dispatch follow from
+                # the dispatch count; the optics kernels are also called 3 more times each for their separate timing
+                n = cnts["rrtmg::" + k].get("FETCH_SIZE") or max(cnts["rrtmg::" + k].values())
+                per_step = n / (calls + (3 if k.startswith("optics") else 0))
+                v["dispatches_per_step"] = per_step
+                v["columns_per_dispatch"] = cols / per_step
+        except Exception:
+            pass
+        out = {"source": f"profiles/{tag}_pmc.txt", "columns_per_launch": cols, "kernels": traffic,
                "hbm_bytes_per_launch": sw.get("hbm_bytes_per_launch"),
                "fetch_size_kb": sw.get("fetch_size_kb"), "write_size_kb": sw.get("write_size_kb")}
         with open(os.path.join(root, "traffic_latest.json"), "w") as fh:

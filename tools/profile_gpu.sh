@@ -5,12 +5,15 @@
 # Kernel trace and counter passes are separate runs (counters serialise the dispatches), and every
 # --pmc pass carries only counters (no other trace domain).
 set -eo pipefail
-tag=${1:-r01}
-mode=${2:-swlw}
+tag=${1:-r02}
+shift || true
 out=gpurun_out/prof_${tag}
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd=(python3 bench.py --mode "$mode" --steps 5 --warmup 2 --no-cpu)
+# the bench workload to profile: default = bench.py's default (BASELINE configs[3]); extra arguments are passed on,
+# e.g.  bash tools/profile_gpu.sh r02_c2 --config 2
+cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 "$@")
+"${cmd[@]}" > "$out/bench.json" 2> "$out/bench.err" || echo "plain bench run failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o trace -- "${cmd[@]}" > "$out/trace.log" 2>&1
 echo "trace done"
 i=0

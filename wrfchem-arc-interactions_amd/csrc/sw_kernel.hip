@@ -1215,6 +1215,9 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
 
     double *flux = c.flux + (size_t)wave * (nlp + 1) * 2;
     const bool do_cln = a.clean > 0;
+    // the clean-sky call differs from the one with aerosol only if there is aerosol: without any, the reference's two
+    // calls are the same arithmetic on the same numbers and the CLN outputs are copies
+    const bool cln_own = do_cln && (a.aer_ra_feedback == 1 || a.tauaer3d_sw != nullptr || a.aerod != nullptr);
     if (lane < SUMS_N) wsums[lane] = 0.;   // clean_atm_diag <= 0: CLN fluxes are exactly 0 (SW:9473-9478)
     if (PROF) {
         // every call as a P stream: with aerosol; clean sky (call #2, SW:9439-9467); clear sky of a cloudy column
@@ -1232,7 +1235,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
         // columns only: S = the clear-sky fluxes of call #1.  Cloud-free columns reuse the total-sky result.
         const int nround = CLOUD && col_cloudy ? 2 : 1;
         for (int r = 0; r < nround; ++r)
-            sweep(r == 0, true, true, true, flux, r == 0 ? do_cln : true, r == 1, r == 0, r == 0 ? SUM_S : SUM_K);
+            sweep(r == 0, true, true, true, flux, r == 0 ? cln_own : true, r == 1, r == 0, r == 0 ? SUM_S : SUM_K);
     }
     if (CLOUD && bad) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
@@ -1273,6 +1276,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             } else {
                 const int o = l == 0 ? 2 : 0;
                 upc = s0[SUM_S + o] + s1[SUM_S + o]; dnc = s0[SUM_S + o + 1] + s1[SUM_S + o + 1];
+                if (do_cln && !cln_own) { upc = up; dnc = dn; }
                 if (CLOUD && col_cloudy) {
                     upk = s0[SUM_K + o] + s1[SUM_K + o]; dnk = s0[SUM_K + o + 1] + s1[SUM_K + o + 1];
                 } else {

@@ -70,14 +70,21 @@ extern "C" int rrtmg_hip_tile_sums(const void *const *fields12, int real_bytes, 
 {
     if (real_bytes != 4 && real_bytes != 8) return fail(err, "rrtmg_hip_tile_sums: real_bytes must be 4 or 8");
     if (!out16_dev) return fail(err, "rrtmg_hip_tile_sums: out16 is NULL");
-    if (its < ims || ite > ime || jts < jms || jte > jme || ite < its || jte < jts)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ite < its || jte < jts) {
+        // an empty tile (a rank without rows: tiles.slab_bounds with fewer rows than ranks) contributes zeros, as
+        // swrad / lwrad / the optical averaging treat it as a no-op -- the rank still takes part in the all-reduce
+        hipError_t e = hipMemsetAsync(out16_dev, 0, 16 * sizeof(double), s);
+        if (e != hipSuccess) return fail(err, std::string("rrtmg_hip_tile_sums: ") + hipGetErrorString(e));
+        return 0;
+    }
+    if (its < ims || ite > ime || jts < jms || jte > jme)
         return fail(err, "rrtmg_hip_tile_sums: inconsistent tile / memory dimensions");
     SumArgs a{};
     for (int i = 0; i < 12; ++i) a.f[i] = fields12[i];
     a.real4 = real_bytes == 4;
     a.ni_m = ime - ims + 1; a.i0 = its - ims; a.j0 = jts - jms; a.ni_t = ite - its + 1; a.nj_t = jte - jts + 1;
     a.out = out16_dev;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(tile_sums_kernel, dim3(12), dim3(256), 0, s, a);
     hipLaunchKernelGGL(tile_sums_finish, dim3(1), dim3(1), 0, s, out16_dev, (double)a.ni_t * a.nj_t);
     hipError_t e = hipGetLastError();

@@ -268,6 +268,22 @@ def make_wrf_state(ni, nj, nk, seed=20260002, night_fraction=0.0, aerosol=True,
     return st
 
 
+def make_wrf_rows(ni, nj, nk, j0, j1, seed=20260002, aerosol=True, p_top_hpa=50.0) -> WrfState:
+    """Rows j0 <= j < j1 (0-based) of ONE synthetic ni x nj domain: every row is generated from its own seed, so any
+    partition of the domain into j-slabs (one per rank) yields the same domain -- what a strong-scaling run needs
+    (each rank builds only its slab).  Night columns are set by the caller (bench.py) from a per-row mask."""
+    if not (0 <= j0 <= j1 <= nj):
+        raise ValueError("rows outside the domain")
+    rows = [make_wrf_state(ni, 1, nk, seed=seed + 7919 * j, aerosol=aerosol, p_top_hpa=p_top_hpa) for j in range(j0, j1)]
+    st = WrfState(ni=ni, nj=j1 - j0, nk=nk, p_top=p_top_hpa * 100.0)
+    if rows:
+        for n in rows[0].a3:
+            st.a3[n] = np.concatenate([r.a3[n] for r in rows], axis=0)
+        for n in rows[0].a2:
+            st.a2[n] = np.concatenate([r.a2[n] for r in rows], axis=0)
+    return st
+
+
 # --------------------------------------------------------------------------
 # RRTMG_LW_DATA: record schema in READ order (lw_kgb01..16, LW:13021-14387)
 # --------------------------------------------------------------------------

@@ -105,6 +105,28 @@ def make_mosaic_state(st, nbin=4, seed=20260005, empty_fraction=0.02) -> MosaicS
     return MosaicState(nbin=nbin, chem=chem, alt=alt, dz8w=st.a3["dz8w"].copy(), idx=idx, names=names)
 
 
+def make_mosaic_rows(ni, nj, nk, j0, j1, nbin=4, seed=20260005, wrf_seed=20260002, empty_fraction=0.02):
+    """MOSAIC tracers for rows j0 <= j < j1 of one synthetic domain, row by row from per-row seeds (see
+    synth.make_wrf_rows): returns (WrfState of the slab, MosaicState of the slab)."""
+    from . import synth
+    sts, mss = [], []
+    for j in range(j0, j1):
+        st = synth.make_wrf_state(ni, 1, nk, seed=wrf_seed + 7919 * j)
+        sts.append(st)
+        mss.append(make_mosaic_state(st, nbin=nbin, seed=seed + 7919 * j, empty_fraction=empty_fraction))
+    slab = synth.WrfState(ni=ni, nj=j1 - j0, nk=nk, p_top=sts[0].p_top if sts else 5000.0)
+    if not sts:
+        return slab, None
+    for n in sts[0].a3:
+        slab.a3[n] = np.concatenate([r.a3[n] for r in sts], axis=0)
+    for n in sts[0].a2:
+        slab.a2[n] = np.concatenate([r.a2[n] for r in sts], axis=0)
+    ms = MosaicState(nbin=nbin, chem=np.concatenate([m.chem for m in mss], axis=1),
+                     alt=np.concatenate([m.alt for m in mss], axis=0),
+                     dz8w=np.concatenate([m.dz8w for m in mss], axis=0), idx=mss[0].idx, names=mss[0].names)
+    return slab, ms
+
+
 @dataclass
 class ModalState:
     chem: np.ndarray          # (num_chem, nj, kme, ni)

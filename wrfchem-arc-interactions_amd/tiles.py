@@ -30,8 +30,10 @@ def slab_bounds(jts: int, jte: int, world: int, rank: int, weights=None):
     get one more row).  With `weights` (one non-negative number per j row, e.g.
     the daylit-column count: night columns cost nothing in the shortwave) the
     cut points are placed where the running weight crosses k/world of the total.
-    Slabs are disjoint, ordered, cover [jts, jte]; a rank may get an empty slab
-    (js > je) only when there are fewer rows than ranks."""
+    Slabs are disjoint, ordered, cover [jts, jte].  With at least as many rows as
+    ranks every rank gets at least one row (a heavy row cannot collapse the cuts
+    around it); with fewer rows than ranks the surplus ranks get an empty slab
+    (js > je), which every entry point of the engine treats as a no-op."""
     n = jte - jts + 1
     if world <= 0 or not (0 <= rank < world):
         raise ValueError("bad world/rank")
@@ -51,8 +53,14 @@ def slab_bounds(jts: int, jte: int, world: int, rank: int, weights=None):
     for k in range(1, world):
         cuts.append(int(np.searchsorted(cum, total * k / world, side="left")))
     cuts.append(n)
-    for k in range(1, world + 1):
-        cuts[k] = max(cuts[k], cuts[k - 1])
+    if n >= world:
+        for k in range(1, world):          # at least one row per rank: push collapsed cuts apart ...
+            cuts[k] = max(cuts[k], cuts[k - 1] + 1)
+        for k in range(world - 1, 0, -1):  # ... and keep room for the ranks behind
+            cuts[k] = min(cuts[k], cuts[k + 1] - 1)
+    else:
+        for k in range(1, world + 1):
+            cuts[k] = max(cuts[k], cuts[k - 1])
     return jts + cuts[rank], jts + cuts[rank + 1] - 1
 
 
