@@ -24,8 +24,12 @@
  *      flux profiles (ims:ime, kms:kme+2, jms:jme)      (SW:10099)
  *  - real_bytes selects the width of every REAL array (8 for a -r8 build,
  *    4 for stock WRF); all arithmetic is fp64 on the device either way.
- *  - mem = 0: pointers are host memory, the call stages them through HBM and
- *    is synchronous.  mem = 1: pointers are device (HBM) addresses, work is
+ *  - mem = 0: pointers are host memory and the call is synchronous.  Only the
+ *    tile its:ite x jts:jte of every array is read, staged (packed into the
+ *    calling thread's pinned buffer, one copy each way) and written back, so
+ *    concurrent calls on disjoint tiles of SHARED arrays do not disturb each
+ *    other, and each call has its own status word: a fatal is delivered to the
+ *    call that raised it.  mem = 1: pointers are device (HBM) addresses, work is
  *    enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
  *    returns without synchronising.
  *  - an OPTIONAL Fortran argument that is not PRESENT is passed as NULL.
@@ -191,6 +195,9 @@ int rrtmg_hip_interp_sw_radiation(const rrtmg_hip_tile2d *dims, const rrtmg_hip_
 int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, double cpdair, double p_top_pa, int kme,
                       int device, char *err);
 int rrtmg_hip_lw_nlayers(int kme, double p_top_pa);
+/* the same with the quotient evaluated in the caller's REAL (real_bytes 4: single precision, as a stock WRF build
+ * does, LW:12861); rrtmg_hip_lw_init uses data_real_bytes this way */
+int rrtmg_hip_lw_nlayers_real(int kme, double p_top_pa, int real_bytes);
 
 typedef struct rrtmg_hip_lwrad_args {
     int ims, ime, jms, jme, kms, kme;

@@ -52,7 +52,29 @@ def test_decomposition_arithmetic(wa):
     assert d["SW_DIRECT"][1] == pytest.approx(np.sqrt(base["SWUPTCLN"]["SE"] ** 2 + base["SWUPT"]["SE"] ** 2 +
                                                       alt["SWUPTCLN"]["SE"] ** 2 + alt["SWUPT"]["SE"] ** 2))
     lw_cre = lambda s: s["LWUPTC"]["avg"] - s["LWUPT"]["avg"]
+    # with the LW indirect effect as the reference DOCUMENTS it (the default reproduces the reference's code, in which
+    # it is identically zero: see test_decomposition_reproduces_the_reference)
+    d = f.decompose(base, base_na, alt, alt_na, "SE", lw_indirect_as_documented=True)
     assert d["LW_INDIRECT"][0] + d["LW_SEMIDIRECT"][0] == pytest.approx(lw_cre(base) - lw_cre(alt))
+
+
+def test_decomposition_reproduces_the_reference(wa):
+    """forcing.decompose against the numbers the reference's own RadDecomp_functions.py returned for seeded
+    statistics tables (tests/golden/raddecomp.npz, written by tools/make_golden_raddecomp.py in the build container):
+    bit for bit, for both error types, including LW_INDIRECT as coded (zero, LWUPTC_nA read for every operand)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "raddecomp.npz"))
+    f = wa.forcing
+    cols = {"avg": 0, "SE": 1, "SE_corr": 2}
+    for et in ("SE", "SE_corr"):
+        for h in range(len(g["hours"])):
+            scen = {s: {v: {c: float(g[f"in_{s}_{v}"][h, i]) for c, i in cols.items()}
+                        for v in ("SWUPT", "LWUPT", "LWUPTC", "SWUPTCLN")} for s in ("BASE", "BASE_nA", "ALT", "ALT_nA")}
+            d = f.decompose(scen["BASE"], scen["BASE_nA"], scen["ALT"], scen["ALT_nA"], et)
+            for name in ("Delta_S", "Delta_L", "SW_DIRECT", "SW_INDIRECT", "SW_SEMIDIRECT", "LW_INDIRECT", "LW_SEMIDIRECT"):
+                ref = g[f"ref_{name}_{et}"][h]
+                assert d[name][0] == ref[0] and d[name][1] == ref[1], (name, et, h, d[name], ref)
+            assert d["LW_INDIRECT"][0] == 0.0
 
 
 @pytest.mark.gpu

@@ -41,3 +41,66 @@ def test_concurrent_tiles(hip_lib, wa, sw_table_file, tmp_path):
             res = list(pool.map(work, tiles))
             _check(whole_sw, [r[0] for r in res], tiles)
             _check(whole_lw, [r[1] for r in res], tiles)
+
+
+def test_concurrent_tiles_share_the_output_arrays(hip_lib, wa, sw_table_file, tmp_path):
+    """What the OpenMP tile loop of the driver does: every thread passes the SAME patch arrays and its own tile.  A
+    call may touch its tile only (a full-array write-back would overwrite the neighbours' results with stale data),
+    and night columns / untouched fields keep what the arrays held."""
+    st = wa.synth.make_wrf_state(19, 13, 40, seed=20261010, night_fraction=0.15)
+    tiles = _uneven(st)
+    wa.engine.rrtmg_swinit(sw_table_file, device=0)
+    tabl = str(tmp_path / "RRTMG_LW_DATA")
+    wa.synth.write_lw_data(tabl, seed=20260003, real_bytes=8)
+    wa.engine_lw.rrtmg_lwinit(P_TOP, tabl, kme=st.nk + 1, device=0)
+    whole_sw = run_hip_swrad(wa.engine, st, device=False, profiles=False)
+    whole_lw = run_hip_lwrad(wa.engine_lw, st, device=False, profiles=False)
+    from helpers import AER, IN2, IN3, alloc_outputs, dims_of
+    import helpers_lw as hl
+    for _ in range(4):
+        sw_out = {n: np.ascontiguousarray(v) for n, v in alloc_outputs(st, profiles=False).items()}
+        lw_out = {n: np.ascontiguousarray(v) for n, v in hl.alloc_outputs(st, profiles=False).items()}
+        sw_in = {n: np.ascontiguousarray(st.a2[n]) for n in IN2}
+        sw_in.update({n: np.ascontiguousarray(st.a3[n]) for n in IN3 + AER})
+        lw_in = {n: np.ascontiguousarray(st.a2[n]) for n in hl.IN2}
+        lw_in.update({n: sw_in[n] for n in hl.IN3})
+        lw_in.update({n: np.ascontiguousarray(st.a3[n]) for n in hl.AER})
+
+        def work(t):
+            d = dims_of(st, t)
+            wa.engine.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **sw_in, **sw_out)
+            wa.engine_lw.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **d, **lw_in, **lw_out)
+
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            list(pool.map(work, tiles))
+        for n in sw_out:
+            np.testing.assert_array_equal(sw_out[n], whole_sw[n], err_msg=n)
+        for n in lw_out:
+            np.testing.assert_array_equal(lw_out[n], whole_lw[n], err_msg=n)
+
+
+def test_fatal_goes_to_the_thread_that_raised_it(hip_lib, wa, sw_table_file):
+    """Four concurrent host-pointer calls, one of them on a tile with a negative column aerosol optical depth: exactly
+    that call returns the reference's fatal (SW:11031-11033), the other three succeed -- each call has its own status
+    word."""
+    st = wa.synth.make_wrf_state(16, 12, 40, seed=20261020)
+    tiles = _uneven(st)
+    wa.engine.rrtmg_swinit(sw_table_file, device=0)
+    bad = tiles[2]
+    st.a3["tauaer400"][bad["jts"] - 1 + 1, :, bad["its"] - 1 + 1] = -0.5
+    ok = run_hip_swrad(wa.engine, st, tile=tiles[0], device=False)
+
+    def work(t):
+        try:
+            run_hip_swrad(wa.engine, st, tile=t, device=False)
+            return None
+        except wa.engine.WrfFatal as e:
+            return str(e)
+
+    for _ in range(5):
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            res = list(pool.map(work, tiles))
+        assert [r is not None for r in res] == [False, False, True, False], res
+        assert "Negative total optical depth" in res[2]
+        i_bad, j_bad = bad["its"] + 1, bad["jts"] + 1
+        assert f"{i_bad:5d}{j_bad:5d}" in res[2]

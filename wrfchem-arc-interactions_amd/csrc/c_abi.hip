@@ -13,6 +13,7 @@
 #include "rrtmg_common.h"
 #include "rrtmg_state.h"
 #include "sw_kernel.h"
+#include "tile_staging.h"
 
 namespace rrtmg {
 
@@ -41,35 +42,6 @@ int fail(char *err, const std::string &msg)
         if (e_ != hipSuccess)                                                               \
             return fail(err, std::string("rrtmg_hip: ") + #expr + ": " + hipGetErrorString(e_)); \
     } while (0)
-
-// per-call staging of a mem=0 (host pointer) tile
-struct Staging {
-    std::vector<void *> bufs;
-    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
-    hipError_t in(const void *host, size_t bytes, hipStream_t s, const void **dev)
-    {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
-        if (e != hipSuccess) return e;
-        bufs.push_back(d);
-        *dev = d;
-        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
-    }
-    hipError_t out(void *host, size_t bytes, hipStream_t s, void **dev, bool preload)
-    {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
-        if (e != hipSuccess) return e;
-        bufs.push_back(d);
-        *dev = d;
-        // INOUT semantics: the routine writes only its tile / daylit columns
-        return preload ? hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
-    }
-};
 
 }  // namespace
 }  // namespace rrtmg
@@ -184,9 +156,11 @@ static const char *sw_status_text(int kind)
 
 extern "C" long long rrtmg_hip_swrad_staging_bytes(const rrtmg_hip_swrad_args *a)
 {
-    const long long ni = a->ime - a->ims + 1, nk = a->kme - a->kms + 1, nj = a->jme - a->jms + 1;
+    // what one mem = 0 call moves over PCIe: the tile of every array (tile_staging.h), inputs one way, outputs both
+    const long long ni = a->ite - a->its + 1, nk = a->kme - a->kms + 1, nj = a->jte - a->jts + 1;
+    if (ni <= 0 || nj <= 0) return 0;
     const long long n2 = ni * nj * a->real_bytes, n3 = ni * nk * nj * a->real_bytes;
-    return 3 * n2 + 6 * n3 + (a->aer_ra_feedback ? 8 * n3 : 0) + n3 + 22 * n2;
+    return 3 * n2 + 6 * n3 + (a->aer_ra_feedback ? 8 * n3 : 0) + 2 * (n3 + 22 * n2);
 }
 
 extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
@@ -226,8 +200,6 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
 
     hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
     const size_t rb = a->real_bytes;
-    const size_t n2 = (size_t)ni_m * nj_m * rb, n3 = (size_t)ni_m * nk_m * nj_m * rb,
-                 n3f = (size_t)ni_m * (nk_m + 2) * nj_m * rb;
 
     SwKernelArgs k{};
     k.ims = a->ims; k.jms = a->jms; k.kms = a->kms; k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
@@ -245,23 +217,22 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         k.cldtab = static_cast<const double *>(st.dCld);
         // KISS jump table of this layer count (permuteseed = 1, SW:10952), built once per nlay
         std::lock_guard<std::mutex> lock(st.jump_mutex);
-        void *&dj = st.dJump[nk + 1];
-        if (!dj) {
+        void *dj = st.dJump.count(nk + 1) ? st.dJump[nk + 1] : nullptr;
+        if (!dj) {   // enters the map only once its contents are on the device
             std::vector<uint32_t> h((size_t)SW_NGPT * KISS_JUMP_WORDS);
             kiss_jump_table(nk + 1, 1, SW_NGPT, h.data());
             HIPCHK(hipMalloc(&dj, h.size() * sizeof(uint32_t)));
-            HIPCHK(hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            hipError_t e = hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(dj); HIPCHK(e); }
+            st.dJump[nk + 1] = dj;
         }
         k.jump = static_cast<const uint32_t *>(dj);
     }
 
-    Staging stg;
-    int *d_status = static_cast<int *>(st.dStatus);
-    if (a->mem != 1) HIPCHK(hipMemsetAsync(d_status, 0, sizeof(int), stream));
-    k.status = d_status;
-
-    struct OutCopy { void *host; void *dev; size_t bytes; };
-    std::vector<OutCopy> outs;
+    // mem = 0: the tile of every array is packed, staged and unpacked by this thread's stager (tile_staging.h) and the
+    // kernels see arrays whose memory dimensions are the tile's; the call has its own status word
+    TileStager stg(TileGeom{ni_m, nk_m, nj_m, a->its - a->ims, a->jts - a->jms, ni_t, nj_t, rb});
+    k.status = static_cast<int *>(st.dStatus);
     if (a->mem == 1) {
         k.xcoszen = a->xcoszen; k.albedo = a->albedo; k.tsk = a->tsk;
         k.t3d = a->t3d; k.t8w = a->t8w; k.p3d = a->p3d; k.p8w = a->p8w; k.pi3d = a->pi3d; k.qv3d = a->qv3d;
@@ -291,26 +262,20 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             if (a->is_cammgmp_used) { k.iradius = a->iradius; k.lradius = a->lradius; }
         }
     } else {
-#define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
-#define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
-#define OUT(f, bytes)                                                           \
-    do {                                                                        \
-        HIPCHK(stg.out(a->f, bytes, stream, &k.f, true));                       \
-        if (a->f) outs.push_back({a->f, k.f, bytes});                           \
-    } while (0)
+        k.ims = a->its; k.jms = a->jts; k.ni_m = ni_t; k.nj_m = nj_t;   // packed arrays: memory = tile (k unchanged)
+#define IN2(f) stg.in(a->f, 1, 1, &k.f)
+#define IN3(f) stg.in(a->f, nk_m, 1, &k.f)
+#define OUT2(f) stg.out(a->f, 1, 1, &k.f)
         IN2(xcoszen); IN2(albedo); IN2(tsk);
         IN3(t3d); IN3(t8w); IN3(p3d); IN3(p8w); IN3(pi3d); IN3(qv3d); IN3(o33d);
         if (a->aer_ra_feedback == 1) {
             IN3(tauaer300); IN3(tauaer400); IN3(tauaer600); IN3(tauaer999);
             IN3(gaer400); IN3(gaer600); IN3(waer400); IN3(waer600);
         }
-        {
-            const size_t n4 = n3 * SW_NBND;
-            HIPCHK(stg.in(a->tauaer3d_sw, n4, stream, &k.tauaer3d_sw));
-            HIPCHK(stg.in(a->ssaaer3d_sw, n4, stream, &k.ssaaer3d_sw));
-            HIPCHK(stg.in(a->asyaer3d_sw, n4, stream, &k.asyaer3d_sw));
-            HIPCHK(stg.in(a->aerod, n3 * 6, stream, &k.aerod));
-        }
+        stg.in(a->tauaer3d_sw, nk_m, SW_NBND, &k.tauaer3d_sw);
+        stg.in(a->ssaaer3d_sw, nk_m, SW_NBND, &k.ssaaer3d_sw);
+        stg.in(a->asyaer3d_sw, nk_m, SW_NBND, &k.asyaer3d_sw);
+        stg.in(a->aerod, nk_m, 6, &k.aerod);
         if (a->alswvisdir) {
             IN2(alswvisdir); IN2(alswvisdif); IN2(alswnirdir); IN2(alswnirdif);
             if (a->icloud == 0) IN2(xland);
@@ -324,16 +289,19 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             IN2(xland); IN2(xice); IN2(snow);
             if (a->is_cammgmp_used) { IN3(iradius); IN3(lradius); }
         }
-        OUT(rthratensw, n3); OUT(coszr, n2); OUT(gsw, n2); OUT(swcf, n2);
-        OUT(swupt, n2); OUT(swuptc, n2); OUT(swuptcln, n2); OUT(swdnt, n2); OUT(swdntc, n2); OUT(swdntcln, n2);
-        OUT(swupb, n2); OUT(swupbc, n2); OUT(swupbcln, n2); OUT(swdnb, n2); OUT(swdnbc, n2); OUT(swdnbcln, n2);
-        OUT(swvisdir, n2); OUT(swvisdif, n2); OUT(swnirdir, n2); OUT(swnirdif, n2);
-        OUT(swddir, n2); OUT(swddni, n2); OUT(swddif, n2);
-        OUT(swupflx, n3f); OUT(swupflxc, n3f); OUT(swupflxcln, n3f);
-        OUT(swdnflx, n3f); OUT(swdnflxc, n3f); OUT(swdnflxcln, n3f);
+        stg.out(a->rthratensw, nk_m, 1, &k.rthratensw); OUT2(coszr); OUT2(gsw); OUT2(swcf);
+        OUT2(swupt); OUT2(swuptc); OUT2(swuptcln); OUT2(swdnt); OUT2(swdntc); OUT2(swdntcln);
+        OUT2(swupb); OUT2(swupbc); OUT2(swupbcln); OUT2(swdnb); OUT2(swdnbc); OUT2(swdnbcln);
+        OUT2(swvisdir); OUT2(swvisdif); OUT2(swnirdir); OUT2(swnirdif);
+        OUT2(swddir); OUT2(swddni); OUT2(swddif);
+        stg.out(a->swupflx, nk_m + 2, 1, &k.swupflx); stg.out(a->swupflxc, nk_m + 2, 1, &k.swupflxc);
+        stg.out(a->swupflxcln, nk_m + 2, 1, &k.swupflxcln); stg.out(a->swdnflx, nk_m + 2, 1, &k.swdnflx);
+        stg.out(a->swdnflxc, nk_m + 2, 1, &k.swdnflxc); stg.out(a->swdnflxcln, nk_m + 2, 1, &k.swdnflxcln);
+        HIPCHK(stg.upload(stream));
+        k.status = stg.status_word();
+#undef OUT2
 #undef IN2
 #undef IN3
-#undef OUT
     }
     if (!(k.xcoszen && k.albedo && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
         return fail(err, "rrtmg_hip_swrad: a required input array is NULL");
@@ -386,10 +354,8 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     }
 
     if (a->mem != 1) {
-        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
         int status = 0;
-        HIPCHK(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(stg.download(stream, &status));
         if (status != 0) {
             const int col = (status & 0x0fffffff) - 1;
             char m[RRTMG_HIP_ERRLEN];
@@ -431,6 +397,7 @@ extern "C" int rrtmg_hip_finalize(void)
     for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     st.scratch.clear();
     st.dK = st.dExp = st.dG = st.dStatus = st.dCld = nullptr;
+    stage_pools_release();
     st.ready = false;
     return 0;
 }

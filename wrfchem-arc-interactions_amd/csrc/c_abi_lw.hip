@@ -11,6 +11,7 @@
 #include "../../include/rrtmg_hip.h"
 #include "lw_common.h"
 #include "lw_kernel.h"
+#include "tile_staging.h"
 #include "sw_kernel.h"   // kiss_jump_table
 #include "lw_ref_tables.h"
 #include "lw_state.h"
@@ -43,33 +44,6 @@ int failw(char *err, const std::string &msg)
             return failw(err, std::string("rrtmg_hip: ") + #expr + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-struct Staging {
-    std::vector<void *> bufs;
-    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
-    hipError_t in(const void *host, size_t bytes, hipStream_t s, const void **dev)
-    {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
-        if (e != hipSuccess) return e;
-        bufs.push_back(d);
-        *dev = d;
-        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
-    }
-    hipError_t out(void *host, size_t bytes, hipStream_t s, void **dev)
-    {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
-        if (e != hipSuccess) return e;
-        bufs.push_back(d);
-        *dev = d;
-        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);   // INOUT: only the tile is rewritten
-    }
-};
-
 template <class T>
 hipError_t upload(void **dptr, const std::vector<T> &v)
 {
@@ -84,10 +58,21 @@ hipError_t upload(void **dptr, const std::vector<T> &v)
 
 using namespace rrtmg;
 
-extern "C" int rrtmg_hip_lw_nlayers(int kme, double p_top_pa)
+// NLAYERS = kme + nint(p_top*0.01/deltap) - 1 with deltap = 4 mb, LW:12861.  The reference evaluates the quotient in
+// default REAL: single precision in a stock build, where a quotient next to .5 can round to the other side than in
+// double precision -- so the width of the caller's REAL decides the arithmetic (nint rounds halves away from zero).
+static int lw_nlayers_of(int kme, double p_top_pa, int real_bytes)
 {
-    // NLAYERS = kme + nint(p_top*0.01/deltap) - 1 with deltap = 4 mb, LW:12861
+    if (real_bytes == 4) {
+        const float q = (float)p_top_pa * 0.01f / 4.0f;
+        return kme + (int)std::lroundf(q) - 1;
+    }
     return kme + (int)std::lround(p_top_pa * 0.01 / 4.) - 1;
+}
+extern "C" int rrtmg_hip_lw_nlayers(int kme, double p_top_pa) { return lw_nlayers_of(kme, p_top_pa, 8); }
+extern "C" int rrtmg_hip_lw_nlayers_real(int kme, double p_top_pa, int real_bytes)
+{
+    return lw_nlayers_of(kme, p_top_pa, real_bytes);
 }
 
 extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, double cpdair, double p_top_pa, int kme,
@@ -128,7 +113,7 @@ extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, dou
     st.dev.oneminus = host.oneminus;
     st.host = std::move(host);
     st.device = device;
-    st.nlayers = rrtmg_hip_lw_nlayers(kme, p_top_pa);
+    st.nlayers = lw_nlayers_of(kme, p_top_pa, data_real_bytes);
     st.ready = true;
     return 0;
 }
@@ -215,8 +200,6 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     HIPCHK(hipSetDevice(st.device));
     hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
     const size_t rb = a->real_bytes;
-    const size_t n2 = (size_t)ni_m * nj_m * rb, n3 = (size_t)ni_m * nk_m * nj_m * rb,
-                 n3f = (size_t)ni_m * (nk_m + 2) * nj_m * rb;
 
     LwKernelArgs k{};
     k.ims = a->ims; k.jms = a->jms; k.kms = a->kms; k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
@@ -236,19 +219,19 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         k.cldtab = static_cast<const double *>(st.dCld);
         // KISS jump table: NLAYERS draws per sub-column, permuteseed = 150 (LW:12555)
         std::lock_guard<std::mutex> lock(st.scratch_mutex);
-        void *&dj = st.dJump[nl];
-        if (!dj) {
+        void *dj = st.dJump.count(nl) ? st.dJump[nl] : nullptr;
+        if (!dj) {   // enters the map only once its contents are on the device
             std::vector<uint32_t> h((size_t)LW_NGPT * KISS_JUMP_WORDS);
             kiss_jump_table(nl, 150, LW_NGPT, h.data());
             HIPCHK(hipMalloc(&dj, h.size() * sizeof(uint32_t)));
-            HIPCHK(hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            hipError_t e = hipMemcpy(dj, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(dj); HIPCHK(e); }
+            st.dJump[nl] = dj;
         }
         k.jump = static_cast<const uint32_t *>(dj);
     }
-    Staging stg;
-    if (a->mem != 1) HIPCHK(hipMemsetAsync(st.dStatus, 0, sizeof(int), stream));
-    struct OutCopy { void *host; void *dev; size_t bytes; };
-    std::vector<OutCopy> outs;
+    // mem = 0: tile-only staging through this thread's buffers, own status word (tile_staging.h)
+    TileStager stg(TileGeom{ni_m, nk_m, nj_m, a->its - a->ims, a->jts - a->jms, ni_t, nj_t, rb});
     if (a->mem == 1) {
         k.emiss = a->emiss; k.tsk = a->tsk;
         k.t3d = a->t3d; k.t8w = a->t8w; k.p3d = a->p3d; k.p8w = a->p8w; k.pi3d = a->pi3d; k.qv3d = a->qv3d; k.o33d = a->o33d;
@@ -268,17 +251,15 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             if (a->is_cammgmp_used) { k.iradius = a->iradius; k.lradius = a->lradius; }
         }
     } else {
-#define IN2(f) HIPCHK(stg.in(a->f, n2, stream, &k.f))
-#define IN3(f) HIPCHK(stg.in(a->f, n3, stream, &k.f))
-#define OUT(f, bytes)                                             \
-    do {                                                          \
-        HIPCHK(stg.out(a->f, bytes, stream, &k.f));               \
-        if (a->f) outs.push_back({a->f, k.f, bytes});             \
-    } while (0)
+        k.ims = a->its; k.jms = a->jts; k.ni_m = ni_t; k.nj_m = nj_t;   // packed arrays: memory = tile (k unchanged)
+#define IN2(f) stg.in(a->f, 1, 1, &k.f)
+#define IN3(f) stg.in(a->f, nk_m, 1, &k.f)
+#define OUT2(f) stg.out(a->f, 1, 1, &k.f)
+#define OUTF(f) stg.out(a->f, nk_m + 2, 1, &k.f)
         IN2(emiss); IN2(tsk);
         IN3(t3d); IN3(t8w); IN3(p3d); IN3(p8w); IN3(pi3d); IN3(qv3d); IN3(o33d);
         if (a->aer_ra_feedback == 1)
-            for (int b = 0; b < 16; ++b) HIPCHK(stg.in(a->tauaerlw[b], n3, stream, &k.tauaerlw[b]));
+            for (int b = 0; b < 16; ++b) stg.in(a->tauaerlw[b], nk_m, 1, &k.tauaerlw[b]);
         if (a->icloud != 0) {
             IN3(cldfra3d); IN3(qc3d); IN3(qr3d); IN3(qi3d); IN3(qs3d);
             if (a->has_reqc) IN3(re_cloud);
@@ -288,14 +269,16 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             IN2(xland); IN2(xice); IN2(snow);
             if (a->is_cammgmp_used) { IN3(iradius); IN3(lradius); }
         }
-        OUT(rthratenlw, n3); OUT(glw, n2); OUT(olr, n2); OUT(lwcf, n2);
-        OUT(lwupt, n2); OUT(lwuptc, n2); OUT(lwuptcln, n2); OUT(lwdnt, n2); OUT(lwdntc, n2); OUT(lwdntcln, n2);
-        OUT(lwupb, n2); OUT(lwupbc, n2); OUT(lwupbcln, n2); OUT(lwdnb, n2); OUT(lwdnbc, n2); OUT(lwdnbcln, n2);
-        OUT(lwupflx, n3f); OUT(lwupflxc, n3f); OUT(lwupflxcln, n3f);
-        OUT(lwdnflx, n3f); OUT(lwdnflxc, n3f); OUT(lwdnflxcln, n3f);
+        stg.out(a->rthratenlw, nk_m, 1, &k.rthratenlw); OUT2(glw); OUT2(olr); OUT2(lwcf);
+        OUT2(lwupt); OUT2(lwuptc); OUT2(lwuptcln); OUT2(lwdnt); OUT2(lwdntc); OUT2(lwdntcln);
+        OUT2(lwupb); OUT2(lwupbc); OUT2(lwupbcln); OUT2(lwdnb); OUT2(lwdnbc); OUT2(lwdnbcln);
+        OUTF(lwupflx); OUTF(lwupflxc); OUTF(lwupflxcln); OUTF(lwdnflx); OUTF(lwdnflxc); OUTF(lwdnflxcln);
+        HIPCHK(stg.upload(stream));
+        k.status = stg.status_word();
+#undef OUT2
+#undef OUTF
 #undef IN2
 #undef IN3
-#undef OUT
     }
     if (!(k.emiss && k.tsk && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
         return failw(err, "rrtmg_hip_lwrad: a required input array is NULL");
@@ -335,10 +318,8 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     }
 
     if (a->mem != 1) {
-        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, stream));
         int status = 0;
-        HIPCHK(hipMemcpyAsync(&status, st.dStatus, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(stg.download(stream, &status));
         if (status != 0) {
             const int col = (status & 0x0fffffff) - 1;
             char m[RRTMG_HIP_ERRLEN];

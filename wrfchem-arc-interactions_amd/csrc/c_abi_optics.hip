@@ -9,6 +9,7 @@
 #include "../../include/rrtmg_hip.h"
 #include "optics_common.h"
 #include "optics_kernel.h"
+#include "tile_staging.h"
 
 namespace rrtmg {
 namespace {
@@ -58,22 +59,6 @@ int fill_tables(OpticsTables &t, int nbin, double dlo_um, double dhi_um, const d
         }
     return 0;
 }
-
-struct Staging {
-    std::vector<void *> bufs;
-    ~Staging() { for (void *p : bufs) (void)hipFree(p); }
-    hipError_t put(const void *host, size_t bytes, hipStream_t s, void **dev)
-    {
-        *dev = nullptr;
-        if (!host) return hipSuccess;
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, bytes);
-        if (e != hipSuccess) return e;
-        bufs.push_back(d);
-        *dev = d;
-        return hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, s);
-    }
-};
 
 }  // namespace
 
@@ -160,10 +145,9 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
     k.real4 = a->real_bytes == 4;
     k.mix = (a->aer_op_opt == 2 || a->aer_op_opt == 4) ? 1 : 0;
     k.nbin = nbin;
-    const size_t n3 = (size_t)ni_m * nk_m * nj_m * a->real_bytes;
-    Staging stg;
-    struct OutCopy { void *host; void *dev; };
-    std::vector<OutCopy> outs;
+    // mem = 0: tile-only staging through this thread's buffers (tile_staging.h); of the tracer array only the span of
+    // species the sections use travels (MOSAIC's aerosol tracers are contiguous in the Registry)
+    TileStager stg(TileGeom{ni_m, nk_m, nj_m, a->its - a->ims, a->jts - a->jms, ni_t, nj_t, (size_t)a->real_bytes});
     if (a->mem == 1) {
         k.chem = a->chem; k.alt = a->alt; k.dz8w = a->dz8w;
         for (int w = 0; w < OPT_NSW; ++w) {
@@ -172,27 +156,33 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
         }
         for (int b = 0; b < OPT_NLW; ++b) { k.tauaerlw[b] = a->tauaerlw[b]; k.extaerlw[b] = a->extaerlw[b]; }
     } else {
-        void *d = nullptr;
-        HIPCHK(stg.put(a->chem, n3 * (size_t)a->num_chem, stream, &d)); k.chem = d;
-        HIPCHK(stg.put(a->alt, n3, stream, &d)); k.alt = d;
-        HIPCHK(stg.put(a->dz8w, n3, stream, &d)); k.dz8w = d;
-        auto out = [&](void *host, void **dev) -> hipError_t {
-            hipError_t e = stg.put(host, n3, stream, dev);   // upload first: only the tile is rewritten
-            if (e == hipSuccess && host) outs.push_back({host, *dev});
-            return e;
-        };
+        int lo = a->num_chem, hi = -1;
+        for (int b = 0; b < nbin; ++b)
+            for (int sp = 0; sp < OPT_NSLOT; ++sp)
+                if (k.idx[b][sp] >= 0) { lo = k.idx[b][sp] < lo ? k.idx[b][sp] : lo; hi = k.idx[b][sp] > hi ? k.idx[b][sp] : hi; }
+        if (hi < lo) { lo = 0; hi = 0; }
+        for (int b = 0; b < nbin; ++b)
+            for (int sp = 0; sp < OPT_NSLOT; ++sp)
+                if (k.idx[b][sp] >= 0) k.idx[b][sp] -= lo;
+        k.ni_m = ni_t; k.nj_m = nj_t; k.i0 = 0; k.j0 = 0;   // packed arrays: memory = tile (k unchanged)
+        const size_t sspec = (size_t)ni_m * nk_m * nj_m * a->real_bytes;
+        stg.in(static_cast<const char *>(a->chem) + (size_t)lo * sspec, nk_m, hi - lo + 1, &k.chem);
+        stg.in(a->alt, nk_m, 1, &k.alt);
+        stg.in(a->dz8w, nk_m, 1, &k.dz8w);
         for (int w = 0; w < OPT_NSW; ++w) {
-            HIPCHK(out(a->tauaer[w], &k.tauaer[w])); HIPCHK(out(a->waer[w], &k.waer[w])); HIPCHK(out(a->gaer[w], &k.gaer[w]));
-            HIPCHK(out(a->extaer[w], &k.extaer[w])); HIPCHK(out(a->bscoef[w], &k.bscoef[w]));
+            stg.out(a->tauaer[w], nk_m, 1, &k.tauaer[w]); stg.out(a->waer[w], nk_m, 1, &k.waer[w]);
+            stg.out(a->gaer[w], nk_m, 1, &k.gaer[w]); stg.out(a->extaer[w], nk_m, 1, &k.extaer[w]);
+            stg.out(a->bscoef[w], nk_m, 1, &k.bscoef[w]);
         }
         for (int b = 0; b < OPT_NLW; ++b) {
-            HIPCHK(out(a->tauaerlw[b], &k.tauaerlw[b])); HIPCHK(out(a->extaerlw[b], &k.extaerlw[b]));
+            stg.out(a->tauaerlw[b], nk_m, 1, &k.tauaerlw[b]); stg.out(a->extaerlw[b], nk_m, 1, &k.extaerlw[b]);
         }
+        HIPCHK(stg.upload(stream));
     }
     HIPCHK(optics_launch(k, stream, g_opt.precision));
     if (a->mem != 1) {
-        for (auto &o : outs) HIPCHK(hipMemcpyAsync(o.host, o.dev, n3, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
+        int status = 0;
+        HIPCHK(stg.download(stream, &status));
     }
     return 0;
 }

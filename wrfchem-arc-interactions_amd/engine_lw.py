@@ -32,7 +32,7 @@ class LwradArgs(C.Structure):
                 + [(n, C.c_void_p) for n in _CAMRAD])
 
 
-EXPORTS_LW = ["rrtmg_hip_lw_init", "rrtmg_hip_lw_nlayers", "rrtmg_hip_lwrad", "rrtmg_hip_lw_status",
+EXPORTS_LW = ["rrtmg_hip_lw_init", "rrtmg_hip_lw_nlayers", "rrtmg_hip_lw_nlayers_real", "rrtmg_hip_lwrad", "rrtmg_hip_lw_status",
               "rrtmg_hip_lw_finalize", "rrtmg_hip_lw_reduce_tables", "rrtmg_hip_lw_table_info"]
 
 _ready = False

@@ -94,14 +94,21 @@ def _q(*errs):
     return float(np.sqrt(sum(e * e for e in errs)))
 
 
-def decompose(base: dict, base_na: dict, alt: dict, alt_na: dict, error_type: str = "SE") -> dict:
+def decompose(base: dict, base_na: dict, alt: dict, alt_na: dict, error_type: str = "SE",
+              lw_indirect_as_documented: bool = False) -> dict:
     """Each argument maps a field name (SWUPT, SWUPTCLN, LWUPT, LWUPTC) to its statistics dict (``domain_stats``).
-    Returns {effect: (value, error)} for SW_DIRECT, SW_INDIRECT, SW_SEMIDIRECT, LW_INDIRECT, LW_SEMIDIRECT
-    (RadDecomp_functions.py:147-266; sign conventions and error propagation as there).  LW_INDIRECT follows the
-    formula in the reference's comment (:218-221); its code reads LWUPTC_nA for both terms (:224-227), which makes
-    the reference's own LW_INDIRECT identically zero."""
+    Returns {effect: (value, error)} for Delta_S, Delta_L, SW_DIRECT, SW_INDIRECT, SW_SEMIDIRECT, LW_INDIRECT,
+    LW_SEMIDIRECT exactly as RadDecomp_functions.py:118-266 computes them (same operands, same order of operations,
+    errors in quadrature) -- pinned on the reference itself: tests/golden/raddecomp.npz, tools/make_golden_raddecomp.py.
+
+    LW_INDIRECT: the reference's code reads LWUPTC_nA where its comment says LWUPT_nA (:224-227), so its value is
+    identically zero and its error counts the two LWUPTC_nA errors twice.  The default reproduces the code; with
+    ``lw_indirect_as_documented=True`` the formula of the comment (:218-221) is used instead,
+    (LWUPTC - LWUPT)_BASE_nA - (LWUPTC - LWUPT)_ALT_nA."""
     a, e = "avg", error_type
     out = {}
+    out["Delta_S"] = (alt["SWUPT"][a] - base["SWUPT"][a], _q(alt["SWUPT"][e], base["SWUPT"][e]))
+    out["Delta_L"] = (alt["LWUPT"][a] - base["LWUPT"][a], _q(alt["LWUPT"][e], base["LWUPT"][e]))
     # SW direct = (SWUPTCLN - SWUPT)_BASE - (SWUPTCLN - SWUPT)_ALT
     out["SW_DIRECT"] = (base["SWUPTCLN"][a] - base["SWUPT"][a] - alt["SWUPTCLN"][a] + alt["SWUPT"][a],
                         _q(base["SWUPTCLN"][e], base["SWUPT"][e], alt["SWUPTCLN"][e], alt["SWUPT"][e]))
@@ -110,10 +117,11 @@ def decompose(base: dict, base_na: dict, alt: dict, alt_na: dict, error_type: st
     # SW semi-direct = SWUPTCLN_ALT - SWUPTCLN_BASE - SWUPT_ALT_nA + SWUPT_BASE_nA
     out["SW_SEMIDIRECT"] = (alt["SWUPTCLN"][a] - base["SWUPTCLN"][a] - alt_na["SWUPT"][a] + base_na["SWUPT"][a],
                             _q(alt["SWUPTCLN"][e], base["SWUPTCLN"][e], alt_na["SWUPT"][e], base_na["SWUPT"][e]))
-    # LW indirect = (LWUPTC - LWUPT)_BASE_nA - (LWUPTC - LWUPT)_ALT_nA
-    out["LW_INDIRECT"] = (base_na["LWUPTC"][a] - base_na["LWUPT"][a] - alt_na["LWUPTC"][a] + alt_na["LWUPT"][a],
-                          _q(base_na["LWUPTC"][e], base_na["LWUPT"][e], alt_na["LWUPTC"][e], alt_na["LWUPT"][e]))
-    # LW semi-direct = (LWUPTC - LWUPT)_BASE - (LWUPTC - LWUPT)_ALT - LW indirect
+    # LW indirect, as coded: every operand is LWUPTC_nA (:224-227)
+    lwup_b, lwup_a = (base_na["LWUPT"], alt_na["LWUPT"]) if lw_indirect_as_documented else (base_na["LWUPTC"], alt_na["LWUPTC"])
+    out["LW_INDIRECT"] = (base_na["LWUPTC"][a] - lwup_b[a] - alt_na["LWUPTC"][a] + lwup_a[a],
+                          _q(base_na["LWUPTC"][e], lwup_b[e], alt_na["LWUPTC"][e], lwup_a[e]))
+    # LW semi-direct = (LWUPTC - LWUPT)_BASE - (LWUPTC - LWUPT)_ALT - LW indirect (written out, :236-266)
     out["LW_SEMIDIRECT"] = (base["LWUPTC"][a] - base["LWUPT"][a] - alt["LWUPTC"][a] + alt["LWUPT"][a]
                             - base_na["LWUPTC"][a] + base_na["LWUPT"][a] + alt_na["LWUPTC"][a] - alt_na["LWUPT"][a],
                             _q(base["LWUPTC"][e], base["LWUPT"][e], alt["LWUPTC"][e], alt["LWUPT"][e],
