@@ -19,6 +19,8 @@
 // VALU): ~10^5 flop per cell against 0.6 KB of tracer data.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "optics_common.h"
 #include "optics_kernel.h"
 
@@ -32,15 +34,23 @@ __constant__ OpticsTables c_opt;
 // weights of the asymmetry sum, functions of the (wave-uniform) term number only:
 // c_gw[0][n] = (2n+1)/(n(n+1)), c_gw[1][n] = (n-1)(n+1)/n
 __constant__ double c_gw[2][OPT_NMIE + 2];
+// per wavelength slot: pi / lambda (size parameter per um of diameter) and its cube root
+__constant__ double c_pil[2][OPT_NWAVE];
 
 struct cplx { double re, im; };
 
-__device__ __forceinline__ double frcp(double b)
+// v_rcp_f64 is good to 2^-24.4 (tools/probes/rcp_probe.hip): one Newton step gives 2.2e-15 (frcp1: inside the
+// recurrences and series terms, where hundreds of them are spent per particle), two give 1.1e-16 (frcp)
+__device__ __forceinline__ double frcp1(double b)
 {
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-b, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double frcp(double b)
+{
+    double r = frcp1(b);
+    double e = __builtin_fma(-b, r, 1.0);
     return __builtin_fma(r, e, r);
 }
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
@@ -48,7 +58,7 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cplx crecip(cplx a)
 {
-    const double r = frcp(a.re * a.re + a.im * a.im);
+    const double r = frcp1(a.re * a.re + a.im * a.im);
     return {a.re * r, -a.im * r};
 }
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) { return cmul(a, crecip(b)); }
@@ -101,7 +111,7 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
     const cplx nb = {t.re * psi - A.psi1, t.im * psi}, db = csub(cmul(t, xi), xi1);
     // a_n = na/da, b_n = nb/db with one reciprocal: 1/|da|^2 = |db|^2 / (|da|^2 |db|^2)
     const double ma = da.re * da.re + da.im * da.im, mb = db.re * db.re + db.im * db.im;
-    const double r = frcp(ma * mb);
+    const double r = frcp1(ma * mb);
     const double ra = r * mb, rb = r * ma;
     const cplx an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
     const cplx bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
@@ -246,6 +256,112 @@ __device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2,
             if (n <= s1.nstop) mie_term<false>(A1, n, dd1[i], m1, s1.minv, s1.xinv);
             if (n <= s2.nstop) mie_term<false>(A2, n, dd2[i], m2, s2.minv, s2.xinv);
         }
+    }
+    const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
+    qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
+    qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
+}
+
+// ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 2, at most OPT_MB2 terms) ----
+// Most longwave evaluations are of this kind (x = pi d / lambda with d <= 10 um and lambda >= 3 um).  The whole
+// logarithmic-derivative ladder D_1..D_8 then fits the registers: the downward recurrence runs ONCE, from a start
+// order chosen from its own contraction rate -- an error e in D_n becomes e |y|^2 / (2n+1)^2 in D_(n-1), so the
+// arbitrary start value D_N = 0 has decayed below 1e-20 after a handful of steps (on 17 000 random cases with
+// |y| <= 2 the ladder equals the one started at N = 120 bit for bit; the fixed rule of the general path starts 16
+// above) -- and nothing goes through LDS.  sin x and cos x come from their Taylor series (x <= 2.1, no reduction).
+__device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
+{
+    const double z = x * x;
+    {
+        double p = 6.44695028438447359e-26;
+        p = __builtin_fma(p, z, -3.86817017063068413e-23);
+        p = __builtin_fma(p, z, 1.95729410633912626e-20);
+        p = __builtin_fma(p, z, -8.22063524662432950e-18);
+        p = __builtin_fma(p, z, 2.81145725434552060e-15);
+        p = __builtin_fma(p, z, -7.64716373181981641e-13);
+        p = __builtin_fma(p, z, 1.60590438368216133e-10);
+        p = __builtin_fma(p, z, -2.50521083854417202e-08);
+        p = __builtin_fma(p, z, 2.75573192239858925e-06);
+        p = __builtin_fma(p, z, -1.98412698412698413e-04);
+        p = __builtin_fma(p, z, 8.33333333333333322e-03);
+        p = __builtin_fma(p, z, -1.66666666666666657e-01);
+        p = __builtin_fma(p, z, 1.00000000000000000e+00);
+        sn = p * x;
+    }
+    {
+        double p = 1.61173757109611839e-24;
+        p = __builtin_fma(p, z, -8.89679139245057408e-22);
+        p = __builtin_fma(p, z, 4.11031762331216484e-19);
+        p = __builtin_fma(p, z, -1.56192069685862253e-16);
+        p = __builtin_fma(p, z, 4.77947733238738525e-14);
+        p = __builtin_fma(p, z, -1.14707455977297245e-11);
+        p = __builtin_fma(p, z, 2.08767569878681002e-09);
+        p = __builtin_fma(p, z, -2.75573192239858883e-07);
+        p = __builtin_fma(p, z, 2.48015873015873016e-05);
+        p = __builtin_fma(p, z, -1.38888888888888894e-03);
+        p = __builtin_fma(p, z, 4.16666666666666644e-02);
+        p = __builtin_fma(p, z, -5.00000000000000000e-01);
+        p = __builtin_fma(p, z, 1.00000000000000000e+00);
+        cs = p;
+    }
+}
+
+struct MieSetupS {
+    cplx yinv, minv;
+    double xinv;
+    int nstop, nstart;
+    bool small;
+};
+// cbx: cube root of x (the caller has it from the particle's diameter)
+__device__ __forceinline__ MieSetupS mie_setup_small(double x, cplx m, double cbx)
+{
+    MieSetupS s;
+    const cplx y = {x * m.re, x * m.im};
+    const double ay2 = y.re * y.re + y.im * y.im;
+    s.nstop = (int)(x + 4. * cbx + 2.);
+    s.small = ay2 <= 4.0 && s.nstop <= OPT_MB2;
+    // steps until the start error has contracted by 1e-20: each contributes at least 2 ln((2 nstop + 3) / |y|)
+    const float g = 2.f * __logf((float)(2 * s.nstop + 3) * __builtin_amdgcn_rsqf((float)ay2));
+    const int steps = (int)(46.1f * __builtin_amdgcn_rcpf(g)) + 2;
+    const int n0 = s.nstop + steps;
+    s.nstart = n0 < OPT_MB2 + 1 ? OPT_MB2 + 1 : n0;
+    s.yinv = crecip(y);
+    s.minv = crecip(m);
+    s.xinv = frcp1(x);
+    return s;
+}
+
+__device__ __forceinline__ void mie_pair_small(double x1, cplx m1, double x2, cplx m2, const MieSetupS &s1,
+                                               const MieSetupS &s2, double &qext1, double &qsca1, double &qext2,
+                                               double &qsca2)
+{
+    cplx d1 = {0., 0.}, d2 = {0., 0.};
+    const int nstart = s1.nstart > s2.nstart ? s1.nstart : s2.nstart;
+    for (int n = nstart; n > OPT_MB2 + 1; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), down to D_9
+        const double en = (double)n;
+        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+        d1 = csub(ny1, crecip(cadd(d1, ny1)));
+        d2 = csub(ny2, crecip(cadd(d2, ny2)));
+    }
+    cplx dd1[OPT_MB2], dd2[OPT_MB2];
+#pragma unroll
+    for (int i = OPT_MB2 - 1; i >= 0; --i) {       // dd[i] = D_{i+1}
+        const double en = (double)(i + 2);
+        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+        d1 = csub(ny1, crecip(cadd(d1, ny1)));
+        d2 = csub(ny2, crecip(cadd(d2, ny2)));
+        dd1[i] = d1; dd2[i] = d2;
+    }
+    MieAcc A1, A2;
+    sincos_small(x1, A1.psi1, A1.psi0);
+    sincos_small(x2, A2.psi1, A2.psi0);
+    A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
+    A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
+#pragma unroll
+    for (int i = 0; i < OPT_MB2; ++i) {
+        const int n = i + 1;
+        if (n <= s1.nstop) mie_term<false>(A1, n, dd1[i], m1, s1.minv, s1.xinv);
+        if (n <= s2.nstop) mie_term<false>(A2, n, dd2[i], m2, s2.minv, s2.xinv);
     }
     const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
     qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
@@ -481,7 +597,12 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             const cplx mb = mix_index(vol, vwet, a.mix, w2);
             double xb = pi * dwet * frcp(lam2);
             xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            {
+            // the register-only small-size path when every lane of the wave qualifies (|mx| <= 2, <= 8 terms)
+            const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for both bands
+            const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
+            if (__all(t1.small && t2.small)) {
+                mie_pair_small(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);
+            } else {
                 const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
                 if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
                     mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
@@ -812,7 +933,8 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelA
     optics_body<false>(a, s_ck);
 }
 
-__global__ void __launch_bounds__(OPT_THREADS) optics_lw_kernel(const OpticsKernelArgs a)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+optics_lw_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
     optics_body<true>(a, s_ck);
@@ -842,6 +964,13 @@ hipError_t optics_upload_tables(const OpticsTables &t)
         gw[1][n] = (en - 1.) * (en + 1.) / en;
     }
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gw), gw, sizeof gw);
+    if (e != hipSuccess) return e;
+    double pil[2][OPT_NWAVE];
+    for (int w = 0; w < OPT_NWAVE; ++w) {
+        pil[0][w] = 3.14159265358979323846 / t.wavelength_um[w];
+        pil[1][w] = std::cbrt(pil[0][w]);
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_pil), pil, sizeof pil);
     if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_opt), &t, sizeof(OpticsTables));
 }
