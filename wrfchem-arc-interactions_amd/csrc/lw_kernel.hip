@@ -281,14 +281,22 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
             }
             if (!binary) { wm1[q] = 0.; w0[q] = 1.; w1[q] = 0.; w2[q] = 0.; jsi = 0; speccomb = colA[q]; }
             const int rb = m == 0 ? c.rb0[k] : c.rb1[k];
+#ifdef LW_EXP_ROW0
+            Kp[q] = tb.K + R.off_major + (size_t)(0 * rb * nsp + jsi) * ng;
+#else
             Kp[q] = tb.K + R.off_major + (size_t)(rb * nsp + jsi) * ng;
+#endif
             fTa[q] = m == 0 ? c.fac00[k] : c.fac01[k];
             fTb[q] = m == 0 ? c.fac10[k] : c.fac11[k];
             sc[q][m] = speccomb;
         }
         double v[NLY][4];
 #pragma unroll
+#ifdef LW_EXP_HALF
+        for (int q = 0; q < NLY; ++q) { v[q][0] = Kp[q][0]; v[q][1] = v[q][0]; v[q][2] = Kp[q][ts]; v[q][3] = v[q][2]; }
+#else
         for (int q = 0; q < NLY; ++q) { v[q][0] = Kp[q][0]; v[q][1] = Kp[q][ng]; v[q][2] = Kp[q][ts]; v[q][3] = Kp[q][ts + ng]; }
+#endif
         // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
         // their weights are exact zeros and the products drop out
         double e[NLY][4];
@@ -316,7 +324,11 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         for (int q = 0; q < NLY; ++q) {
             const double *Sf = tb.K + L.off_self + (size_t)c.inds[ks[q]] * ng;
             const double *Ff = tb.K + L.off_for + (size_t)c.indf[ks[q]] * ng;
+#ifdef LW_EXP_HALF
+            s0[q] = Sf[0]; s1[q] = s0[q]; f0[q] = Ff[0]; f1[q] = f0[q];
+#else
             s0[q] = Sf[0]; s1[q] = Sf[ng]; f0[q] = Ff[0]; f1[q] = Ff[ng];
+#endif
         }
 #pragma unroll
         for (int q = 0; q < NLY; ++q) {
@@ -341,8 +353,16 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
                     double scb, spp;
                     spec_idx(colA[q], M.refrat, colB[q], mult, tb.oneminus, scb, spp, jm, fm[q]);
                 }
+#ifdef LW_EXP_ROW0
+                const double *Kp = tb.K + M.off + (size_t)(0 * c.indm[ks[q]] * M.nsp + jm) * ng;
+#else
                 const double *Kp = tb.K + M.off + (size_t)(c.indm[ks[q]] * M.nsp + jm) * ng;
+#endif
+#ifdef LW_EXP_HALF
+                a0[q] = Kp[0]; a1[q] = a0[q]; b0[q] = Kp[tm]; b1[q] = b0[q];
+#else
                 a0[q] = Kp[0]; a1[q] = Kp[ng]; b0[q] = Kp[tm]; b1[q] = Kp[tm + ng];
+#endif
             }
 #pragma unroll
             for (int q = 0; q < NLY; ++q) {
@@ -387,6 +407,142 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         taug[q] = t * R.postscale;
         frac[q] = fr[q];
     }
+}
+
+// gaseous optical depth and Planck fraction of layer k for this lane's g-point: the 16 taugbNN routines
+// (LW:4712-7828) as one data-driven expression WITHOUT control flow in front of the table reads.  The kernel is not
+// short of cache bandwidth (reading every table at its first row changes nothing) but of parallelism in one wave:
+// with a branch per feature (continua, each minor species, the Planck fraction) the compiler keeps each feature's
+// "LDS read -> index arithmetic -> gather -> use" chain behind the previous one, five dependent memory round trips
+// per layer at three waves per SIMD.  Here every index is formed first and all 26 gathers go out together; features a
+// g-point does not have read the zero pad (descriptor offsets point there) or carry a zero weight / multiplier, so
+// their terms are exact zeros.  Only the outer points of the 3-point edge stencils (LW:5231-5290) keep a branch,
+// taken by the few lanes that sit on an edge, behind the gathers.
+__device__ __forceinline__ void gas_optics_flat(const LwDeviceTables &tb, const LCol &c, const LwRegime &R,
+                                                const LaneL &L, const int k, double &taug, double &frac)
+{
+    const uint32_t cf = R.cfg;
+    const int nl = c.nl, ng = L.ng;
+    const int type = (cf >> LC_TYPE_SHIFT) & 3;
+    const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
+    const int nsp = (cf >> LC_NSP_SHIFT) & 15;
+    const bool binary = type == 2, edges = cf & LC_EDGES;
+    const double mult = (cf & LC_MULT4) ? 4. : 8.;
+    const int ts = (binary ? nsp : 1) * ng;
+    // ---- everything the layer contributes (LDS) ----
+    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
+    const double rat0 = c.rat[(rs * 2 + 0) * nl + k], rat1 = c.rat[(rs * 2 + 1) * nl + k];
+    const double f00 = c.fac00[k], f10 = c.fac10[k], f01 = c.fac01[k], f11 = c.fac11[k];
+    const int rb0 = c.rb0[k], rb1 = c.rb1[k], inds = c.inds[k], indf = c.indf[k], im = c.indm[k];
+    const double selffac = c.selffac[k], selffrac = c.selffrac[k], forfac = c.forfac[k], forfrac = c.forfrac[k];
+    const double mf = c.minorfrac[k];
+    const double mm0 = c.mul[R.minor[0].slot * nl + k], mm1 = c.mul[R.minor[1].slot * nl + k],
+                 mm2 = c.mul[R.minor[2].slot * nl + k];
+    const double halo = c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
+    const double pp = c.pavel[k];
+    // ---- indices: major species at the two reference pressures, the minors, the Planck fraction ----
+    double sc[2], wm1[2], w0[2], w1[2], w2[2];
+    int js[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        double speccomb, specparm, fs;
+        int jsi;
+        spec_idx(colA, m == 0 ? rat0 : rat1, colB, mult, tb.oneminus, speccomb, specparm, jsi, fs);
+        wm1[m] = 0.; w0[m] = 1. - fs; w1[m] = fs; w2[m] = 0.;
+        {   // LW:5231-5290 (weights only; selected below)
+            const bool lo = specparm < 0.125, hi = specparm > 0.875;
+            const double p = lo ? fs - 1 : -fs;
+            const double p4 = (p * p) * (p * p);
+            const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+            const double e_m1 = hi ? fk2 : 0., e_0 = lo ? fk0 : (hi ? fk1 : w0[m]), e_1 = lo ? fk1 : (hi ? fk0 : w1[m]),
+                         e_2 = lo ? fk2 : 0.;
+            wm1[m] = edges ? e_m1 : 0.; w0[m] = edges ? e_0 : w0[m]; w1[m] = edges ? e_1 : w1[m]; w2[m] = edges ? e_2 : 0.;
+        }
+        wm1[m] = binary ? wm1[m] : 0.; w0[m] = binary ? w0[m] : 1.; w1[m] = binary ? w1[m] : 0.; w2[m] = binary ? w2[m] : 0.;
+        js[m] = binary ? jsi : 0;
+        sc[m] = binary ? speccomb : colA;
+    }
+    int jm[3];
+    double fm[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        double scb, spp, f;
+        int j;
+        spec_idx(colA, R.minor[m].refrat, colB, mult, tb.oneminus, scb, spp, j, f);
+        const bool many = R.minor[m].nsp > 1;
+        jm[m] = many ? j : 0;
+        fm[m] = many ? f : 0.;
+    }
+    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    int jpl;
+    double fpl;
+    {
+        double scb, spp;
+        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
+        jpl = fmode == 2 ? jpl : 0;
+    }
+    // ---- all table reads ----
+    const double *Ka = tb.K + R.off_major + (size_t)(rb0 * nsp + js[0]) * ng;
+    const double *Kb = tb.K + R.off_major + (size_t)(rb1 * nsp + js[1]) * ng;
+    const double *Sf = tb.K + L.off_self + (size_t)inds * ng, *Ff = tb.K + L.off_for + (size_t)indf * ng;
+    const double *M0 = tb.K + R.minor[0].off + (size_t)(im * R.minor[0].nsp + jm[0]) * ng;
+    const double *M1 = tb.K + R.minor[1].off + (size_t)(im * R.minor[1].nsp + jm[1]) * ng;
+    const double *M2 = tb.K + R.minor[2].off + (size_t)(im * R.minor[2].nsp + jm[2]) * ng;
+    const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
+    const int t0 = R.minor[0].nsp * ng, t1 = R.minor[1].nsp * ng, t2 = R.minor[2].nsp * ng;
+    const double a00 = Ka[0], a01 = Ka[ng], a10 = Ka[ts], a11 = Ka[ts + ng];
+    const double b00 = Kb[0], b01 = Kb[ng], b10 = Kb[ts], b11 = Kb[ts + ng];
+    const double s0 = Sf[0], s1 = Sf[ng], fo0 = Ff[0], fo1 = Ff[ng];
+    const double m0a0 = M0[0], m0a1 = M0[ng], m0b0 = M0[t0], m0b1 = M0[t0 + ng];
+    const double m1a0 = M1[0], m1a1 = M1[ng], m1b0 = M1[t1], m1b1 = M1[t1 + ng];
+    const double m2a0 = M2[0], m2a1 = M2[ng], m2b0 = M2[t2], m2b1 = M2[t2 + ng];
+    const double fr0 = Fp[0], fr1 = Fp[ng];
+    // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
+    // their weights are exact zeros and the products drop out
+    double ea[4] = {0., 0., 0., 0.}, eb[4] = {0., 0., 0., 0.};
+    if (wm1[0] != 0.) { ea[0] = Ka[-ng]; ea[1] = Ka[ts - ng]; }
+    if (w2[0] != 0.) { ea[2] = Ka[2 * ng]; ea[3] = Ka[ts + 2 * ng]; }
+    if (wm1[1] != 0.) { eb[0] = Kb[-ng]; eb[1] = Kb[ts - ng]; }
+    if (w2[1] != 0.) { eb[2] = Kb[2 * ng]; eb[3] = Kb[ts + 2 * ng]; }
+    // ---- sums ----
+    const double maj0 = (wm1[0] * f00) * ea[0] + (w0[0] * f00) * a00 + (w1[0] * f00) * a01 + (w2[0] * f00) * ea[2] +
+                        (wm1[0] * f10) * ea[1] + (w0[0] * f10) * a10 + (w1[0] * f10) * a11 + (w2[0] * f10) * ea[3];
+    const double maj1 = (wm1[1] * f01) * eb[0] + (w0[1] * f01) * b00 + (w1[1] * f01) * b01 + (w2[1] * f01) * eb[2] +
+                        (wm1[1] * f11) * eb[1] + (w0[1] * f11) * b10 + (w1[1] * f11) * b11 + (w2[1] * f11) * eb[3];
+    double tau = 0.;
+    {
+        const double t2s = sc[0] * maj0 + sc[1] * maj1, t1s = colA * (maj0 + maj1);
+        tau = type == 2 ? t2s : (type == 1 ? t1s : 0.);
+    }
+    {   // continua (selffac / forfac already carry colh2o, LW:3806-3807)
+        const double tauself = (cf & LC_SELF) ? selffac * (s0 + selffrac * (s1 - s0)) : 0.;
+        const double taufor = (cf & LC_FOR) ? forfac * (fo0 + forfrac * (fo1 - fo0)) : 0.;
+        tau = (cf & (LC_SELF | LC_FOR)) ? tau + tauself + taufor : tau;
+    }
+    {   // minor species, e.g. LW:5297-5301, 5877-5878 (an absent one multiplies the zero column)
+        const double x1 = m0a0 + fm[0] * (m0a1 - m0a0), x2 = m0b0 + fm[0] * (m0b1 - m0b0);
+        const double y1 = m1a0 + fm[1] * (m1a1 - m1a0), y2 = m1b0 + fm[1] * (m1b1 - m1b0);
+        const double z1 = m2a0 + fm[2] * (m2a1 - m2a0), z2 = m2b0 + fm[2] * (m2b1 - m2b0);
+        const double add0 = mm0 * (x1 + mf * (x2 - x1)), add1 = mm1 * (y1 + mf * (y2 - y1)),
+                     add2 = mm2 * (z1 + mf * (z2 - z1));
+        // the reference adds only the minors a band has: keep the order and skip exact zeros of absent ones
+        tau = R.minor[0].slot != LS_ZERO ? tau + add0 : tau;
+        tau = R.minor[1].slot != LS_ZERO ? tau + add1 : tau;
+        tau = R.minor[2].slot != LS_ZERO ? tau + add2 : tau;
+    }
+    tau = tau + halo;
+    // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
+    const int corr = (cf >> LC_CORR_SHIFT) & 3;
+    {
+        const double c1 = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
+        const double c2 = 1. - 0.15 * (pp / 95.6);
+        const double c3 = 1. - .05 * (pp - 100.) / 900.;
+        const double corradj = corr == 1 ? c1 : (corr == 2 ? c2 : c3);
+        tau = corr ? corradj * tau : tau;
+    }
+    taug = tau * R.postscale;
+    const double fri = fr0 + fpl * (fr1 - fr0);
+    frac = fmode == 2 ? fri : (fmode == 1 ? R.fracconst : 0.);
 }
 
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
@@ -560,11 +716,14 @@ __device__ double o3clim(double plev_b, double plev_t)
 // "too abundant to be minor" column adjustment, e.g. LW:5209-5216
 __device__ __forceinline__ double adjcol(double col, double coldry, double chiref, double thr, double a0, double ex)
 {
-    double chi = col / coldry;
-    double rat = 1.e20 * chi / chiref;
-    double adjfac = a0 + pow(rat - a0, ex);
-    double adj = adjfac * chiref * coldry * 1.e-20;
-    return rat > thr ? adj : col;
+    double chi = fdiv(col, coldry);
+    double rat = fdiv(1.e20 * chi, chiref);
+    double out = col;
+    if (rat > thr) {   // rare (a species several times more abundant than in the reference atmosphere): pow only there
+        const double adjfac = a0 + pow(rat - a0, ex);
+        out = adjfac * chiref * coldry * 1.e-20;
+    }
+    return out;
 }
 
 }  // namespace
@@ -709,18 +868,12 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         const double minorfrac = factor - (double)indminor;
         const double *X = tb.chi_mls;   // [7][59]
 #define CHI(m, l) X[((m)-1) * 59 + (l)-1]
-        c.rat[(LR_H2OCO2 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(2, jp);
-        c.rat[(LR_H2OCO2 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(2, jp + 1);
-        c.rat[(LR_H2OO3 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(3, jp);
-        c.rat[(LR_H2OO3 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(3, jp + 1);
-        c.rat[(LR_H2ON2O * 2 + 0) * nl + k] = CHI(1, jp) / CHI(4, jp);
-        c.rat[(LR_H2ON2O * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(4, jp + 1);
-        c.rat[(LR_H2OCH4 * 2 + 0) * nl + k] = CHI(1, jp) / CHI(6, jp);
-        c.rat[(LR_H2OCH4 * 2 + 1) * nl + k] = CHI(1, jp + 1) / CHI(6, jp + 1);
-        c.rat[(LR_N2OCO2 * 2 + 0) * nl + k] = CHI(4, jp) / CHI(2, jp);
-        c.rat[(LR_N2OCO2 * 2 + 1) * nl + k] = CHI(4, jp + 1) / CHI(2, jp + 1);
-        c.rat[(LR_O3CO2 * 2 + 0) * nl + k] = CHI(3, jp) / CHI(2, jp);
-        c.rat[(LR_O3CO2 * 2 + 1) * nl + k] = CHI(3, jp + 1) / CHI(2, jp + 1);
+        // chi_mls ratios at jp and jp + 1 from the tabulated quotients (lw_tables.hip: [LR_*][59] behind the 7 x 59)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            c.rat[(r * 2 + 0) * nl + k] = X[7 * 59 + r * 59 + jp - 1];
+            c.rat[(r * 2 + 1) * nl + k] = X[7 * 59 + r * 59 + jp];
+        }
         c.rat[(LR_ONE * 2 + 0) * nl + k] = 1.;
         c.rat[(LR_ONE * 2 + 1) * nl + k] = 1.;
         const double colh2o = 1.e-20 * wh2o;
@@ -980,8 +1133,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     LaneL L;
     L.ng = gd->stride; L.off_self = gd->off_self; L.off_for = gd->off_for;   // row stride (padded ng)
     double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
-    // one layer at a time: two layers side by side (gas_optics<2>) need more registers than three waves per SIMD
-    // leave (measured: 492 bytes of spills per lane, 2.4x slower)
+    // one layer at a time (two layers side by side, gas_optics<2>, need more registers than three waves per SIMD
+    // leave: 492 bytes of spills per lane, 2.4x slower; batching the stores of four layers changes nothing)
     auto run = [&](const LwRegime &R, int kbeg, int kend) {
         for (int k = kbeg; k < kend; ++k) {
             const int ks[1] = {k};
@@ -990,10 +1143,16 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             if (active) { tg[(size_t)k * LW_NGPT] = taug[0]; fr[(size_t)k * LW_NGPT] = plfrac[0]; }
         }
     };
+#ifdef LW_EXP_NOGAS
+    if (ltrop > 100000)
+#endif
     {
         const LwRegime R = gd->lo;
         run(R, 0, ltrop);
     }
+#ifdef LW_EXP_NOGAS
+    if (ltrop > 100000)
+#endif
     {
         const LwRegime R = gd->up;
         run(R, ltrop, nl);

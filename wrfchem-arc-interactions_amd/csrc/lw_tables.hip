@@ -341,6 +341,15 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
     K.resize(K.size() + 64 * MG16, 0.0);
     out.totplnk.assign(&LWREF_TOTPLNK[0][0], &LWREF_TOTPLNK[0][0] + 16 * 181);
     out.chi_mls.assign(&LWREF_CHI_MLS[0][0], &LWREF_CHI_MLS[0][0] + 7 * 59);
+    // behind the 7 x 59 mixing ratios: the six species ratios setcoef forms per layer (LW:3713-3726, 3769-3772),
+    // tabulated per reference level so that the kernel reads a quotient instead of dividing -- [LR_*][59], the same
+    // IEEE quotients
+    {
+        static const int num[6] = {1, 1, 1, 1, 4, 3}, den[6] = {2, 3, 4, 6, 2, 2};   // LR_H2OCO2 .. LR_O3CO2
+        for (int r = 0; r < 6; ++r)
+            for (int l = 0; l < 59; ++l)
+                out.chi_mls.push_back(LWREF_CHI_MLS[num[r] - 1][l] / LWREF_CHI_MLS[den[r] - 1][l]);
+    }
     return 0;
 }
 

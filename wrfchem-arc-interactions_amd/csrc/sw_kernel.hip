@@ -1104,6 +1104,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     if (b) bad = b;
                 }
             }
+            RT rtp;
             if (hasP) {
                 if ((k & (BLK - 1)) == 0) {
                     ck[((k / BLK) * 2 + 0) * 64] = rup;
@@ -1112,10 +1113,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                 RT rt;
                 double dnl = 1.;
                 layer_rt(want_sfc, tb, taug, taur, p_aer ? ta : 0.0, wa, ga, prmu0, rprmu0, cloudy && p_mask, cl, rt, dnl);
-                {   // keep the layer's two-stream result for the way down
-                    double *s = scr + (size_t)k * SW_SCR_VALS * 64;
-                    s[0] = rt.ref; s[64] = rt.refd; s[128] = rt.tra; s[192] = rt.trad; s[256] = rt.dbt;
-                }
+                rtp = rt;   // stored at the end of the iteration, see below
                 tdbt_nodel = dnl * tdbt_nodel;
                 // vrtqdr_sw, SW:7997-8015
                 const double zreflect = frcp1(1. - rupd * rt.refd);
@@ -1135,6 +1133,13 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     layer_rt_clean(tb, taug, taur, prmu0, rprmu0, rt);
                 }
                 add_on_top(st, rt);
+            }
+            if (hasP) {
+                // keep the layer's two-stream result for the way down.  Last in the iteration: vector memory
+                // operations retire in order, and a table gather issued behind these stores would have its first
+                // use wait for their acknowledgement too -- here the next gather is a whole layer preparation away
+                double *s = scr + (size_t)k * SW_SCR_VALS * 64;
+                s[0] = rtp.ref; s[64] = rtp.refd; s[128] = rtp.tra; s[192] = rtp.trad; s[256] = rtp.dbt;
             }
         }
         if (hasS) {
