@@ -195,7 +195,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         return fail(err, "rrtmg_hip_swrad: the four SSiB albedos and xland must be passed together");
     if (a->tauaer3d_sw && !(a->ssaaer3d_sw && a->asyaer3d_sw))
         return fail(err, "rrtmg_hip_swrad: tauaer3d_sw needs ssaaer3d_sw and asyaer3d_sw");
-    if (sw_lds_bytes(nk, a->icloud != 0, a->swupflx != nullptr) > 160 * 1024) return fail(err, "rrtmg_hip_swrad: column does not fit LDS");
+    if (sw_lds_bytes(nk, a->icloud != 0, a->swupflx != nullptr, !a->tauaer3d_sw && !a->aerod) > 160 * 1024) return fail(err, "rrtmg_hip_swrad: column does not fit LDS");
     HIPCHK(hipSetDevice(st.device));
 
     hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;

@@ -50,7 +50,7 @@ constexpr int CLD_NTAB = 7, CLD_STRIDE = 58;
 void sw_cloud_tables(double *out /*[CLD_NTAB][SW_NBND][CLD_STRIDE]*/);
 hipError_t sw_upload_retab();
 
-size_t sw_lds_bytes(int nk, bool cloud, bool prof);
+size_t sw_lds_bytes(int nk, bool cloud, bool prof, bool compact_aerosol);
 hipError_t sw_upload_constants(hipStream_t stream);
 size_t sw_scratch_doubles_per_column(int nk);
 hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream);

@@ -41,6 +41,8 @@
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "rrtmg_common.h"
 #include "sw_kernel.h"
 #include "cld_retab.h"
@@ -82,6 +84,7 @@ __constant__ double c_o3ann[31];
 __constant__ double c_ppwrkh[32];
 // band mid wavelengths (um) of the 14 SW intervals, from wavemin/wavemax SW:10080-10085
 __constant__ double c_wavemid[SW_NBND];
+__constant__ double c_lnwave[SW_NBND];   // ln(0.4 / wavemid)
 
 __device__ __forceinline__ double ldr(const void *p, size_t idx, int real4)
 {
@@ -266,7 +269,8 @@ struct ColView {
     double *selffac, *selffrac, *forfac, *forfrac;
     double *col;        // [SP_COUNT][nlp]
     double *colmol, *pdp;
-    double *taer, *waer, *gaer;   // [14][nlp]
+    double *taer, *waer, *gaer;   // [14][nlp]; compact: waer = {slope, value at 600 nm}[nlp] of omega, gaer of g
+    bool compact;                 // WRF-Chem route only: omega and g of a band follow from two values per layer
     int *rb0, *rb1, *inds, *indf, *jp;   // row bases (0-based), continuum rows, jp
     double *flux;       // [NWAVE][nlp + 1][2] level fluxes of the P stream (call with aerosol)
     double *sums;       // [NWAVE][SUMS_N] surface / TOA sums of the waves (SUM_* slots)
@@ -283,16 +287,19 @@ struct ColView {
 // level, then {TOA up, TOA down, surface up, surface down} of the clean-sky (S) and clear-sky (K) streams
 enum : int { SUM_DIRBB = 0, SUM_UVFD, SUM_UVDIR, SUM_NIFD, SUM_NIDIR, SUM_S = 8, SUM_K = 12, SUMS_N = 16 };
 
-__device__ __forceinline__ ColView carve(double *base, int nlp, bool cloud, bool prof)
+__device__ __forceinline__ ColView carve(double *base, int nlp, bool cloud, bool prof, bool compact)
 {
     ColView v;
     v.nlp = nlp;
+    v.compact = compact;
     double *p = base;
     v.fac00 = p; p += nlp; v.fac01 = p; p += nlp; v.fac10 = p; p += nlp; v.fac11 = p; p += nlp;
     v.selffac = p; p += nlp; v.selffrac = p; p += nlp; v.forfac = p; p += nlp; v.forfrac = p; p += nlp;
     v.col = p; p += SP_COUNT * nlp;
     v.colmol = p; p += nlp; v.pdp = p; p += nlp;
-    v.taer = p; p += SW_NBND * nlp; v.waer = p; p += SW_NBND * nlp; v.gaer = p; p += SW_NBND * nlp;
+    v.taer = p; p += SW_NBND * nlp;
+    v.waer = p; p += (compact ? 2 : SW_NBND) * nlp;
+    v.gaer = p; p += (compact ? 2 : SW_NBND) * nlp;
     v.flux = p; p += NWAVE * (nlp + 1) * 2;
     v.sums = p; p += NWAVE * SUMS_N;
     v.fluxc = v.fluxk = nullptr;
@@ -612,7 +619,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nlay = nk + 1, nlev = nlay + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK, nblk = nlp / BLK;
-    ColView c = carve(lds, nlp, CLOUD, PROF);
+    // the WRF-Chem aerosol route alone (300/400/600/999 nm arrays; no band-resolved input, no ECMWF types) keeps
+    // omega and g as two numbers per layer instead of 14: 10 KB less LDS per column at 50 layers = one more workgroup
+    // per CU
+    const bool compact = a.tauaer3d_sw == nullptr && a.aerod == nullptr;
+    ColView c = carve(lds, nlp, CLOUD, PROF, compact);
 
     // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
     int col;
@@ -923,6 +934,35 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     const int laytrop = __syncthreads_count(lowerp ? 1 : 0);
 
     // aerosol: defaults, then 300/400/600/999 nm -> 14 bands (SW:10974-11023)
+    if (compact) {
+        // per layer: Angstrom exponent, tau(400 nm) and the two straight lines of omega and g over wavelength (parked
+        // in the flux slots, which are free until the sweeps); per (band, layer): tau = tau400 * (0.4 / wavemid)^ang
+        // as exp(ang * ln(0.4 / wavemid)) -- one log per layer and one exp per item instead of two logs and a pow
+        double *ang = c.flux, *t400 = c.flux + nlp;
+        if (tid < nlp) {
+            const int k = tid;
+            double an = 0., t4 = 0., slw = 0., w6 = 1., slg = 0., g6 = 0.5;   // no aerosol: tau = 0 (omega, g idle)
+            if (a.aer_ra_feedback == 1 && k < nk) {
+                const size_t q = base3 + (size_t)k * sk;
+                const double t300 = ldr(a.tauaer300, q, r4), t999 = ldr(a.tauaer999, q, r4);
+                if (t300 > 1.e-9 && t999 > 1.e-9) {
+                    an = log(t300 / t999) / log(999. / 300.);
+                    t4 = ldr(a.tauaer400, q, r4);
+                    const double w4 = ldr(a.waer400, q, r4), g4 = ldr(a.gaer400, q, r4);
+                    w6 = ldr(a.waer600, q, r4); g6 = ldr(a.gaer600, q, r4);
+                    slw = (w6 - w4) / .2; slg = (g6 - g4) / .2;
+                }
+            }
+            ang[k] = an; t400[k] = t4;
+            c.waer[k] = slw; c.waer[nlp + k] = w6; c.gaer[k] = slg; c.gaer[nlp + k] = g6;
+        }
+        __syncthreads();
+        for (int item = tid; item < SW_NBND * nlp; item += NTHREADS) {
+            const int nb = item / nlp, k = item - nb * nlp;
+            const double t4 = t400[k];
+            c.taer[item] = t4 != 0. ? t4 * exp(ang[k] * c_lnwave[nb]) : 0.;
+        }
+    } else
     for (int item = tid; item < SW_NBND * nlp; item += NTHREADS) {
         const int nb = item / nlp, k = item - nb * nlp;
         double tau = 0., ssa = 1., asy = 0.;
@@ -992,6 +1032,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     LaneG L;
     L.lo = gd.lo; L.up = gd.up; L.ng = gd.ng; L.off_self = gd.off_self; L.off_for = gd.off_for;
     L.band = gd.band; L.off_rayla = gd.off_rayla;
+    const double dwave = c_wavemid[gd.band] - .6;
 
     // McICA: this lane's sub-column of binary cloud (generate_stochastic_clouds_sw, SW:1737-1772, icld = 2):
     // bit k of cmask = cloudy in layer k.  The lane jumps the column's KISS sequence to its own nlay draws.
@@ -1093,7 +1134,14 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             const int kn = k + 1 < nlay ? k + 1 : k;
             if (!hasS) gas_fetch(tb, c, L, kn, kn < laytrop, gp);
             const int ia = L.band * nlp + k;
-            const double ta = c.taer[ia], wa = c.waer[ia], ga = c.gaer[ia];
+            const double ta = c.taer[ia];
+            double wa, ga;
+            if (compact) {   // omega and g of this lane's band from the layer's two lines (SW:11006-11021)
+                wa = fmin(fmax(c.waer[k] * dwave + c.waer[nlp + k], 0.4), 1.0);
+                ga = fmin(fmax(c.gaer[k] * dwave + c.gaer[nlp + k], 0.5), 1.0);
+            } else {
+                wa = c.waer[ia]; ga = c.gaer[ia];
+            }
             bool cloudy = false;
             CldLayer cl = {0., 1., 0., 0.};
             if (CLOUD) {
@@ -1335,11 +1383,12 @@ size_t sw_scratch_doubles_per_column(int nk)
 }
 
 // ---------------------------------------------------------------------------
-size_t sw_lds_bytes(int nk, bool cloud, bool prof)
+size_t sw_lds_bytes(int nk, bool cloud, bool prof, bool compact)
 {
     const int nlay = nk + 1;
     const int nlp = (nlay + BLK - 1) / BLK * BLK;
-    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + 3 * SW_NBND) + (size_t)NWAVE * (nlp + 1) * 2 + NWAVE * SUMS_N;
+    size_t nd = (size_t)nlp * (8 + SP_COUNT + 2 + (compact ? SW_NBND + 4 : 3 * SW_NBND)) + (size_t)NWAVE * (nlp + 1) * 2 +
+                NWAVE * SUMS_N;
     if (prof) nd += (size_t)NWAVE * (nlp + 1) * 2 * (cloud ? 2 : 1);
     if (cloud) nd += (size_t)nlp * 7 + NTHREADS;
     size_t ni = (size_t)nlp * 5 + 1 + (cloud ? (size_t)nlp * 3 + 4 : 0);
@@ -1384,6 +1433,9 @@ hipError_t sw_upload_constants(hipStream_t)
     hipError_t e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_o3ann), o3ann, sizeof o3ann)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_ppwrkh), ppwrkh, sizeof ppwrkh)) != hipSuccess) return e;
+    double lnwave[SW_NBND];
+    for (int i = 0; i < SW_NBND; ++i) lnwave[i] = std::log(0.4 / wavemid[i]);
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lnwave), lnwave, sizeof lnwave)) != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_wavemid), wavemid, sizeof wavemid);
 }
 
@@ -1401,7 +1453,7 @@ hipError_t sw_upload_retab()
 hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream)
 {
     const bool cloud = a.icloud != 0, prof = a.swupflx != nullptr;
-    const size_t lds = sw_lds_bytes(a.nk, cloud, prof);
+    const size_t lds = sw_lds_bytes(a.nk, cloud, prof, a.tauaer3d_sw == nullptr && a.aerod == nullptr);
     const void *fn = cloud ? (prof ? reinterpret_cast<const void *>(sw_column_kernel<true, true>)
                                    : reinterpret_cast<const void *>(sw_column_kernel<true, false>))
                            : (prof ? reinterpret_cast<const void *>(sw_column_kernel<false, true>)
