@@ -87,7 +87,9 @@ def main():
         out = {"source": f"profiles/{tag}_pmc.txt", "columns_per_launch": cols, "kernels": traffic,
                "hbm_bytes_per_launch": sw.get("hbm_bytes_per_launch"),
                "fetch_size_kb": sw.get("fetch_size_kb"), "write_size_kb": sw.get("write_size_kb")}
-        with open(os.path.join(root, "traffic_latest.json"), "w") as fh:
+        # traffic_latest.json is what bench.py reads: keep it on the default workload (pass --keep-latest for others)
+        target = f"{tag}_traffic.json" if "--keep-latest" in sys.argv else "traffic_latest.json"
+        with open(os.path.join(root, target), "w") as fh:
             json.dump(out, fh, indent=1)
     print("\n".join(lines))
 

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace rrtmg {
@@ -143,18 +144,33 @@ private:
         const size_t b = (size_t)nblk * g_.nj_t * kext * g_.ni_t * g_.rb;
         return (b + 63) & ~size_t(63);
     }
-    void copy_tile(const Req &r, bool to_pinned) const
+    void copy_rows(const Req &r, bool to_pinned, int j0, int j1) const
     {
         const size_t row = (size_t)g_.ni_t * g_.rb;
         char *pk = static_cast<char *>(pool_->pin) + r.off;
         for (int b = 0; b < r.nblk; ++b)
-            for (int j = 0; j < g_.nj_t; ++j)
+            for (int j = j0; j < j1; ++j)
                 for (int k = 0; k < r.kext; ++k) {
                     const size_t h = ((((size_t)b * g_.nj_m + (g_.j0 + j)) * r.kext + k) * g_.ni_m + g_.i0) * g_.rb;
                     const size_t q = (((size_t)b * g_.nj_t + j) * r.kext + k) * row;
                     if (to_pinned) std::memcpy(pk + q, static_cast<const char *>(r.hin) + h, row);
                     else std::memcpy(static_cast<char *>(r.hout) + h, pk + q, row);
                 }
+    }
+    // the packing is plain memory copying; large arrays are split over a few helper threads by rows (a patch of a
+    // production domain is hundreds of MB per call, one core moves about 5 GB/s)
+    void copy_tile(const Req &r, bool to_pinned) const
+    {
+        const size_t total = (size_t)r.nblk * g_.nj_t * r.kext * g_.ni_t * g_.rb;
+        unsigned nt = total >= (size_t(4) << 20) ? std::thread::hardware_concurrency() : 1;
+        if (nt > 8) nt = 8;
+        if (nt > (unsigned)g_.nj_t) nt = (unsigned)g_.nj_t;
+        if (nt <= 1) { copy_rows(r, to_pinned, 0, g_.nj_t); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t)
+            th.emplace_back([=, &r] { copy_rows(r, to_pinned, (int)((size_t)g_.nj_t * t / nt), (int)((size_t)g_.nj_t * (t + 1) / nt)); });
+        copy_rows(r, to_pinned, 0, (int)((size_t)g_.nj_t / nt));
+        for (auto &x : th) x.join();
     }
     TileGeom g_;
     std::vector<Req> reqs_;
