@@ -53,7 +53,13 @@ __constant__ double c_a2[LW_NBND] = {0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.
 
 __device__ __forceinline__ double ldr(const void *p, size_t idx, int real4)
 {
-    return real4 ? (double)reinterpret_cast<const float *>(p)[idx] : reinterpret_cast<const double *>(p)[idx];
+    // branch-free for both widths: a branch around every load would put a wait behind each one (the loads of a
+    // phase then cost one trip to memory each instead of one together), so the value comes in as two dwords -- the
+    // same dword twice for a REAL*4 array -- and is picked by a select
+    const unsigned *w = reinterpret_cast<const unsigned *>(p) + (real4 ? idx : 2 * idx);
+    const unsigned lo = w[0], hi = w[real4 ? 0 : 1];
+    const double f = (double)__uint_as_float(lo), d = __hiloint2double((int)hi, (int)lo);
+    return real4 ? f : d;
 }
 __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
 {
@@ -173,8 +179,9 @@ struct LCol {   // LDS image of the column
     double *taua;      // [16][nl]
     double *secdiff, *plankbnd;   // [16]
     double *wrk;       // [2][nl] scratch for the column sums
-    double *pfr;       // [2][nl]+2 Planck-table fractions (layer, level above; surface level, boundary)
-    int *pix;          // [2][nl]+2 Planck-table indices, same order
+    double *tz;        // [nl+1] level temperatures
+    double *tav;       // [nl] t3d of the layer (the layers kte-1.. take the level mean instead)
+    double *taul;      // [16][nl] LDS copy of taua for the column sums
     double *flux;      // [3 waves][4][nl+1]: down clean, down total, up clean, up total
     int *rb0, *rb1, *inds, *indf, *indm;
     int nl;
@@ -194,10 +201,11 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
     c.mul = p; p += LS_COUNT * nl;
     c.rat = p; p += LR_COUNT * 2 * nl;
     c.wrk = p; p += 2 * nl;
-    c.pfr = p; p += 2 * nl + 2;
+    c.tz = p; p += nl + 1;
+    c.tav = p; p += nl;
+    c.taul = p; p += LW_NBND * nl;
     int *q = reinterpret_cast<int *>(p);
     c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
-    c.pix = q; q += 2 * nl + 2;
     double *r = rec;
     c.planklay = r; r += LW_NBND * nl;
     c.planklev = r; r += LW_NBND * (nl + 1);
@@ -684,11 +692,11 @@ __device__ double plev_at(const LwKernelArgs &a, size_t base3, size_t sk, int l,
 // temperature of the 60-level mean profile interpolated to pressure p, LW:12219-12241
 __device__ double varint_at(double p)
 {
-    int klev = 60;
-    if (c_pprof[59] < p) {
-        for (int LL = 2; LL <= 60; ++LL)
-            if (c_pprof[LL - 1] < p) { klev = LL - 1; break; }
-    }
+    // first level (from the surface) of the mean profile below p; without the search loop's early exit
+    int first = 60;
+#pragma unroll
+    for (int j = 59; j >= 1; --j) first = c_pprof[j] < p ? j : first;
+    const int klev = c_pprof[59] < p ? first : 60;
     double vark = c_tprof[klev - 1], vark1 = klev != 60 ? c_tprof[klev] : vark;
     double wght = klev != 60 ? (p - c_pprof[klev - 1]) / (c_pprof[klev] - c_pprof[klev - 1]) : 0.0;
     return wght * (vark1 - vark) + vark;
@@ -758,17 +766,57 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     const double tbound = ldr(a.tsk, i2, r4);
     const double semiss = ldr(a.emiss, i2, r4);   // same emissivity in all 16 bands, LW:12296-12298
 
-    // ======================= prologue: lanes = layers =======================
+    // ======================= prologue =======================
+    // three phases between two barriers, so that no wave sits through the whole of it:
+    //   A  wave 0, lanes = levels: level pressures / temperatures and the layers' p, T, qv -> LDS (one round trip to
+    //      memory); waves 1-2 meanwhile: aerosol optical depths (memory only)
+    //   B  wave 0, lanes = layers: inatm + setcoef; waves 1-2: Planck functions of the layers and levels
+    //   C  column sums (precipitable water, aerosol optical depth) by 16 lanes each of waves 0 and 1
+#ifdef LW_EXP_CLOCK   // cycle stamps of the phases, printed by three workgroups (profiling aid)
+    long long tstamp[8];
+#define LW_STAMP(i) tstamp[i] = clock64()
+#else
+#define LW_STAMP(i)
+#endif
+    __shared__ int s_laytrop;
+    if (tid == 0) s_laytrop = 0;
+    LW_STAMP(0);
+    if (wave == 0) {
+        for (int l = lane; l <= nl; l += 64) {
+            c.pz[l] = plev_at(a, base3, sk, l, nk, nl);
+            c.tz[l] = tlev_at(a, base3, sk, l, nk, nl);
+            if (l < nl) {
+                const int km = l < nk ? l : nk - 1;
+                c.tav[l] = ldr(a.t3d, base3 + (size_t)km * sk, r4);
+                c.pavel[l] = ldr(a.p3d, base3 + (size_t)km * sk, r4) / 100.;
+                c.wrk[l] = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
+            }
+        }
+    } else {
+        // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers)
+        for (int item = tid - 64; item < LW_NBND * nl; item += LW_THREADS - 64) {
+            const int nb = item / nl, k = item - nb * nl;
+            double tau = 0.;
+            if (a.aer_ra_feedback == 1 && k < nk) {
+                const size_t q = base3 + (size_t)k * sk;
+                const double t0 = ldr(a.tauaerlw[0], q, r4), t15 = ldr(a.tauaerlw[15], q, r4), tn = ldr(a.tauaerlw[nb], q, r4);
+                if (t0 > 1.e-9 && t15 > 1.e-9) tau = tn;
+            }
+            c.taua[item] = tau;
+            c.taul[item] = tau;
+        }
+    }
+    LW_STAMP(1);
+    __syncthreads();
+    LW_STAMP(2);
     int nlower = 0;
-    for (int k = tid; k < nl; k += LW_THREADS) {
-        const double plev_b = plev_at(a, base3, sk, k, nk, nl), plev_t = plev_at(a, base3, sk, k + 1, nk, nl);
-        const double pavel = k < nk ? ldr(a.p3d, base3 + (size_t)k * sk, r4) / 100. : 0.5 * (plev_b + plev_t);
-        const double tz_t = tlev_at(a, base3, sk, k + 1, nk, nl);
-        double tavel;
-        if (k <= nk - 2) tavel = ldr(a.t3d, base3 + (size_t)k * sk, r4);
-        else tavel = 0.5 * (tz_t + tlev_at(a, base3, sk, k, nk, nl));   // LW:12246 (also overwrites tlay(kte))
-        const int km = k < nk ? k : nk - 1;
-        double qv = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
+    if (wave == 0)
+    for (int k = lane; k < nl; k += 64) {
+        const double plev_b = c.pz[k], plev_t = c.pz[k + 1];
+        const double pavel = k < nk ? c.pavel[k] : 0.5 * (plev_b + plev_t);
+        const double tz_t = c.tz[k + 1];
+        const double tavel = k <= nk - 2 ? c.tav[k] : 0.5 * (tz_t + c.tz[k]);   // LW:12246 (also overwrites tlay(kte))
+        double qv = c.wrk[k];
         qv = fmax(0., qv);
         qv = fmax(qv, 1.E-12);
         const double amdw = 1.607793, amdo = 0.603461;
@@ -802,30 +850,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         c.mul[LS_WX2 * nl + k] = coldry * cfc11 * 1.e-20;
         c.mul[LS_WX3 * nl + k] = coldry * cfc12 * 1.e-20;
         c.mul[LS_WX4 * nl + k] = coldry * cfc22 * 1.e-20;
-        // setcoef: Planck functions, LW:3583-3644
-        int indlay = (int)(tavel - 159.);
-        indlay = indlay < 1 ? 1 : (indlay > 180 ? 180 : indlay);
-        const double tlayfrac = tavel - 159. - (double)indlay;
-        int indlev = (int)(tz_t - 159.);
-        indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
-        const double tlevfrac = tz_t - 159. - (double)indlev;
-        // the 16-band table lookups are done by all threads after the barrier (LW:3600-3644)
-        c.pix[k] = indlay; c.pfr[k] = tlayfrac;
-        c.pix[nl + k] = indlev; c.pfr[nl + k] = tlevfrac;
-        if (k == 0) {
-            const double tz0 = tlev_at(a, base3, sk, 0, nk, nl);
-            int indbound = (int)(tbound - 159.);
-            indbound = indbound < 1 ? 1 : (indbound > 180 ? 180 : indbound);
-            const double tbndfrac = tbound - 159. - (double)indbound;
-            int indlev0 = (int)(tz0 - 159.);
-            indlev0 = indlev0 < 1 ? 1 : (indlev0 > 180 ? 180 : indlev0);
-            const double t0frac = tz0 - 159. - (double)indlev0;
-            c.pix[2 * nl] = indlev0; c.pfr[2 * nl] = t0frac;
-            c.pix[2 * nl + 1] = indbound; c.pfr[2 * nl + 1] = tbndfrac;
-            c.pz[0] = plev_b;
-        }
-        c.pz[k + 1] = plev_t;
-        // setcoef: interpolation factors, LW:3647-3808
+        // setcoef: interpolation factors, LW:3647-3808 (the Planck functions are with waves 1-2 below)
         const double stpfac = 296. / 1013.;
         const double plog = log(pavel);
         int jp = (int)(36. - 5 * (plog + 0.04));
@@ -1061,43 +1086,53 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
-    // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers)
-    for (int item = tid; item < LW_NBND * nl; item += LW_THREADS) {
-        const int nb = item / nl, k = item - nb * nl;
-        double tau = 0.;
-        if (a.aer_ra_feedback == 1 && k < nk) {
-            const size_t q = base3 + (size_t)k * sk;
-            if (ldr(a.tauaerlw[0], q, r4) > 1.e-9 && ldr(a.tauaerlw[15], q, r4) > 1.e-9) tau = ldr(a.tauaerlw[nb], q, r4);
-        }
-        c.taua[item] = tau;
-    }
     // laytrop: layers with ln(p) > 4.56 (LW:3673)
-    __shared__ int s_laytrop;
-    if (tid == 0) s_laytrop = 0;
-    __syncthreads();
     if (nlower) atomicAdd(&s_laytrop, nlower);
-    // Planck functions of the layers and of the levels above them in the 16 bands: (band, layer) items over all
-    // threads; the surface level and the boundary by the first 16 threads
-    for (int item = tid; item < LW_NBND * nl; item += LW_THREADS) {
-        const int ib = item / nl, k = item - ib * nl;
-        const double *P = tb.totplnk + ib * 181;
-        const int indlay = c.pix[k], indlev = c.pix[nl + k];
-        const double dbdtlev = P[indlev] - P[indlev - 1];
-        const double dbdtlay = P[indlay] - P[indlay - 1];
-        c.planklay[ib * nl + k] = P[indlay - 1] + c.pfr[k] * dbdtlay;
-        c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + c.pfr[nl + k] * dbdtlev;
+    if (wave != 0) {
+        // setcoef: Planck functions of the layers and of the levels above them in the 16 bands, LW:3583-3644;
+        // (band, layer) items
+        for (int item = tid - 64; item < LW_NBND * nl; item += LW_THREADS - 64) {
+            const int ib = item / nl, k = item - ib * nl;
+            const double *P = tb.totplnk + ib * 181;
+            const double tz_t = c.tz[k + 1];
+            const double tavel = k <= nk - 2 ? c.tav[k] : 0.5 * (tz_t + c.tz[k]);
+            int indlay = (int)(tavel - 159.);
+            indlay = indlay < 1 ? 1 : (indlay > 180 ? 180 : indlay);
+            const double tlayfrac = tavel - 159. - (double)indlay;
+            int indlev = (int)(tz_t - 159.);
+            indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
+            const double tlevfrac = tz_t - 159. - (double)indlev;
+            const double dbdtlev = P[indlev] - P[indlev - 1];
+            const double dbdtlay = P[indlay] - P[indlay - 1];
+            c.planklay[ib * nl + k] = P[indlay - 1] + tlayfrac * dbdtlay;
+            c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + tlevfrac * dbdtlev;
+        }
+        if (tid >= 128 && tid < 128 + LW_NBND) {   // the surface level and the boundary
+            const int ib = tid - 128;
+            const double *P = tb.totplnk + ib * 181;
+            const double tz0 = c.tz[0];
+            int indbound = (int)(tbound - 159.);
+            indbound = indbound < 1 ? 1 : (indbound > 180 ? 180 : indbound);
+            const double tbndfrac = tbound - 159. - (double)indbound;
+            int indlev0 = (int)(tz0 - 159.);
+            indlev0 = indlev0 < 1 ? 1 : (indlev0 > 180 ? 180 : indlev0);
+            const double t0frac = tz0 - 159. - (double)indlev0;
+            double dbdtlev = P[indbound] - P[indbound - 1];
+            c.plankbnd[ib] = semiss * (P[indbound - 1] + tbndfrac * dbdtlev);
+            dbdtlev = P[indlev0] - P[indlev0 - 1];
+            c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + t0frac * dbdtlev;
+        }
     }
+    LW_STAMP(3);
+    __syncthreads();
+    LW_STAMP(4);
+    const int ltrop = s_laytrop;
     if (tid < LW_NBND) {
         const int ib = tid;
-        const double *P = tb.totplnk + ib * 181;
-        const int indlev0 = c.pix[2 * nl], indbound = c.pix[2 * nl + 1];
-        double dbdtlev = P[indbound] - P[indbound - 1];
-        c.plankbnd[ib] = semiss * (P[indbound - 1] + c.pfr[2 * nl + 1] * dbdtlev);
-        dbdtlev = P[indlev0] - P[indlev0 - 1];
-        c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + c.pfr[2 * nl] * dbdtlev;
         // precipitable water -> diffusivity angle of this band, LW:11307-11309 and LW:3142-3150 (every one of the
         // 16 threads forms the column sums in the reference's order)
         double amttl = 0.0, wvttl = 0.0;
+#pragma unroll 8
         for (int k = 0; k < nl; ++k) { amttl = amttl + c.wrk[k]; wvttl = wvttl + c.wrk[nl + k]; }
         const double amd = 28.9660, amw = 18.0160, grav = 9.8066;
         const double wvsh = (amw * wvttl) / (amd * amttl);
@@ -1110,20 +1145,19 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         c.secdiff[ib] = sd;
     }
-    __syncthreads();
-    const int ltrop = s_laytrop;
     if (a.aer_ra_feedback == 1 && tid >= 64 && tid < 64 + LW_NBND) {
         // negative column aerosol optical depth is fatal, LW:12607-12615
         const int nb = tid - 64;
         double slope = 0.;
-        for (int k = 0; k < nk; ++k) slope = slope + c.taua[nb * nl + k];
+#pragma unroll 8
+        for (int k = 0; k < nk; ++k) slope = slope + c.taul[nb * nl + k];
         if (slope < 0.) atomicMax(a.status, 1 + col);
     }
-    __syncthreads();
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
     for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 1) + l] = c.pz[l];
 
+    LW_STAMP(5);
     // ======================= gas optics: lanes = g-points, loop over layers =======================
     const int gbeg = wave * LW_CHUNK;
     const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
@@ -1154,9 +1188,17 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     if (ltrop > 100000)
 #endif
     {
+        LW_STAMP(6);
         const LwRegime R = gd->up;
         run(R, ltrop, nl);
     }
+#ifdef LW_EXP_CLOCK
+    LW_STAMP(7);
+    if ((blockIdx.x == 5 || blockIdx.x == 3000 || blockIdx.x == 20000) && lane == 0)
+        printf("blk %d wave %d: A %lld bar %lld B %lld bar %lld C %lld gaslo %lld gasup %lld (ltrop %d nl %d)\n", blockIdx.x, wave,
+               tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3],
+               tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], ltrop, nl);
+#endif
 }
 
 // Kernel 2 of 2: radiative transfer (rtrnmc) for the clean and the aerosol optical depths, lanes = g-points;
@@ -1656,8 +1698,8 @@ lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
 // ---------------------------------------------------------------------------
 size_t lw_gas_lds_bytes(int nl)
 {
-    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 2) + 2 + (nl + 1);
-    size_t ni = (size_t)nl * 7 + 2;
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1 + LW_NBND) + 2 * (nl + 1);
+    size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)

@@ -597,10 +597,12 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             const cplx mb = mix_index(vol, vwet, a.mix, w2);
             double xb = pi * dwet * frcp(lam2);
             xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            // the register-only small-size path when every lane of the wave qualifies (|mx| <= 2, <= 8 terms)
+            // the register-only small-size path for the particles that qualify (|mx| <= 2, <= 8 terms).  The choice is
+            // the particle's own -- a wave with both kinds runs both branches -- so that a cell's result does not
+            // depend on which cells share its wave, i.e. on the tiling of the domain
             const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for both bands
             const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
-            if (__all(t1.small && t2.small)) {
+            if (t1.small && t2.small) {
                 mie_pair_small(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);
             } else {
                 const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);

@@ -88,7 +88,13 @@ __constant__ double c_lnwave[SW_NBND];   // ln(0.4 / wavemid)
 
 __device__ __forceinline__ double ldr(const void *p, size_t idx, int real4)
 {
-    return real4 ? (double)reinterpret_cast<const float *>(p)[idx] : reinterpret_cast<const double *>(p)[idx];
+    // branch-free for both widths: a branch around every load would put a wait behind each one (the loads of a
+    // phase then cost one trip to memory each instead of one together), so the value comes in as two dwords -- the
+    // same dword twice for a REAL*4 array -- and is picked by a select
+    const unsigned *w = reinterpret_cast<const unsigned *>(p) + (real4 ? idx : 2 * idx);
+    const unsigned lo = w[0], hi = w[real4 ? 0 : 1];
+    const double f = (double)__uint_as_float(lo), d = __hiloint2double((int)hi, (int)lo);
+    return real4 ? f : d;
 }
 __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
 {
