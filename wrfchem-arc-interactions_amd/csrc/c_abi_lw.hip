@@ -94,6 +94,7 @@ extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, dou
     HIPCHK(upload(&st.dChi, host.chi_mls));
     HIPCHK(upload(&st.dG, host.gdesc));
     HIPCHK(lw_upload_constants(LWREF_PREFLOG, LWREF_TREF));
+    HIPCHK(lw_upload_segments(host.gdesc.data()));
     HIPCHK(lw_upload_retab());
     {
         std::vector<double> cld((size_t)2 * LW_NBND * 58);

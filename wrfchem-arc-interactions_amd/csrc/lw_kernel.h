@@ -50,6 +50,7 @@ inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_
 size_t lw_gas_lds_bytes(int nlayers);
 size_t lw_rt_lds_bytes(int nlayers, bool cloud = true);
 hipError_t lw_upload_constants(const double *preflog, const double *tref);
+hipError_t lw_upload_segments(const LwGDesc *gdesc);   // [LW_NGPT] host descriptors
 // runs ncol columns in batches of at most cap_cols through the two kernels; `scratch` holds
 // cap_cols * lw_scratch_doubles(nlayers) doubles
 hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream);

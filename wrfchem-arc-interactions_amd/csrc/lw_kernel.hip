@@ -15,6 +15,8 @@
 // layer optics (no per-lane profile store); level fluxes are wave reductions.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "lw_common.h"
 #include "lw_kernel.h"
 #include "sw_kernel.h"   // KISS_JUMP_WORDS
@@ -242,315 +244,152 @@ __device__ __forceinline__ void spec_idx(double cola, double ratio, double colb,
     f = specmult - (double)j;
 }
 
-struct LaneL {
-    int ng, off_self, off_for;
+// Band descriptors for the gas-optics segments: entry ib is the LwGDesc of the band's FIRST g-point (offsets of
+// g-point ig are + ig), read with a wave-uniform index, i.e. into scalar registers; c_lwseg_order lists the 32
+// (band, regime) segments (2 ib + upper), costliest first.
+__constant__ LwGDesc c_lwband[LW_NBND];
+__constant__ int c_lwband_g0[LW_NBND];
+__constant__ int c_lwseg_order[2 * LW_NBND];
+
+// what differs between the g-points of a band besides the table column
+struct LaneG {
+    int ig;
+    double fracconst, halo0, halo1, postscale;
 };
 
-// gaseous optical depth and Planck fraction of NLY layers (same regime) for this lane's g-point.  Every step is
-// taken for all NLY layers before the next one, so that the table reads of the layers are in flight together: the
-// kernel waits on dependent gathers (LDS -> index arithmetic -> table rows -> sums), and two layers side by side
-// double the reads outstanding per wave.
-template <int NLY>
-__device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol &c, const LwRegime &R,
-                                           const LaneL &L, const int (&ks)[NLY], double (&taug)[NLY], double (&frac)[NLY])
+// gaseous optical depth and Planck fraction of layer k for this lane's g-point: the 16 taugbNN routines
+// (LW:4712-7828) as one data-driven expression.  R is the regime of the wave's band -- the same for every lane, so
+// every feature test (binary species, edge stencils, continua, each minor species, Planck fraction mode) is a
+// scalar branch and no lane pays for another band's terms.  The kernel waits on dependent gathers (LDS -> index
+// arithmetic -> table rows -> sums), so the item is written in two passes: first every index is formed and every
+// table read issued (up to 30 gathers in flight), then the sums are taken in the reference's order.
+__device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
+                                           const int off_self, const int off_for, const LaneG &G, const int k,
+                                           double &taug, double &frac)
 {
     const uint32_t cf = R.cfg;
-    const int nl = c.nl, ng = L.ng;
+    const int nl = c.nl, ig = G.ig;
     const int type = (cf >> LC_TYPE_SHIFT) & 3;
     const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
     const int nsp = (cf >> LC_NSP_SHIFT) & 15;
     const bool binary = type == 2, edges = cf & LC_EDGES;
     const double mult = (cf & LC_MULT4) ? 4. : 8.;
     const int ts = (binary ? nsp : 1) * ng;
-    double colA[NLY], colB[NLY], tau[NLY];
+    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
+    // ---- pass 1: indices and table reads ----
+    double sc[2] = {colA, colA}, wm1[2] = {0., 0.}, w0[2] = {1., 1.}, w1[2] = {0., 0.}, w2[2] = {0., 0.};
+    double v[2][4] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}}, e[2][4] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}};
+    const double *Kp[2] = {tb.K, tb.K};
+    if (type != 0) {
 #pragma unroll
-    for (int q = 0; q < NLY; ++q) { colA[q] = c.mul[spa * nl + ks[q]]; colB[q] = c.mul[spb * nl + ks[q]]; tau[q] = 0.; }
-    double maj[NLY][2], sc[NLY][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        double wm1[NLY], w0[NLY], w1[NLY], w2[NLY], fTa[NLY], fTb[NLY];
-        const double *Kp[NLY];
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) {
-            const int k = ks[q];
-            double speccomb, specparm, fs;
-            int jsi;
-            spec_idx(colA[q], c.rat[(rs * 2 + m) * nl + k], colB[q], mult, tb.oneminus, speccomb, specparm, jsi, fs);
-            wm1[q] = 0.; w0[q] = 1. - fs; w1[q] = fs; w2[q] = 0.;
-            if (edges) {   // LW:5231-5290
-                const bool lo = specparm < 0.125, hi = specparm > 0.875;
-                double p = lo ? fs - 1 : -fs;
-                double p4 = (p * p) * (p * p);
-                double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-                wm1[q] = hi ? fk2 : 0.;
-                w0[q] = lo ? fk0 : (hi ? fk1 : w0[q]);
-                w1[q] = lo ? fk1 : (hi ? fk0 : w1[q]);
-                w2[q] = lo ? fk2 : 0.;
+        for (int m = 0; m < 2; ++m) {
+            int jsi = 0;
+            if (binary) {
+                double specparm, fs;
+                spec_idx(colA, c.rat[(rs * 2 + m) * nl + k], colB, mult, tb.oneminus, sc[m], specparm, jsi, fs);
+                w0[m] = 1. - fs; w1[m] = fs;
+                if (edges) {   // LW:5231-5290
+                    const bool lo = specparm < 0.125, hi = specparm > 0.875;
+                    double p = lo ? fs - 1 : -fs;
+                    double p4 = (p * p) * (p * p);
+                    double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+                    wm1[m] = hi ? fk2 : 0.;
+                    w0[m] = lo ? fk0 : (hi ? fk1 : w0[m]);
+                    w1[m] = lo ? fk1 : (hi ? fk0 : w1[m]);
+                    w2[m] = lo ? fk2 : 0.;
+                }
             }
-            if (!binary) { wm1[q] = 0.; w0[q] = 1.; w1[q] = 0.; w2[q] = 0.; jsi = 0; speccomb = colA[q]; }
             const int rb = m == 0 ? c.rb0[k] : c.rb1[k];
-#ifdef LW_EXP_ROW0
-            Kp[q] = tb.K + R.off_major + (size_t)(0 * rb * nsp + jsi) * ng;
-#else
-            Kp[q] = tb.K + R.off_major + (size_t)(rb * nsp + jsi) * ng;
-#endif
-            fTa[q] = m == 0 ? c.fac00[k] : c.fac01[k];
-            fTb[q] = m == 0 ? c.fac10[k] : c.fac11[k];
-            sc[q][m] = speccomb;
+            Kp[m] = tb.K + R.off_major + ig + (size_t)(rb * nsp + jsi) * ng;
+            v[m][0] = Kp[m][0]; v[m][1] = Kp[m][ng]; v[m][2] = Kp[m][ts]; v[m][3] = Kp[m][ts + ng];
         }
-        double v[NLY][4];
-#pragma unroll
-#ifdef LW_EXP_HALF
-        for (int q = 0; q < NLY; ++q) { v[q][0] = Kp[q][0]; v[q][1] = v[q][0]; v[q][2] = Kp[q][ts]; v[q][3] = v[q][2]; }
-#else
-        for (int q = 0; q < NLY; ++q) { v[q][0] = Kp[q][0]; v[q][1] = Kp[q][ng]; v[q][2] = Kp[q][ts]; v[q][3] = Kp[q][ts + ng]; }
-#endif
-        // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
-        // their weights are exact zeros and the products drop out
-        double e[NLY][4];
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) {
-            e[q][0] = e[q][1] = e[q][2] = e[q][3] = 0.;
-            if (wm1[q] != 0.) { e[q][0] = Kp[q][-ng]; e[q][1] = Kp[q][ts - ng]; }
-            if (w2[q] != 0.) { e[q][2] = Kp[q][2 * ng]; e[q][3] = Kp[q][ts + 2 * ng]; }
-        }
-#pragma unroll
-        for (int q = 0; q < NLY; ++q)
-            maj[q][m] = (wm1[q] * fTa[q]) * e[q][0] + (w0[q] * fTa[q]) * v[q][0] + (w1[q] * fTa[q]) * v[q][1] +
-                        (w2[q] * fTa[q]) * e[q][2] + (wm1[q] * fTb[q]) * e[q][1] + (w0[q] * fTb[q]) * v[q][2] +
-                        (w1[q] * fTb[q]) * v[q][3] + (w2[q] * fTb[q]) * e[q][3];
     }
+    double s0 = 0., s1 = 0., f0 = 0., f1 = 0.;
+    if (cf & (LC_SELF | LC_FOR)) {
+        const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
+        f0 = Ff[0]; f1 = Ff[ng];
+        if (cf & LC_SELF) {
+            const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
+            s0 = Sf[0]; s1 = Sf[ng];
+        }
+    }
+    double ma0[3], ma1[3], mb0[3], mb1[3], fm[3];
 #pragma unroll
-    for (int q = 0; q < NLY; ++q) {
-        if (type == 2) tau[q] = sc[q][0] * maj[q][0] + sc[q][1] * maj[q][1];
-        else if (type == 1) tau[q] = colA[q] * (maj[q][0] + maj[q][1]);
+    for (int m = 0; m < 3; ++m) {
+        const LwMinor &M = R.minor[m];
+        ma0[m] = ma1[m] = mb0[m] = mb1[m] = fm[m] = 0.;
+        if (M.slot != LS_ZERO) {
+            const int tm = M.nsp * ng;
+            int jm = 0;
+            if (M.nsp > 1) {
+                double scb, spp;
+                spec_idx(colA, M.refrat, colB, mult, tb.oneminus, scb, spp, jm, fm[m]);
+            }
+            const double *Km = tb.K + M.off + ig + (size_t)(c.indm[k] * M.nsp + jm) * ng;
+            ma0[m] = Km[0]; ma1[m] = Km[ng]; mb0[m] = Km[tm]; mb1[m] = Km[tm + ng];
+        }
+    }
+    double fr0 = 0., fr1 = 0., fpl = 0.;
+    if (fmode == 2) {   // LW:5354-5355
+        double scb, spp;
+        int jpl;
+        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
+        const double *Fp = tb.K + R.off_frac + ig + (size_t)jpl * ng;
+        fr0 = Fp[0]; fr1 = Fp[ng];
+    }
+    // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere their
+    // weights are exact zeros and the products drop out
+    if (edges) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (wm1[m] != 0.) { e[m][0] = Kp[m][-ng]; e[m][1] = Kp[m][ts - ng]; }
+            if (w2[m] != 0.) { e[m][2] = Kp[m][2 * ng]; e[m][3] = Kp[m][ts + 2 * ng]; }
+        }
+    }
+    // ---- pass 2: sums ----
+    double tau = 0.;
+    if (type != 0) {
+        double maj[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const double fTa = m == 0 ? c.fac00[k] : c.fac01[k], fTb = m == 0 ? c.fac10[k] : c.fac11[k];
+            maj[m] = (wm1[m] * fTa) * e[m][0] + (w0[m] * fTa) * v[m][0] + (w1[m] * fTa) * v[m][1] + (w2[m] * fTa) * e[m][2] +
+                     (wm1[m] * fTb) * e[m][1] + (w0[m] * fTb) * v[m][2] + (w1[m] * fTb) * v[m][3] + (w2[m] * fTb) * e[m][3];
+        }
+        if (type == 2) tau = sc[0] * maj[0] + sc[1] * maj[1];
+        else tau = colA * (maj[0] + maj[1]);
     }
     // continua (selffac / forfac already carry colh2o, LW:3806-3807)
     if (cf & (LC_SELF | LC_FOR)) {
-        double s0[NLY], s1[NLY], f0[NLY], f1[NLY];
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) {
-            const double *Sf = tb.K + L.off_self + (size_t)c.inds[ks[q]] * ng;
-            const double *Ff = tb.K + L.off_for + (size_t)c.indf[ks[q]] * ng;
-#ifdef LW_EXP_HALF
-            s0[q] = Sf[0]; s1[q] = s0[q]; f0[q] = Ff[0]; f1[q] = f0[q];
-#else
-            s0[q] = Sf[0]; s1[q] = Sf[ng]; f0[q] = Ff[0]; f1[q] = Ff[ng];
-#endif
-        }
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) {
-            const int k = ks[q];
-            double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0[q] + c.selffrac[k] * (s1[q] - s0[q])) : 0.;
-            double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0[q] + c.forfrac[k] * (f1[q] - f0[q])) : 0.;
-            tau[q] = tau[q] + tauself + taufor;
-        }
+        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
+        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
+        tau = tau + tauself + taufor;
     }
     // minor species, e.g. LW:5297-5301, 5877-5878
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
-        if (__any(M.slot != LS_ZERO)) {
-            double a0[NLY], a1[NLY], b0[NLY], b1[NLY], fm[NLY];
-            const int tm = M.nsp * ng;
-#pragma unroll
-            for (int q = 0; q < NLY; ++q) {
-                int jm = 0;
-                fm[q] = 0.;
-                if (M.nsp > 1) {
-                    double scb, spp;
-                    spec_idx(colA[q], M.refrat, colB[q], mult, tb.oneminus, scb, spp, jm, fm[q]);
-                }
-#ifdef LW_EXP_ROW0
-                const double *Kp = tb.K + M.off + (size_t)(0 * c.indm[ks[q]] * M.nsp + jm) * ng;
-#else
-                const double *Kp = tb.K + M.off + (size_t)(c.indm[ks[q]] * M.nsp + jm) * ng;
-#endif
-#ifdef LW_EXP_HALF
-                a0[q] = Kp[0]; a1[q] = a0[q]; b0[q] = Kp[tm]; b1[q] = b0[q];
-#else
-                a0[q] = Kp[0]; a1[q] = Kp[ng]; b0[q] = Kp[tm]; b1[q] = Kp[tm + ng];
-#endif
-            }
-#pragma unroll
-            for (int q = 0; q < NLY; ++q) {
-                const double m1 = a0[q] + fm[q] * (a1[q] - a0[q]);
-                const double m2 = b0[q] + fm[q] * (b1[q] - b0[q]);
-                const double absm = m1 + c.minorfrac[ks[q]] * (m2 - m1);
-                tau[q] = tau[q] + c.mul[M.slot * nl + ks[q]] * absm;
-            }
+        if (M.slot != LS_ZERO) {
+            const double m1 = ma0[m] + fm[m] * (ma1[m] - ma0[m]);
+            const double m2 = mb0[m] + fm[m] * (mb1[m] - mb0[m]);
+            const double absm = m1 + c.minorfrac[k] * (m2 - m1);
+            tau = tau + c.mul[M.slot * nl + k] * absm;
         }
     }
-    const int corr = (cf >> LC_CORR_SHIFT) & 3;
-    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
-    double fr[NLY];
-#pragma unroll
-    for (int q = 0; q < NLY; ++q) fr[q] = fmode == 1 ? R.fracconst : 0.;
-    if (fmode == 2) {   // LW:5354-5355
-        double f0[NLY], f1[NLY], fpl[NLY];
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) {
-            double scb, spp;
-            int jpl;
-            spec_idx(colA[q], R.planck_ratio, colB[q], mult, tb.oneminus, scb, spp, jpl, fpl[q]);
-            const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
-            f0[q] = Fp[0]; f1[q] = Fp[ng];
-        }
-#pragma unroll
-        for (int q = 0; q < NLY; ++q) fr[q] = f0[q] + fpl[q] * (f1[q] - f0[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < NLY; ++q) {
-        const int k = ks[q];
-        double t = tau[q] + c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
-        // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
-        if (corr) {
-            const double pp = c.pavel[k];
-            double corradj = 1.;
-            if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
-            else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
-            else corradj = 1. - .05 * (pp - 100.) / 900.;
-            t = corradj * t;
-        }
-        taug[q] = t * R.postscale;
-        frac[q] = fr[q];
-    }
-}
-
-// gaseous optical depth and Planck fraction of layer k for this lane's g-point: the 16 taugbNN routines
-// (LW:4712-7828) as one data-driven expression WITHOUT control flow in front of the table reads.  The kernel is not
-// short of cache bandwidth (reading every table at its first row changes nothing) but of parallelism in one wave:
-// with a branch per feature (continua, each minor species, the Planck fraction) the compiler keeps each feature's
-// "LDS read -> index arithmetic -> gather -> use" chain behind the previous one, five dependent memory round trips
-// per layer at three waves per SIMD.  Here every index is formed first and all 26 gathers go out together; features a
-// g-point does not have read the zero pad (descriptor offsets point there) or carry a zero weight / multiplier, so
-// their terms are exact zeros.  Only the outer points of the 3-point edge stencils (LW:5231-5290) keep a branch,
-// taken by the few lanes that sit on an edge, behind the gathers.
-__device__ __forceinline__ void gas_optics_flat(const LwDeviceTables &tb, const LCol &c, const LwRegime &R,
-                                                const LaneL &L, const int k, double &taug, double &frac)
-{
-    const uint32_t cf = R.cfg;
-    const int nl = c.nl, ng = L.ng;
-    const int type = (cf >> LC_TYPE_SHIFT) & 3;
-    const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
-    const int nsp = (cf >> LC_NSP_SHIFT) & 15;
-    const bool binary = type == 2, edges = cf & LC_EDGES;
-    const double mult = (cf & LC_MULT4) ? 4. : 8.;
-    const int ts = (binary ? nsp : 1) * ng;
-    // ---- everything the layer contributes (LDS) ----
-    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
-    const double rat0 = c.rat[(rs * 2 + 0) * nl + k], rat1 = c.rat[(rs * 2 + 1) * nl + k];
-    const double f00 = c.fac00[k], f10 = c.fac10[k], f01 = c.fac01[k], f11 = c.fac11[k];
-    const int rb0 = c.rb0[k], rb1 = c.rb1[k], inds = c.inds[k], indf = c.indf[k], im = c.indm[k];
-    const double selffac = c.selffac[k], selffrac = c.selffrac[k], forfac = c.forfac[k], forfrac = c.forfrac[k];
-    const double mf = c.minorfrac[k];
-    const double mm0 = c.mul[R.minor[0].slot * nl + k], mm1 = c.mul[R.minor[1].slot * nl + k],
-                 mm2 = c.mul[R.minor[2].slot * nl + k];
-    const double halo = c.mul[R.halo_slot[0] * nl + k] * R.halo_coef[0] + c.mul[R.halo_slot[1] * nl + k] * R.halo_coef[1];
-    const double pp = c.pavel[k];
-    // ---- indices: major species at the two reference pressures, the minors, the Planck fraction ----
-    double sc[2], wm1[2], w0[2], w1[2], w2[2];
-    int js[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        double speccomb, specparm, fs;
-        int jsi;
-        spec_idx(colA, m == 0 ? rat0 : rat1, colB, mult, tb.oneminus, speccomb, specparm, jsi, fs);
-        wm1[m] = 0.; w0[m] = 1. - fs; w1[m] = fs; w2[m] = 0.;
-        {   // LW:5231-5290 (weights only; selected below)
-            const bool lo = specparm < 0.125, hi = specparm > 0.875;
-            const double p = lo ? fs - 1 : -fs;
-            const double p4 = (p * p) * (p * p);
-            const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-            const double e_m1 = hi ? fk2 : 0., e_0 = lo ? fk0 : (hi ? fk1 : w0[m]), e_1 = lo ? fk1 : (hi ? fk0 : w1[m]),
-                         e_2 = lo ? fk2 : 0.;
-            wm1[m] = edges ? e_m1 : 0.; w0[m] = edges ? e_0 : w0[m]; w1[m] = edges ? e_1 : w1[m]; w2[m] = edges ? e_2 : 0.;
-        }
-        wm1[m] = binary ? wm1[m] : 0.; w0[m] = binary ? w0[m] : 1.; w1[m] = binary ? w1[m] : 0.; w2[m] = binary ? w2[m] : 0.;
-        js[m] = binary ? jsi : 0;
-        sc[m] = binary ? speccomb : colA;
-    }
-    int jm[3];
-    double fm[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        double scb, spp, f;
-        int j;
-        spec_idx(colA, R.minor[m].refrat, colB, mult, tb.oneminus, scb, spp, j, f);
-        const bool many = R.minor[m].nsp > 1;
-        jm[m] = many ? j : 0;
-        fm[m] = many ? f : 0.;
-    }
-    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
-    int jpl;
-    double fpl;
-    {
-        double scb, spp;
-        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
-        jpl = fmode == 2 ? jpl : 0;
-    }
-    // ---- all table reads ----
-    const double *Ka = tb.K + R.off_major + (size_t)(rb0 * nsp + js[0]) * ng;
-    const double *Kb = tb.K + R.off_major + (size_t)(rb1 * nsp + js[1]) * ng;
-    const double *Sf = tb.K + L.off_self + (size_t)inds * ng, *Ff = tb.K + L.off_for + (size_t)indf * ng;
-    const double *M0 = tb.K + R.minor[0].off + (size_t)(im * R.minor[0].nsp + jm[0]) * ng;
-    const double *M1 = tb.K + R.minor[1].off + (size_t)(im * R.minor[1].nsp + jm[1]) * ng;
-    const double *M2 = tb.K + R.minor[2].off + (size_t)(im * R.minor[2].nsp + jm[2]) * ng;
-    const double *Fp = tb.K + R.off_frac + (size_t)jpl * ng;
-    const int t0 = R.minor[0].nsp * ng, t1 = R.minor[1].nsp * ng, t2 = R.minor[2].nsp * ng;
-    const double a00 = Ka[0], a01 = Ka[ng], a10 = Ka[ts], a11 = Ka[ts + ng];
-    const double b00 = Kb[0], b01 = Kb[ng], b10 = Kb[ts], b11 = Kb[ts + ng];
-    const double s0 = Sf[0], s1 = Sf[ng], fo0 = Ff[0], fo1 = Ff[ng];
-    const double m0a0 = M0[0], m0a1 = M0[ng], m0b0 = M0[t0], m0b1 = M0[t0 + ng];
-    const double m1a0 = M1[0], m1a1 = M1[ng], m1b0 = M1[t1], m1b1 = M1[t1 + ng];
-    const double m2a0 = M2[0], m2a1 = M2[ng], m2b0 = M2[t2], m2b1 = M2[t2 + ng];
-    const double fr0 = Fp[0], fr1 = Fp[ng];
-    // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere
-    // their weights are exact zeros and the products drop out
-    double ea[4] = {0., 0., 0., 0.}, eb[4] = {0., 0., 0., 0.};
-    if (wm1[0] != 0.) { ea[0] = Ka[-ng]; ea[1] = Ka[ts - ng]; }
-    if (w2[0] != 0.) { ea[2] = Ka[2 * ng]; ea[3] = Ka[ts + 2 * ng]; }
-    if (wm1[1] != 0.) { eb[0] = Kb[-ng]; eb[1] = Kb[ts - ng]; }
-    if (w2[1] != 0.) { eb[2] = Kb[2 * ng]; eb[3] = Kb[ts + 2 * ng]; }
-    // ---- sums ----
-    const double maj0 = (wm1[0] * f00) * ea[0] + (w0[0] * f00) * a00 + (w1[0] * f00) * a01 + (w2[0] * f00) * ea[2] +
-                        (wm1[0] * f10) * ea[1] + (w0[0] * f10) * a10 + (w1[0] * f10) * a11 + (w2[0] * f10) * ea[3];
-    const double maj1 = (wm1[1] * f01) * eb[0] + (w0[1] * f01) * b00 + (w1[1] * f01) * b01 + (w2[1] * f01) * eb[2] +
-                        (wm1[1] * f11) * eb[1] + (w0[1] * f11) * b10 + (w1[1] * f11) * b11 + (w2[1] * f11) * eb[3];
-    double tau = 0.;
-    {
-        const double t2s = sc[0] * maj0 + sc[1] * maj1, t1s = colA * (maj0 + maj1);
-        tau = type == 2 ? t2s : (type == 1 ? t1s : 0.);
-    }
-    {   // continua (selffac / forfac already carry colh2o, LW:3806-3807)
-        const double tauself = (cf & LC_SELF) ? selffac * (s0 + selffrac * (s1 - s0)) : 0.;
-        const double taufor = (cf & LC_FOR) ? forfac * (fo0 + forfrac * (fo1 - fo0)) : 0.;
-        tau = (cf & (LC_SELF | LC_FOR)) ? tau + tauself + taufor : tau;
-    }
-    {   // minor species, e.g. LW:5297-5301, 5877-5878 (an absent one multiplies the zero column)
-        const double x1 = m0a0 + fm[0] * (m0a1 - m0a0), x2 = m0b0 + fm[0] * (m0b1 - m0b0);
-        const double y1 = m1a0 + fm[1] * (m1a1 - m1a0), y2 = m1b0 + fm[1] * (m1b1 - m1b0);
-        const double z1 = m2a0 + fm[2] * (m2a1 - m2a0), z2 = m2b0 + fm[2] * (m2b1 - m2b0);
-        const double add0 = mm0 * (x1 + mf * (x2 - x1)), add1 = mm1 * (y1 + mf * (y2 - y1)),
-                     add2 = mm2 * (z1 + mf * (z2 - z1));
-        // the reference adds only the minors a band has: keep the order and skip exact zeros of absent ones
-        tau = R.minor[0].slot != LS_ZERO ? tau + add0 : tau;
-        tau = R.minor[1].slot != LS_ZERO ? tau + add1 : tau;
-        tau = R.minor[2].slot != LS_ZERO ? tau + add2 : tau;
-    }
-    tau = tau + halo;
+    double t = tau + c.mul[R.halo_slot[0] * nl + k] * G.halo0 + c.mul[R.halo_slot[1] * nl + k] * G.halo1;
     // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
     const int corr = (cf >> LC_CORR_SHIFT) & 3;
-    {
-        const double c1 = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
-        const double c2 = 1. - 0.15 * (pp / 95.6);
-        const double c3 = 1. - .05 * (pp - 100.) / 900.;
-        const double corradj = corr == 1 ? c1 : (corr == 2 ? c2 : c3);
-        tau = corr ? corradj * tau : tau;
+    if (corr) {
+        const double pp = c.pavel[k];
+        double corradj = 1.;
+        if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
+        else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
+        else corradj = 1. - .05 * (pp - 100.) / 900.;
+        t = corradj * t;
     }
-    taug = tau * R.postscale;
-    const double fri = fr0 + fpl * (fr1 - fr0);
-    frac = fmode == 2 ? fri : (fmode == 1 ? R.fracconst : 0.);
+    taug = t * G.postscale;
+    frac = fmode == 2 ? fr0 + fpl * (fr1 - fr0) : (fmode == 1 ? G.fracconst : 0.);
 }
 
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
@@ -778,8 +617,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
 #else
 #define LW_STAMP(i)
 #endif
-    __shared__ int s_laytrop;
-    if (tid == 0) s_laytrop = 0;
+    __shared__ int s_laytrop, s_nextseg;
+    if (tid == 0) { s_laytrop = 0; s_nextseg = 0; }
     LW_STAMP(0);
     if (wave == 0) {
         for (int l = lane; l <= nl; l += 64) {
@@ -1158,46 +997,51 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 1) + l] = c.pz[l];
 
     LW_STAMP(5);
-    // ======================= gas optics: lanes = g-points, loop over layers =======================
-    const int gbeg = wave * LW_CHUNK;
-    const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
-    const bool active = lane < gcnt;
-    const int g = gbeg + (active ? lane : gcnt - 1);
-    const LwGDesc *gd = tb.gdesc + g;
-    LaneL L;
-    L.ng = gd->stride; L.off_self = gd->off_self; L.off_for = gd->off_for;   // row stride (padded ng)
-    double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
-    // one layer at a time (two layers side by side, gas_optics<2>, need more registers than three waves per SIMD
-    // leave: 492 bytes of spills per lane, 2.4x slower; batching the stores of four layers changes nothing)
-    auto run = [&](const LwRegime &R, int kbeg, int kend) {
-        for (int k = kbeg; k < kend; ++k) {
-            const int ks[1] = {k};
-            double taug[1], plfrac[1];
-            gas_optics<1>(tb, c, R, L, ks, taug, plfrac);
-            if (active) { tg[(size_t)k * LW_NGPT] = taug[0]; fr[(size_t)k * LW_NGPT] = plfrac[0]; }
+    // ======================= gas optics: (band, regime) segments; lanes = (layer, g-point) =======================
+    // A wave takes one segment at a time off the column's list (LDS counter; costliest first) and lays lpi = 64 / ng
+    // layers x the band's ng g-points over its lanes: the regime is the same for all of them (scalar registers,
+    // scalar branches) and 56 to 64 lanes work, where a fixed g-point per lane left 47 of 64 busy and made every
+    // lane sit through the terms of every band in its wave.
+    double *tg = a.taug + (size_t)slot * nl * LW_NGPT, *fr = a.frac + (size_t)slot * nl * LW_NGPT;
+    for (;;) {
+        int seg = 0;
+        if (lane == 0) seg = atomicAdd(&s_nextseg, 1);
+        seg = __builtin_amdgcn_readfirstlane(seg);
+        if (seg >= 2 * LW_NBND) break;
+        const int sid = c_lwseg_order[seg];
+        const int ib = sid >> 1, upper = sid & 1;
+        const int kbeg = upper ? ltrop : 0, kend = upper ? nl : ltrop;
+        if (kbeg >= kend) continue;
+        const LwGDesc &B = c_lwband[ib];
+        const LwRegime &R = upper ? B.up : B.lo;
+        const int ng = B.ng, g0 = c_lwband_g0[ib];
+        const int lpi = 64 / ng;
+        const int dk = lane / ng;
+        LaneG G;
+        G.ig = lane - dk * ng;
+        {
+            const LwGDesc *gd = tb.gdesc + g0 + G.ig;
+            const LwRegime *rg = upper ? &gd->up : &gd->lo;
+            G.fracconst = rg->fracconst; G.halo0 = rg->halo_coef[0]; G.halo1 = rg->halo_coef[1]; G.postscale = rg->postscale;
         }
-    };
-#ifdef LW_EXP_NOGAS
-    if (ltrop > 100000)
-#endif
-    {
-        const LwRegime R = gd->lo;
-        run(R, 0, ltrop);
-    }
-#ifdef LW_EXP_NOGAS
-    if (ltrop > 100000)
-#endif
-    {
-        LW_STAMP(6);
-        const LwRegime R = gd->up;
-        run(R, ltrop, nl);
+        const bool lane_on = dk < lpi;
+        for (int kb = kbeg; kb < kend; kb += lpi) {
+            const bool act = lane_on && kb + dk < kend;
+            const int k = act ? kb + dk : kend - 1;
+            double taug, plfrac;
+            gas_optics(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
+            if (act) {
+                tg[(size_t)k * LW_NGPT + g0 + G.ig] = taug;
+                fr[(size_t)k * LW_NGPT + g0 + G.ig] = plfrac;
+            }
+        }
     }
 #ifdef LW_EXP_CLOCK
-    LW_STAMP(7);
+    LW_STAMP(6);
     if ((blockIdx.x == 5 || blockIdx.x == 3000 || blockIdx.x == 20000) && lane == 0)
-        printf("blk %d wave %d: A %lld bar %lld B %lld bar %lld C %lld gaslo %lld gasup %lld (ltrop %d nl %d)\n", blockIdx.x, wave,
+        printf("blk %d wave %d: A %lld bar %lld B %lld bar %lld C %lld gas %lld (ltrop %d nl %d)\n", blockIdx.x, wave,
                tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3],
-               tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], ltrop, nl);
+               tstamp[5] - tstamp[4], tstamp[6] - tstamp[5], ltrop, nl);
 #endif
 }
 
@@ -1706,6 +1550,43 @@ size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
     if (!cloud) return (lw_rec_base_doubles(nl) + (size_t)3 * 4 * (nl + 1)) * sizeof(double);
     return (lw_rec_doubles(nl) + (size_t)3 * 6 * (nl + 1)) * sizeof(double);
+}
+
+// band descriptors and the order of the gas-optics segments (see lw_gas_kernel)
+hipError_t lw_upload_segments(const LwGDesc *gdesc)
+{
+    LwGDesc band[LW_NBND];
+    int g0[LW_NBND], order[2 * LW_NBND];
+    double cost[2 * LW_NBND];
+    int g = 0;
+    for (int ib = 0; ib < LW_NBND; ++ib) {
+        if (g >= LW_NGPT || gdesc[g].band != ib || gdesc[g].ig != 0) return hipErrorInvalidValue;
+        band[ib] = gdesc[g];
+        g0[ib] = g;
+        const int ng = gdesc[g].ng, lpi = 64 / ng;
+        for (int up = 0; up < 2; ++up) {
+            // rough relative cost: blocks of a 2:1 lower / upper split x the table reads of one item
+            const LwRegime &R = up ? gdesc[g].up : gdesc[g].lo;
+            const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
+            double w = 1. + (type == 2 ? 10. : (type == 1 ? 8. : 0.));
+            if (R.cfg & LC_EDGES) w += 3.;
+            if (R.cfg & LC_SELF) w += 2.;
+            if (R.cfg & LC_FOR) w += 2.;
+            for (int m = 0; m < 3; ++m)
+                if (R.minor[m].slot != LS_ZERO) w += R.minor[m].nsp > 1 ? 6. : 4.;
+            if (((R.cfg >> LC_FRAC_SHIFT) & 3) == 2) w += 4.;
+            const int layers = up ? 20 : 40;
+            cost[2 * ib + up] = w * ((layers + lpi - 1) / lpi);
+            order[2 * ib + up] = 2 * ib + up;
+        }
+        g += ng;
+    }
+    if (g != LW_NGPT) return hipErrorInvalidValue;
+    std::stable_sort(order, order + 2 * LW_NBND, [&](int x, int y) { return cost[x] > cost[y]; });
+    hipError_t e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lwband), band, sizeof band)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lwband_g0), g0, sizeof g0)) != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_lwseg_order), order, sizeof order);
 }
 
 hipError_t lw_upload_constants(const double *preflog, const double *tref)
