@@ -61,6 +61,28 @@ def test_optics_tile_subset_and_host_mode(hip_lib, wa):
         np.testing.assert_array_equal(a[n], b[n], err_msg=n)
 
 
+def test_optics_giant_wet_particles(hip_lib, wa):
+    """Coarse sections swollen with water: size parameters from ~100 through the segment limit of the shortwave
+    kernel (12 checkpoints x 16 terms per downward pass, nstop > 192 takes a second pass) up to the cap of 225, in
+    every cell of a few columns so that whole waves and mixed waves both occur."""
+    _init(wa, 8)
+    st = wa.synth.make_wrf_state(7, 5, 14, seed=20260350)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260351)
+    names = ms.names
+    rng = np.random.default_rng(20260352)
+    for b in (7, 8):
+        w = names.index(f"water_a{b:02d}")
+        # wet / dry volume ratios of 3 .. 80: wet diameters of the 10 um section up to 40 um
+        factor = 10.0 ** rng.uniform(0.5, 2.6, size=ms.chem[w].shape)
+        factor[:, :, ::3] = 1.0                      # leave every third column as it was
+        ms.chem[w] *= factor
+    got = run_hip_optics(wa, st, ms)
+    ref = run_oracle_optics(wa, st, ms)
+    mask = tile_mask(st, ms.alt.shape)
+    _compare(got, ref, mask, RTOL)
+    assert got["tauaer1"][mask].max() > 1e-3
+
+
 def test_optics_real4_state(hip_lib, wa):
     _init(wa, 4)
     st = wa.synth.make_wrf_state(6, 4, 24, seed=20260330)

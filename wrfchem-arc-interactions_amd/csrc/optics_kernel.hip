@@ -87,8 +87,12 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
 // scratch traffic per 1.6 M cells).  Here the downward pass keeps only every OPT_MB-th D_n in LDS
 // (ck[j][thread]); the upward pass rebuilds each block of OPT_MB values from its checkpoint in registers
 // (statically indexed) and consumes them.  D_n is recomputed once; nothing goes to scratch.
-constexpr int OPT_MB = 16;
-constexpr int OPT_NCK = (OPT_NMIE + OPT_MB - 1) / OPT_MB;   // 16 checkpoints cover nstop <= 256
+constexpr int OPT_MB = 16, OPT_RB = 8;   // checkpoint spacing, register block
+// Checkpoints per thread: 12 cover a pass of 192 terms (size parameters up to ~165: a 15 um particle at 0.3 um);
+// beyond, the series is taken in segments of OPT_NCK * OPT_MB terms with one more downward pass each (mie_sphere).  12 slots and
+// the 8-value register block are what lets three waves per SIMD run (LDS: 6 workgroups x 24 KB per CU).
+constexpr int OPT_NCK = 12;
+
 
 struct MieAcc {
     double psi0, psi1, chi0, chi1, qs, qe, gs, sgn;
@@ -145,15 +149,6 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
     const double base = fmax(xstop, ymod);
     const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
     const cplx yinv = crecip(y);
-    cplx d = {0., 0.};
-    const int ntop = nck * OPT_MB;
-    for (int n = nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y)
-        const cplx ny = {(double)n * yinv.re, (double)n * yinv.im};
-        d = csub(ny, crecip(cadd(d, ny)));
-        const int n1 = n - 1;
-        if (n1 <= ntop && (n1 & (OPT_MB - 1)) == 0) ck[(size_t)(n1 / OPT_MB - 1) * OPT_THREADS] = make_double2(d.re, d.im);
-        if (n1 <= OPT_MB) break;       // the lowest block is rebuilt from its checkpoint below
-    }
     MieAcc A;
     sincos(x, &A.psi1, &A.psi0);
     A.chi0 = -A.psi1; A.chi1 = A.psi0;
@@ -161,21 +156,63 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
     A.an1 = {0., 0.}; A.bn1 = {0., 0.}; A.xb = {0., 0.};
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
-    for (int j = 0; j < nck; ++j) {
-        cplx dd[OPT_MB];
-        const double2 c = ck[(size_t)j * OPT_THREADS];
-        dd[OPT_MB - 1] = {c.x, c.y};                 // D_{MB (j+1)}
+    for (int seg = 0; seg < nck; seg += OPT_NCK) {   // once, unless the series is longer than OPT_NCK * OPT_MB terms
+    const int nseg = nck - seg < OPT_NCK ? nck - seg : OPT_NCK;
+    {
+        // downward pass from the start order to the segment's first block: D_{n-1} = n/y - 1/(D_n + n/y); the
+        // checkpoints D_{MB (seg + j)}, j = 1..nseg, stay in LDS
+        const int nlow = seg * OPT_MB, ntop = (seg + nseg) * OPT_MB;
+        cplx d = {0., 0.};
+        for (int n = nmx; n >= 2; --n) {
+            const cplx ny = {(double)n * yinv.re, (double)n * yinv.im};
+            d = csub(ny, crecip(cadd(d, ny)));
+            const int n1 = n - 1;
+            if (n1 <= ntop && (n1 & (OPT_MB - 1)) == 0) ck[(size_t)((n1 - nlow) / OPT_MB - 1) * OPT_THREADS] = make_double2(d.re, d.im);
+            if (n1 <= nlow + OPT_MB) break;       // the lowest block is rebuilt from its checkpoint below
+        }
+    }
+    for (int js = 0; js < nseg; ++js) {
+        const int j = seg + js;
+        // the block's 16 values of D_n are rebuilt from its checkpoint in two halves of OPT_RB (the register file
+        // holds 8 of them, not 16: a third wave per SIMD); the chain to the lower half passes through the upper one
+        // a second time -- the same operations on the same values
+        const double2 c = ck[(size_t)js * OPT_THREADS];
+        const int n0 = j * OPT_MB;
+        cplx dd[OPT_RB];
+        cplx d = {c.x, c.y};                          // D_{n0 + 16}
 #pragma unroll
-        for (int i = OPT_MB - 1; i >= 1; --i) {      // dd[i] = D_n with n = MB j + i + 1
-            const double en = (double)(j * OPT_MB + i + 1);
+        for (int i = OPT_MB; i > OPT_RB; --i) {       // down to D_{n0 + 8}
+            const double en = (double)(n0 + i);
+            const cplx ny = {en * yinv.re, en * yinv.im};
+            d = csub(ny, crecip(cadd(d, ny)));
+        }
+        dd[OPT_RB - 1] = d;
+#pragma unroll
+        for (int i = OPT_RB - 1; i >= 1; --i) {       // dd[i] = D_n with n = n0 + i + 1
+            const double en = (double)(n0 + i + 1);
             const cplx ny = {en * yinv.re, en * yinv.im};
             dd[i - 1] = csub(ny, crecip(cadd(dd[i], ny)));
         }
 #pragma unroll
-        for (int i = 0; i < OPT_MB; ++i) {
-            const int n = j * OPT_MB + i + 1;
+        for (int i = 0; i < OPT_RB; ++i) {
+            const int n = n0 + i + 1;
             if (n <= nstop) mie_term<FULL>(A, n, dd[i], m, minv, xinv);
         }
+        if (n0 + OPT_RB < nstop) {
+            dd[OPT_RB - 1] = {c.x, c.y};
+#pragma unroll
+            for (int i = OPT_RB - 1; i >= 1; --i) {   // dd[i] = D_n with n = n0 + 8 + i + 1
+                const double en = (double)(n0 + OPT_RB + i + 1);
+                const cplx ny = {en * yinv.re, en * yinv.im};
+                dd[i - 1] = csub(ny, crecip(cadd(dd[i], ny)));
+            }
+#pragma unroll
+            for (int i = 0; i < OPT_RB; ++i) {
+                const int n = n0 + OPT_RB + i + 1;
+                if (n <= nstop) mie_term<FULL>(A, n, dd[i], m, minv, xinv);
+            }
+        }
+    }
     }
     const double x2inv = xinv * xinv;
     qsca = 2. * x2inv * A.qs;
@@ -189,8 +226,8 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
 // leaves the SIMD waiting on its own results; two independent chains in one instruction stream fill those gaps.
 // Both start the downward recurrence at the larger of their two start orders (a higher start is only more
 // accurate), use register blocks of OPT_MB2 terms and the two halves of the thread's checkpoint column
-// (OPT_NCK/2 checkpoints each: nstop <= OPT_MB2*OPT_NCK/2 = 64, the caller checks).  Extinction and scattering only.
-constexpr int OPT_MB2 = 8, OPT_NCK2 = OPT_NCK / 2;
+// (OPT_NCK2 checkpoints each: nstop <= OPT_MB2*OPT_NCK2 = 64, the caller checks).  Extinction and scattering only.
+constexpr int OPT_MB2 = 8, OPT_NCK2 = 8;   // the longwave kernels keep 2 x 8 slots per thread
 constexpr double OPT_XMAX32 = 47.0;   // x + 4 x^(1/3) + 2 < 64 = OPT_MB2 * OPT_NCK2
 constexpr int OPT_NCK32 = OPT_NCK2 + OPT_NCK2 / 2;   // LDS slots per thread of the fp32 pair
 
@@ -929,7 +966,7 @@ __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, doub
     if (a.extaerlw[ib0 + 1]) str(a.extaerlw[ib0 + 1], q, r4, (double)(ab2 * 1.e5f));
 }
 
-__global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelArgs a)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
     optics_body<false>(a, s_ck);
@@ -938,7 +975,7 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_kernel(const OpticsKernelA
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 optics_lw_kernel(const OpticsKernelArgs a)
 {
-    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
+    __shared__ double2 s_ck[2 * OPT_NCK2 * OPT_THREADS];
     optics_body<true>(a, s_ck);
 }
 
