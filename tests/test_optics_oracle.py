@@ -139,3 +139,31 @@ def test_optics_abi_exports_and_refusal(wa):
             wa.engine_optics.optical_averaging(chem=ms.chem, alt=ms.alt, dz8w=ms.dz8w, idx=ms.idx, **dims, **out)
         with pytest.raises(wa.engine.WrfFatal, match="no HIP device"):
             wa.engine_optics.optics_init(4)
+
+
+def test_upward_recurrence_window(oo):
+    """The device carries the logarithmic derivative upward (D_0 = cot y) where x >= 1 and Im(m) x < 10
+    (csrc/optics_kernel.hip: mie_upward_ok); the oracle specifies the downward recurrence throughout.  Inside the
+    window the two agree far below the stage's tolerance of 1e-8; outside they do not (the window is needed)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes"))
+    from mie_updown import mie
+    rng = np.random.default_rng(20260420)
+    n = 6000
+    x = 10 ** rng.uniform(0.0, np.log10(225.0), n)
+    m = rng.uniform(1.1, 2.6, n) + 1j * 10 ** rng.uniform(-9, 0.0, n)
+    inside = m.imag * x < 10.0
+    with np.errstate(all="ignore"):
+        dn, up = mie(x, m, False), mie(x, m, True)
+    for a, b, tol in zip(dn, up, (1e-10, 1e-10, 1e-10, 1e-9)):
+        rel = np.abs(a - b)[inside] / np.maximum(np.abs(a[inside]), 1e-300)
+        assert rel.max() < tol
+    # the numpy downward series is the oracle's series (spot check), so the statement is about the oracle
+    for i in range(0, n, 997):
+        q = oo.mie(float(x[i]), complex(m[i]))
+        assert q[0] == pytest.approx(dn[0][i], rel=1e-11) and q[1] == pytest.approx(dn[1][i], rel=1e-11)
+    # strongly absorbing large particles: upward fails, the device keeps the downward path there
+    bad = m.imag * x > 40.0
+    rel = np.abs(dn[1] - up[1])[bad] / np.abs(dn[1][bad])
+    assert np.nanmax(np.where(np.isfinite(rel), rel, 1.0)) > 1e-6
