@@ -137,11 +137,11 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
 // Where the logarithmic derivative may be carried UPWARD with the series (Wiscombe's MIEV0 does the same under a
 // similar criterion): D_0 = cot y, D_n = 1 / (n/y - D_(n-1)) - n/y.  The upward recurrence loses accuracy when the
 // particle absorbs strongly (Im(m) x large) and at very small size parameters (cancellation in 1/y - cot y); inside
-// x >= 1, Im(m) x < 10 the efficiencies agree with the downward specification to 4e-12 (asymmetry 4e-12,
+// x >= 0.3, Im(m) x < 10 the efficiencies agree with the downward specification to 4e-12 (asymmetry 4e-12,
 // backscatter 6e-11; 60 000 random cases, x to 225, Re m 1.1..2.6, Im m 1e-9..1: tools/probes/mie_updown.py and
-// tests/test_optics_oracle.py).  It costs one recurrence step per term instead of the downward pass from the start
+// tests/test_optics_oracle.py; below x = 0.3 the difference grows like 1/x^2: 3e-10 at 0.1, 4e-8 at 0.03).  It costs one recurrence step per term instead of the downward pass from the start
 // order plus the rebuild (about 3 steps per term), needs no checkpoints, and nearly all aerosol qualifies.
-constexpr double OPT_UP_XMIN = 1.0, OPT_UP_ABSMAX = 10.0;
+constexpr double OPT_UP_XMIN = 0.3, OPT_UP_ABSMAX = 10.0;
 __device__ __forceinline__ bool mie_upward_ok(double x, cplx m) { return x >= OPT_UP_XMIN && m.im * x < OPT_UP_ABSMAX; }
 
 __device__ __forceinline__ cplx ccot(cplx y)
@@ -186,14 +186,11 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
     qback = FULL ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
 }
 
-template <bool FULL, bool ALLOW_UP = true>
-__device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS [OPT_NCK][OPT_THREADS], this thread's column */,
-                           double &qext, double &qsca, double &gasy, double &qback)
+// the downward evaluation (strongly absorbing or very small particles)
+template <bool FULL>
+__device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /* LDS [OPT_NCK][OPT_THREADS], this thread's column */,
+                                                double &qext, double &qsca, double &gasy, double &qback)
 {
-    if (ALLOW_UP && mie_upward_ok(x, m)) {   // the particle's own choice: no vote, see optics_body
-        mie_sphere_up<FULL>(x, m, qext, qsca, gasy, qback);
-        return;
-    }
     const cplx y = {x * m.re, x * m.im};
     const double ymod = sqrt(y.re * y.re + y.im * y.im);
     const double xstop = x + 4. * cbrt(x) + 2.;
@@ -275,6 +272,23 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck /* LDS 
     qext = 2. * x2inv * A.qe;
     gasy = FULL && A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
     qback = FULL ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
+}
+// ... as a real function call, for the longwave kernel: there only particles beyond any aerosol size come here, and
+// inlined twice (one per band of the pair) the code raises the register pressure of the whole kernel
+struct MieQ2 { double qext, qsca; };
+__device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck)
+{
+    double qe, qs, g, b;
+    mie_sphere_down<false>(x, m, ck, qe, qs, g, b);
+    return {qe, qs};
+}
+
+template <bool FULL>
+__device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck, double &qext, double &qsca, double &gasy,
+                                           double &qback)
+{
+    if (mie_upward_ok(x, m)) mie_sphere_up<FULL>(x, m, qext, qsca, gasy, qback);   // the particle's own choice: no vote
+    else mie_sphere_down<FULL>(x, m, ck, qext, qsca, gasy, qback);
 }
 
 // Two longwave evaluations of one particle (neighbouring bands) side by side.  The recurrences of D_n are serial
@@ -732,9 +746,8 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
                 } else if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
                     mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
                 } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
-                    double g0, b0;
-                    mie_sphere<false, false>(x, m, ck, qe, qs, g0, b0);
-                    mie_sphere<false, false>(xb, mb, ck, qe2, qs2, g0, b0);
+                    const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
+                    qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
                 }
             }
         }
