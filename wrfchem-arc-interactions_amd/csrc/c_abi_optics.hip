@@ -57,6 +57,7 @@ int fill_tables(OpticsTables &t, int nbin, double dlo_um, double dhi_um, const d
             if (!(density[s] > 0.)) { msg = "rrtmg_hip_optics_init: density must be positive"; return 1; }
             t.dens[s] = density[s];
         }
+    for (int s = 0; s < OPT_NSPEC; ++s) t.rdens[s] = 1.0 / t.dens[s];
     return 0;
 }
 

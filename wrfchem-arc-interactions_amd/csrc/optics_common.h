@@ -25,6 +25,7 @@ struct OpticsTables {
     double refr[OPT_NSPEC][OPT_NWAVE];
     double refi[OPT_NSPEC][OPT_NWAVE];
     double dens[OPT_NSPEC];            // g cm-3
+    double rdens[OPT_NSPEC];           // 1 / dens (the kernels multiply; formed once on the host)
     double wavelength_um[OPT_NWAVE];
     double dlo_um[OPT_MAXBIN], dhi_um[OPT_MAXBIN];
     int nbin, pad_;

@@ -144,13 +144,28 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
 constexpr double OPT_UP_XMIN = 0.3, OPT_UP_ABSMAX = 10.0;
 __device__ __forceinline__ bool mie_upward_ok(double x, cplx m) { return x >= OPT_UP_XMIN && m.im * x < OPT_UP_ABSMAX; }
 
+// cot(a + ib) = (sin 2a - i sinh 2b) / (cosh 2b - cos 2a) = (sa ca - i sh ch) / (sa^2 + sh^2), b >= 0: one sincos, one
+// sinh (its own series below 0.25, where (e^b - e^-b)/2 would cancel), cosh from sinh
 __device__ __forceinline__ cplx ccot(cplx y)
 {
     double sa, ca;
     sincos(y.re, &sa, &ca);
-    const double sh = sinh(y.im), ch = cosh(y.im);
-    const cplx sn = {sa * ch, ca * sh}, cs = {ca * ch, -sa * sh};
-    return cdiv(cs, sn);
+    const double b = y.im, b2 = b * b;
+    double sh;
+    if (b < 0.25) {
+        double p = 1. / 39916800.;                       // b^11 / 11!: the next term is below 1e-17 of the sum
+        p = __builtin_fma(p, b2, 1. / 362880.);
+        p = __builtin_fma(p, b2, 1. / 5040.);
+        p = __builtin_fma(p, b2, 1. / 120.);
+        p = __builtin_fma(p, b2, 1. / 6.);
+        sh = __builtin_fma(p * b2, b, b);
+    } else {
+        const double e = exp(b);
+        sh = 0.5 * (e - frcp(e));
+    }
+    const double ch = sqrt(__builtin_fma(sh, sh, 1.));
+    const double r = frcp(__builtin_fma(sa, sa, sh * sh));
+    return {sa * ca * r, -(sh * ch) * r};
 }
 
 template <bool FULL>
@@ -397,13 +412,13 @@ __device__ __forceinline__ void mie_pair_up(double x1, cplx m1, double x2, cplx 
     qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
 }
 
-// ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 2, at most OPT_MB2 terms) ----
+// ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 4, at most OPT_MB2 terms) ----
 // Most longwave evaluations are of this kind (x = pi d / lambda with d <= 10 um and lambda >= 3 um).  The whole
 // logarithmic-derivative ladder D_1..D_8 then fits the registers: the downward recurrence runs ONCE, from a start
 // order chosen from its own contraction rate -- an error e in D_n becomes e |y|^2 / (2n+1)^2 in D_(n-1), so the
 // arbitrary start value D_N = 0 has decayed below 1e-20 after a handful of steps (on 17 000 random cases with
-// |y| <= 2 the ladder equals the one started at N = 120 bit for bit; the fixed rule of the general path starts 16
-// above) -- and nothing goes through LDS.  sin x and cos x come from their Taylor series (x <= 2.1, no reduction).
+// |y| <= 2 and 15 600 with 2 < |y| <= 4 the ladder equals the one started at N = 120 / 140 bit for bit, the latter
+// even with one step fewer than the rule gives; the fixed rule of the general path starts 16 above) -- and nothing goes through LDS.  sin x and cos x come from their Taylor series (x <= 2.1, no reduction).
 __device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
 {
     const double z = x * x;
@@ -705,7 +720,7 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
         for (int sp = 0; sp < OPT_NSPEC; ++sp) {
             const int id = a.idx[ib][sp];
             const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
-            vol[sp] = mass * frcp(c_opt.dens[sp]);
+            vol[sp] = mass * c_opt.rdens[sp];
             if (sp != OS_WATER) vdry += vol[sp];
         }
         const int idn = a.idx[ib][OS_NUM];
@@ -732,7 +747,7 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             const cplx mb = mix_index(vol, vwet, a.mix, w2);
             double xb = pi * dwet * frcp(lam2);
             xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            // the register-only small-size path for the particles that qualify (|mx| <= 2, <= 8 terms).  The choice is
+            // the register-only small-size path for the particles that qualify (|mx| <= 4, <= 8 terms).  The choice is
             // the particle's own -- a wave with both kinds runs both branches -- so that a cell's result does not
             // depend on which cells share its wave, i.e. on the tiling of the domain
             const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for both bands
