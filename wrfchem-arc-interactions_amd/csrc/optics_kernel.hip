@@ -32,8 +32,9 @@ constexpr int OPT_THREADS = 128;
 
 __constant__ OpticsTables c_opt;
 // weights of the asymmetry sum, functions of the (wave-uniform) term number only:
-// c_gw[0][n] = (2n+1)/(n(n+1)), c_gw[1][n] = (n-1)(n+1)/n
-__constant__ double c_gw[2][OPT_NMIE + 2];
+// c_gw[n] = {(2n+1)/(n(n+1)), (n-1)(n+1)/n}: the weights of the asymmetry sums of term n (the term number is
+// wave-uniform, so these are scalar loads; 8 entries of slack for the loop that fetches a block of terms ahead)
+__constant__ double2 c_gw[OPT_NMIE + 10];
 // per wavelength slot: pi / lambda (size parameter per um of diameter) and its cube root
 __constant__ double c_pil[2][OPT_NWAVE];
 
@@ -101,7 +102,7 @@ struct MieAcc {
 
 // FULL = false: only the extinction and scattering sums (longwave bands use absorption alone)
 template <bool FULL>
-__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
+__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv, double2 gw)
 {
     const double en = (double)n;
     const double psi = (2. * en - 1.) * xinv * A.psi1 - A.psi0;
@@ -123,9 +124,9 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
     A.qs += w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
     A.qe += w2 * (an.re + bn.re);
     if (FULL) {
-        A.gs += c_gw[0][n] * (an.re * bn.re + an.im * bn.im);
+        A.gs += gw.x * (an.re * bn.re + an.im * bn.im);
         if (n > 1)
-            A.gs += c_gw[1][n] * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+            A.gs += gw.y * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
         A.xb.re += A.sgn * w2 * (an.re - bn.re);
         A.xb.im += A.sgn * w2 * (an.im - bn.im);
         A.sgn = -A.sgn;
@@ -169,6 +170,12 @@ __device__ __forceinline__ cplx ccot(cplx y)
 }
 
 template <bool FULL>
+__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
+{
+    mie_term<FULL>(A, n, D, m, minv, xinv, FULL ? c_gw[n] : make_double2(0., 0.));
+}
+
+template <bool FULL>
 __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, double &qsca, double &gasy, double &qback)
 {
     const cplx y = {x * m.re, x * m.im};
@@ -182,7 +189,14 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
     cplx d = ccot(y);
+    // the asymmetry weights of the NEXT four terms are fetched while these four are evaluated: read where they are
+    // used, each of the two scalar loads of a term stood in front of a wait
+    double2 gw[4], gwn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gw[i] = FULL ? c_gw[i + 1] : make_double2(0., 0.);
     for (int n0 = 0; n0 < nstop; n0 += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gwn[i] = FULL ? c_gw[n0 + 5 + i] : make_double2(0., 0.);
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
             const int n = n0 + i;
@@ -190,9 +204,11 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
                 const double en = (double)n;
                 const cplx ny = {en * yinv.re, en * yinv.im};
                 d = csub(crecip(csub(ny, d)), ny);
-                mie_term<FULL>(A, n, d, m, minv, xinv);
+                mie_term<FULL>(A, n, d, m, minv, xinv, gw[i - 1]);
             }
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gw[i] = gwn[i];
     }
     const double x2inv = xinv * xinv;
     qsca = 2. * x2inv * A.qs;
@@ -859,8 +875,8 @@ __device__ __forceinline__ void mie_term32_full(MieAccF32 &A, int n, cplx2 D, v2
     const bool on1 = n <= s.nstop1, on2 = n <= s.nstop2;   // an evaluation whose series has ended adds nothing
     A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
     A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
-    v2f dg = (float)c_gw[0][n] * (an.re * bn.re + an.im * bn.im);
-    if (n > 1) dg += (float)c_gw[1][n] * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+    v2f dg = (float)c_gw[n].x * (an.re * bn.re + an.im * bn.im);
+    if (n > 1) dg += (float)c_gw[n].y * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
     A.gs += sel2(on1, on2, dg, zero);
     A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
     A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
@@ -1110,11 +1126,11 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_lw32_kernel(const OpticsKe
 
 hipError_t optics_upload_tables(const OpticsTables &t)
 {
-    static double gw[2][OPT_NMIE + 2];
-    for (int n = 1; n < OPT_NMIE + 2; ++n) {
+    static double2 gw[OPT_NMIE + 10];
+    for (int n = 1; n < OPT_NMIE + 10; ++n) {
         const double en = (double)n;
-        gw[0][n] = (2. * en + 1.) / (en * (en + 1.));
-        gw[1][n] = (en - 1.) * (en + 1.) / en;
+        gw[n].x = (2. * en + 1.) / (en * (en + 1.));
+        gw[n].y = (en - 1.) * (en + 1.) / en;
     }
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gw), gw, sizeof gw);
     if (e != hipSuccess) return e;
