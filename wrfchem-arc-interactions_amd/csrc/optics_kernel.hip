@@ -401,7 +401,8 @@ __device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2,
 }
 
 // the pair with the logarithmic derivatives carried upward (both members inside mie_upward_ok): no LDS
-__device__ __forceinline__ void mie_pair_up(double x1, cplx m1, double x2, cplx m2, const MieSetup &s1, const MieSetup &s2,
+template <class Setup>   // MieSetup or MieSetupS: nstop, yinv, minv, xinv
+__device__ __forceinline__ void mie_pair_up(double x1, cplx m1, double x2, cplx m2, const Setup &s1, const Setup &s2,
                                             double &qext1, double &qsca1, double &qext2, double &qsca2)
 {
     const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
@@ -770,11 +771,11 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
             if (t1.small && t2.small) {
                 mie_pair_small(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);
+            } else if (mie_upward_ok(x, m) && mie_upward_ok(xb, mb)) {
+                mie_pair_up(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);   // the small-size set-up holds all it needs
             } else {
                 const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
-                if (mie_upward_ok(x, m) && mie_upward_ok(xb, mb)) {
-                    mie_pair_up(x, m, xb, mb, s1, s2, qe, qs, qe2, qs2);
-                } else if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
+                if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
                     mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
                 } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
                     const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
