@@ -400,35 +400,6 @@ __device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2,
     qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
 }
 
-// the pair with the logarithmic derivatives carried upward (both members inside mie_upward_ok): no LDS
-template <class Setup>   // MieSetup or MieSetupS: nstop, yinv, minv, xinv
-__device__ __forceinline__ void mie_pair_up(double x1, cplx m1, double x2, cplx m2, const Setup &s1, const Setup &s2,
-                                            double &qext1, double &qsca1, double &qext2, double &qsca2)
-{
-    const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
-    cplx d1 = ccot({x1 * m1.re, x1 * m1.im}), d2 = ccot({x2 * m2.re, x2 * m2.im});
-    MieAcc A1, A2;
-    sincos(x1, &A1.psi1, &A1.psi0);
-    sincos(x2, &A2.psi1, &A2.psi0);
-    A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
-    A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
-    for (int n0 = 0; n0 < nstopm; n0 += 4) {
-#pragma unroll
-        for (int i = 1; i <= 4; ++i) {
-            const int n = n0 + i;
-            const double en = (double)n;
-            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
-            d1 = csub(crecip(csub(ny1, d1)), ny1);
-            d2 = csub(crecip(csub(ny2, d2)), ny2);
-            if (n <= s1.nstop) mie_term<false>(A1, n, d1, m1, s1.minv, s1.xinv);
-            if (n <= s2.nstop) mie_term<false>(A2, n, d2, m2, s2.minv, s2.xinv);
-        }
-    }
-    const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
-    qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
-    qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
-}
-
 // ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 4, at most OPT_MB2 terms) ----
 // Most longwave evaluations are of this kind (x = pi d / lambda with d <= 10 um and lambda >= 3 um).  The whole
 // logarithmic-derivative ladder D_1..D_8 then fits the registers: the downward recurrence runs ONCE, from a start
@@ -498,37 +469,72 @@ __device__ __forceinline__ MieSetupS mie_setup_small(double x, cplx m, double cb
     return s;
 }
 
-__device__ __forceinline__ void mie_pair_small(double x1, cplx m1, double x2, cplx m2, const MieSetupS &s1,
-                                               const MieSetupS &s2, double &qext1, double &qsca1, double &qext2,
-                                               double &qsca2)
+// Small-size and upward pairs in ONE pass over the terms.  A fifth of the longwave waves hold both kinds (the limit
+// |mx| = 2 cuts through a section's size range); run one kind after the other such a wave pays for the first eight
+// terms twice.  Here every lane prepares its own source of D_n -- the ladder D_1..D_8 (small) or D_0 = cot y (upward)
+// -- and the terms are taken together: per lane the same operations in the same order as if its kind ran alone, so
+// a particle's result does not depend on the company it keeps.
+__device__ __forceinline__ void mie_pair_su(double x1, cplx m1, double x2, cplx m2, const MieSetupS &s1,
+                                            const MieSetupS &s2, const bool small, double &qext1, double &qsca1,
+                                            double &qext2, double &qsca2)
 {
-    cplx d1 = {0., 0.}, d2 = {0., 0.};
-    const int nstart = s1.nstart > s2.nstart ? s1.nstart : s2.nstart;
-    for (int n = nstart; n > OPT_MB2 + 1; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), down to D_9
-        const double en = (double)n;
-        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
-        d1 = csub(ny1, crecip(cadd(d1, ny1)));
-        d2 = csub(ny2, crecip(cadd(d2, ny2)));
-    }
     cplx dd1[OPT_MB2], dd2[OPT_MB2];
-#pragma unroll
-    for (int i = OPT_MB2 - 1; i >= 0; --i) {       // dd[i] = D_{i+1}
-        const double en = (double)(i + 2);
-        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
-        d1 = csub(ny1, crecip(cadd(d1, ny1)));
-        d2 = csub(ny2, crecip(cadd(d2, ny2)));
-        dd1[i] = d1; dd2[i] = d2;
-    }
+    cplx d1 = {0., 0.}, d2 = {0., 0.};
     MieAcc A1, A2;
-    sincos_small(x1, A1.psi1, A1.psi0);
-    sincos_small(x2, A2.psi1, A2.psi0);
+    if (small) {
+        const int nstart = s1.nstart > s2.nstart ? s1.nstart : s2.nstart;
+        for (int n = nstart; n > OPT_MB2 + 1; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), down to D_9
+            const double en = (double)n;
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(ny1, crecip(cadd(d1, ny1)));
+            d2 = csub(ny2, crecip(cadd(d2, ny2)));
+        }
+#pragma unroll
+        for (int i = OPT_MB2 - 1; i >= 0; --i) {       // dd[i] = D_{i+1}
+            const double en = (double)(i + 2);
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(ny1, crecip(cadd(d1, ny1)));
+            d2 = csub(ny2, crecip(cadd(d2, ny2)));
+            dd1[i] = d1; dd2[i] = d2;
+        }
+        sincos_small(x1, A1.psi1, A1.psi0);
+        sincos_small(x2, A2.psi1, A2.psi0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < OPT_MB2; ++i) { dd1[i] = {0., 0.}; dd2[i] = {0., 0.}; }
+        d1 = ccot({x1 * m1.re, x1 * m1.im});
+        d2 = ccot({x2 * m2.re, x2 * m2.im});
+        sincos(x1, &A1.psi1, &A1.psi0);
+        sincos(x2, &A2.psi1, &A2.psi0);
+    }
     A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
     A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
 #pragma unroll
     for (int i = 0; i < OPT_MB2; ++i) {
         const int n = i + 1;
-        if (n <= s1.nstop) mie_term<false>(A1, n, dd1[i], m1, s1.minv, s1.xinv);
-        if (n <= s2.nstop) mie_term<false>(A2, n, dd2[i], m2, s2.minv, s2.xinv);
+        if (!small) {
+            const double en = (double)n;
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(crecip(csub(ny1, d1)), ny1);
+            d2 = csub(crecip(csub(ny2, d2)), ny2);
+        }
+        const cplx D1 = small ? dd1[i] : d1, D2 = small ? dd2[i] : d2;
+        if (n <= s1.nstop) mie_term<false>(A1, n, D1, m1, s1.minv, s1.xinv);
+        if (n <= s2.nstop) mie_term<false>(A2, n, D2, m2, s2.minv, s2.xinv);
+    }
+    // beyond eight terms only upward lanes are left
+    const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
+    for (int n0 = OPT_MB2; n0 < nstopm; n0 += 4) {
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) {
+            const int n = n0 + i;
+            const double en = (double)n;
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(crecip(csub(ny1, d1)), ny1);
+            d2 = csub(crecip(csub(ny2, d2)), ny2);
+            if (n <= s1.nstop) mie_term<false>(A1, n, d1, m1, s1.minv, s1.xinv);
+            if (n <= s2.nstop) mie_term<false>(A2, n, d2, m2, s2.minv, s2.xinv);
+        }
     }
     const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
     qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
@@ -769,10 +775,9 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
             // depend on which cells share its wave, i.e. on the tiling of the domain
             const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for both bands
             const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
-            if (t1.small && t2.small) {
-                mie_pair_small(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);
-            } else if (mie_upward_ok(x, m) && mie_upward_ok(xb, mb)) {
-                mie_pair_up(x, m, xb, mb, t1, t2, qe, qs, qe2, qs2);   // the small-size set-up holds all it needs
+            const bool small = t1.small && t2.small;
+            if (small || (mie_upward_ok(x, m) && mie_upward_ok(xb, mb))) {
+                mie_pair_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
             } else {
                 const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
                 if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
