@@ -14,9 +14,10 @@
 //     tau = ext * dz; longwave: absorption only (RRTMG-LW has no scattering term).
 //
 // Mapping: one thread = one (cell, wavelength); lanes = consecutive i of the (i,k,j) tile so that every tracer
-// load is a unit-stride segment; the 20 wavelength blocks of a cell group are issued back-to-back on one XCD
-// so that the tracer lines are fetched from HBM once and re-read from that XCD's L2.  Compute-bound (fp64
-// VALU): ~10^5 flop per cell against 0.6 KB of tracer data.
+// load is a unit-stride segment; the eight longwave pair-blocks of a cell group are issued back-to-back on one XCD
+// so that the tracer lines are fetched from HBM once and re-read from that XCD's L2 (the shortwave kernel runs
+// wavelength-major instead, see optics_body).  Compute-bound (fp64 VALU): ~10^5 flop per cell against 0.6 KB of
+// tracer data.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -713,8 +714,14 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
     constexpr int NW = LW ? OPT_NLW / 2 : OPT_NSW;
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
-    const int gl = s / NW, slot = s - gl * NW;
     constexpr bool lw = LW;
+    // Longwave: the eight pair-workgroups of a cell group follow each other on their XCD (tracers from HBM once).
+    // Shortwave: wavelength-major -- all cell groups at 300 nm, then all at 400 nm, ...  The four wavelengths differ
+    // 2x in series length, and with workgroups of unequal duration interleaved the CUs stayed half empty (1.7 of 3
+    // waves per SIMD resident); with equal neighbours the kernel is 22 % faster although the tracers are now read
+    // four times (0.7 TB/s, hidden behind the arithmetic).  The same order costs the longwave kernel 13 %.
+    const int ng8 = (int)(gridDim.x >> 3) / NW;
+    const int slot = lw ? s % NW : s / ng8, gl = lw ? s / NW : s - slot * ng8;
     const int w = lw ? OPT_NSW + 2 * slot : slot, w2 = w + 1;   // w2: second band of a longwave pair
     double2 *ck = s_ck + threadIdx.x;
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
