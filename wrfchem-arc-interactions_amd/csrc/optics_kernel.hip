@@ -219,8 +219,8 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
 }
 
 // the downward evaluation (strongly absorbing or very small particles)
-template <bool FULL>
-__device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /* LDS [OPT_NCK][OPT_THREADS], this thread's column */,
+template <bool FULL, int NCK = OPT_NCK>
+__device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /* LDS [NCK][OPT_THREADS], this thread's column */,
                                                 double &qext, double &qsca, double &gasy, double &qback)
 {
     const cplx y = {x * m.re, x * m.im};
@@ -241,8 +241,8 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
     A.an1 = {0., 0.}; A.bn1 = {0., 0.}; A.xb = {0., 0.};
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
-    for (int seg = 0; seg < nck; seg += OPT_NCK) {   // once, unless the series is longer than OPT_NCK * OPT_MB terms
-    const int nseg = nck - seg < OPT_NCK ? nck - seg : OPT_NCK;
+    for (int seg = 0; seg < nck; seg += NCK) {   // once, unless the series is longer than NCK * OPT_MB terms
+    const int nseg = nck - seg < NCK ? nck - seg : NCK;
     {
         // downward pass from the start order to the segment's first block: D_{n-1} = n/y - 1/(D_n + n/y); the
         // checkpoints D_{MB (seg + j)}, j = 1..nseg, stay in LDS
@@ -308,10 +308,11 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
 // ... as a real function call, for the longwave kernel: there only particles beyond any aerosol size come here, and
 // inlined twice (one per band of the pair) the code raises the register pressure of the whole kernel
 struct MieQ2 { double qext, qsca; };
+constexpr int OPT_NCK_LW = 4;   // checkpoint slots per thread of the longwave kernel (segments of 64 terms)
 __device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck)
 {
     double qe, qs, g, b;
-    mie_sphere_down<false>(x, m, ck, qe, qs, g, b);
+    mie_sphere_down<false, OPT_NCK_LW>(x, m, ck, qe, qs, g, b);
     return {qe, qs};
 }
 
@@ -822,6 +823,95 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
     }
 }
 
+// Longwave, fp64: one thread = one cell, all sixteen bands.  The particle geometry of a section (ten tracer loads, three
+// cube roots, the clipping rule) is formed once instead of once per band pair; the pairs follow in a loop, and the 32
+// running sums of the cell (extinction and scattering per band) live in the thread's LDS column, which a loop may
+// index -- in registers they cost an occupancy step (round 2's first per-cell kernel: 256 VGPRs + 100 AGPRs).
+__device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
+{
+    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
+    if (cell >= ncell) return;
+    unsigned want = 0;   // pairs with an output requested
+#pragma unroll
+    for (int p = 0; p < OPT_NLW / 2; ++p)
+        if (a.tauaerlw[2 * p] || a.extaerlw[2 * p] || a.tauaerlw[2 * p + 1] || a.extaerlw[2 * p + 1]) want |= 1u << p;
+    if (!want) return;
+    double2 *ck = s_ck + threadIdx.x;
+    double *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
+#pragma unroll
+    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = 0.;
+    const int it = (int)(cell % a.ni_t);
+    const long r = cell / a.ni_t;
+    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
+    const int r4 = a.real4;
+    const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
+    const double pi = 3.14159265358979323846;
+    for (int ib = 0; ib < a.nbin; ++ib) {
+        double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
+        double vdry = 0.;
+#pragma unroll
+        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+            const int id = a.idx[ib][sp];
+            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
+            vol[sp] = mass * c_opt.rdens[sp];
+            if (sp != OS_WATER) vdry += vol[sp];
+        }
+        const int idn = a.idx[ib][OS_NUM];
+        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
+        if (!(vdry > 1.e-25)) continue;
+        const double vwet = vdry + vol[OS_WATER];
+        // dry diameter (um) from dry volume and number; clipped to the section, number follows (volume is kept)
+        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));   // cm3 per particle
+        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
+        if (ddry < dlo || ddry > dhi) {
+            ddry = ddry < dlo ? dlo : dhi;
+            const double dcm = ddry * 1.e-4;
+            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
+        }
+        const double dwet = ddry * cbrt(vwet * frcp(vdry));
+        const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for all bands
+        const double dcm = dwet * 1.e-4;
+        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
+#pragma unroll 1
+        for (int p = 0; p < OPT_NLW / 2; ++p) {
+            if (!((want >> p) & 1)) continue;
+            const int w = OPT_NSW + 2 * p, w2 = w + 1;
+            const cplx m = mix_index(vol, vwet, a.mix, w), mb = mix_index(vol, vwet, a.mix, w2);
+            double x = pi * dwet * frcp(c_opt.wavelength_um[w]), xb = pi * dwet * frcp(c_opt.wavelength_um[w2]);
+            x = x > OPT_XMAX ? OPT_XMAX : x;
+            xb = xb > OPT_XMAX ? OPT_XMAX : xb;
+            double qe, qs, qe2, qs2;
+            // the register-only small-size ladder or the upward recurrence, the particle's own choice (a wave with
+            // both kinds takes the terms in one pass, mie_pair_su): a cell's result does not depend on which cells
+            // share its wave, i.e. on the tiling of the domain
+            const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
+            const bool small = t1.small && t2.small;
+            if (small || (mie_upward_ok(x, m) && mie_upward_ok(xb, mb))) {
+                mie_pair_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
+            } else {   // strongly absorbing beyond any aerosol at these wavelengths: downward, one band after the other
+                const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
+                qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
+            }
+            double *s = acc + (size_t)(4 * p) * OPT_THREADS;
+            s[0] += cross * qe;
+            s[OPT_THREADS] += cross * qs;
+            s[2 * OPT_THREADS] += cross * qe2;
+            s[3 * OPT_THREADS] += cross * qs2;
+        }
+    }
+#pragma unroll 1
+    for (int ib = 0; ib < OPT_NLW; ++ib) {
+        const double ext = acc[(size_t)(2 * ib) * OPT_THREADS], sca = acc[(size_t)(2 * ib + 1) * OPT_THREADS];
+        const double ab = fmax(ext - sca, 0.);
+        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
+        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
+    }
+}
+
 // Mixed path, longwave band pair: the whole cell evaluation in fp32 (particle geometry, refractive index of the
 // mixture, Mie series); tracers are read and optical depths written in the arrays' own type.
 struct cf32 { float re, im; };
@@ -1118,8 +1208,9 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 optics_lw_kernel(const OpticsKernelArgs a)
 {
-    __shared__ double2 s_ck[2 * OPT_NCK2 * OPT_THREADS];
-    optics_body<true>(a, s_ck);
+    __shared__ double2 s_ck[OPT_NCK_LW * OPT_THREADS];
+    __shared__ double s_acc[2 * OPT_NLW * OPT_THREADS];
+    optics_lw_cell(a, s_ck, s_acc);
 }
 
 // the mixed-precision path: shortwave wavelength pairs and longwave band pairs in fp32
@@ -1175,8 +1266,9 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
         hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
     if (any_lw && precision == 1)
         hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
-    else if (any_lw)
-        hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
+    else if (any_lw)   // one thread per cell
+        hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                           stream, a);
     return hipGetLastError();
 }
 
