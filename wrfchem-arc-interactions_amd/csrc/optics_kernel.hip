@@ -13,11 +13,11 @@
 //   per cell: ext = sum_b N_b pi r_b^2 Qext, omega = sum sca / sum ext, g = sum g sca / sum sca,
 //     tau = ext * dz; longwave: absorption only (RRTMG-LW has no scattering term).
 //
-// Mapping: one thread = one (cell, wavelength); lanes = consecutive i of the (i,k,j) tile so that every tracer
-// load is a unit-stride segment; the eight longwave pair-blocks of a cell group are issued back-to-back on one XCD
-// so that the tracer lines are fetched from HBM once and re-read from that XCD's L2 (the shortwave kernel runs
-// wavelength-major instead, see optics_body).  Compute-bound (fp64 VALU): ~10^5 flop per cell against 0.6 KB of
-// tracer data.
+// Mapping: lanes = consecutive i of the (i,k,j) tile so that every tracer load is a unit-stride segment.  Shortwave:
+// one thread = one (cell, wavelength), workgroups wavelength-major (optics_sw_body).  Longwave: one thread = one cell
+// with all sixteen bands, two at a time (optics_lw_cell).  The fp32 kernels keep one thread per (cell, band pair) with
+// the pair-blocks of a cell group back-to-back on one XCD.  Compute-bound (fp64 VALU): ~10^5 flop per cell against
+// 0.6 KB of tracer data.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -324,83 +324,13 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck, double
     else mie_sphere_down<FULL>(x, m, ck, qext, qsca, gasy, qback);
 }
 
-// Two longwave evaluations of one particle (neighbouring bands) side by side.  The recurrences of D_n are serial
-// chains of ~10 dependent fp64 operations per step and the longwave series are short, so a single evaluation
-// leaves the SIMD waiting on its own results; two independent chains in one instruction stream fill those gaps.
-// Both start the downward recurrence at the larger of their two start orders (a higher start is only more
-// accurate), use register blocks of OPT_MB2 terms and the two halves of the thread's checkpoint column
-// (OPT_NCK2 checkpoints each: nstop <= OPT_MB2*OPT_NCK2 = 64, the caller checks).  Extinction and scattering only.
-constexpr int OPT_MB2 = 8, OPT_NCK2 = 8;   // the longwave kernels keep 2 x 8 slots per thread
+// Two longwave evaluations of one particle (neighbouring bands) travel side by side (mie_pair_su below; the fp32
+// kernels pack them into one register pair): the recurrences of D_n are serial chains of ~10 dependent fp64 operations
+// per step and the longwave series are short, so a single evaluation leaves the SIMD waiting on its own results; two
+// independent chains in one instruction stream fill those gaps.  Register blocks of OPT_MB2 terms.
+constexpr int OPT_MB2 = 8, OPT_NCK2 = 8;   // the fp32 kernels keep 8 + 4 checkpoint slots per thread
 constexpr double OPT_XMAX32 = 47.0;   // x + 4 x^(1/3) + 2 < 64 = OPT_MB2 * OPT_NCK2
 constexpr int OPT_NCK32 = OPT_NCK2 + OPT_NCK2 / 2;   // LDS slots per thread of the fp32 pair
-
-struct MieSetup {
-    cplx yinv, minv;
-    double xinv;
-    int nstop, nmx;
-};
-__device__ __forceinline__ MieSetup mie_setup(double x, cplx m)
-{
-    MieSetup s;
-    const cplx y = {x * m.re, x * m.im};
-    const double ymod = sqrt(y.re * y.re + y.im * y.im);
-    const double xstop = x + 4. * cbrt(x) + 2.;
-    s.nstop = (int)xstop;
-    const double base = fmax(xstop, ymod);
-    s.nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;   // as in mie_sphere
-    s.yinv = crecip(y);
-    s.minv = crecip(m);
-    s.xinv = frcp(x);
-    return s;
-}
-
-__device__ __forceinline__ void mie_pair(double x1, cplx m1, double x2, cplx m2, const MieSetup &s1, const MieSetup &s2,
-                                         double2 *ck, double &qext1, double &qsca1, double &qext2, double &qsca2)
-{
-    const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
-    const int nck = (nstopm + OPT_MB2 - 1) / OPT_MB2, ntop = nck * OPT_MB2;
-    const int nmx = s1.nmx > s2.nmx ? s1.nmx : s2.nmx;
-    cplx d1 = {0., 0.}, d2 = {0., 0.};
-    for (int n = nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), both particles
-        const double en = (double)n;
-        const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
-        d1 = csub(ny1, crecip(cadd(d1, ny1)));
-        d2 = csub(ny2, crecip(cadd(d2, ny2)));
-        const int n1 = n - 1;
-        if (n1 <= ntop && (n1 & (OPT_MB2 - 1)) == 0) {
-            ck[(size_t)(n1 / OPT_MB2 - 1) * OPT_THREADS] = make_double2(d1.re, d1.im);
-            ck[(size_t)(OPT_NCK2 + n1 / OPT_MB2 - 1) * OPT_THREADS] = make_double2(d2.re, d2.im);
-        }
-        if (n1 <= OPT_MB2) break;
-    }
-    MieAcc A1, A2;
-    sincos(x1, &A1.psi1, &A1.psi0);
-    sincos(x2, &A2.psi1, &A2.psi0);
-    A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
-    A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
-    for (int j = 0; j < nck; ++j) {
-        cplx dd1[OPT_MB2], dd2[OPT_MB2];
-        const double2 c1 = ck[(size_t)j * OPT_THREADS], c2 = ck[(size_t)(OPT_NCK2 + j) * OPT_THREADS];
-        dd1[OPT_MB2 - 1] = {c1.x, c1.y};
-        dd2[OPT_MB2 - 1] = {c2.x, c2.y};
-#pragma unroll
-        for (int i = OPT_MB2 - 1; i >= 1; --i) {
-            const double en = (double)(j * OPT_MB2 + i + 1);
-            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
-            dd1[i - 1] = csub(ny1, crecip(cadd(dd1[i], ny1)));
-            dd2[i - 1] = csub(ny2, crecip(cadd(dd2[i], ny2)));
-        }
-#pragma unroll
-        for (int i = 0; i < OPT_MB2; ++i) {
-            const int n = j * OPT_MB2 + i + 1;
-            if (n <= s1.nstop) mie_term<false>(A1, n, dd1[i], m1, s1.minv, s1.xinv);
-            if (n <= s2.nstop) mie_term<false>(A2, n, dd2[i], m2, s2.minv, s2.xinv);
-        }
-    }
-    const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
-    qsca1 = f1 * A1.qs; qext1 = f1 * A1.qe;
-    qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
-}
 
 // ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 4, at most OPT_MB2 terms) ----
 // Most longwave evaluations are of this kind (x = pi d / lambda with d <= 10 um and lambda >= 3 um).  The whole
@@ -706,32 +636,24 @@ __device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mi
     return m;
 }
 
-// LW = false: one shortwave wavelength per workgroup (4 per cell group); LW = true: one pair of longwave bands
-// (8 per cell group).  Two kernels so that each path gets its own register allocation.
-template <bool LW>
-__device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *s_ck)
+// Shortwave, fp64: one wavelength per workgroup (4 per cell group), one thread per (cell, wavelength).
+__device__ __forceinline__ void optics_sw_body(const OpticsKernelArgs &a, double2 *s_ck)
 {
-    // the workgroups of one cell group run back-to-back on one XCD (blockIdx & 7)
-    constexpr int NW = LW ? OPT_NLW / 2 : OPT_NSW;
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
-    constexpr bool lw = LW;
-    // Longwave: the eight pair-workgroups of a cell group follow each other on their XCD (tracers from HBM once).
-    // Shortwave: wavelength-major -- all cell groups at 300 nm, then all at 400 nm, ...  The four wavelengths differ
-    // 2x in series length, and with workgroups of unequal duration interleaved the CUs stayed half empty (1.7 of 3
-    // waves per SIMD resident); with equal neighbours the kernel is 22 % faster although the tracers are now read
-    // four times (0.7 TB/s, hidden behind the arithmetic).  The same order costs the longwave kernel 13 %.
-    const int ng8 = (int)(gridDim.x >> 3) / NW;
-    const int slot = lw ? s % NW : s / ng8, gl = lw ? s / NW : s - slot * ng8;
-    const int w = lw ? OPT_NSW + 2 * slot : slot, w2 = w + 1;   // w2: second band of a longwave pair
+    // Wavelength-major: all cell groups at 300 nm, then all at 400 nm, ...  The four wavelengths differ 2x in series
+    // length, and with workgroups of unequal duration interleaved (the four wavelengths of a cell group back-to-back
+    // on one XCD, tracers from HBM once) the CUs stayed half empty: 1.7 of 3 waves per SIMD resident.  With equal
+    // neighbours the kernel is 22 % faster although the tracers are now read four times (0.7 TB/s, hidden behind
+    // the arithmetic).
+    const int ng8 = (int)(gridDim.x >> 3) / OPT_NSW;
+    const int w = s / ng8, gl = s - w * ng8;
     double2 *ck = s_ck + threadIdx.x;
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
     // nothing requested at this wavelength (output group absent): no work
-    if (!lw ? !(a.tauaer[w] || a.extaer[w] || a.bscoef[w])
-            : !(a.tauaerlw[w - OPT_NSW] || a.extaerlw[w - OPT_NSW] || a.tauaerlw[w2 - OPT_NSW] || a.extaerlw[w2 - OPT_NSW]))
-        return;
+    if (!(a.tauaer[w] || a.extaer[w] || a.bscoef[w])) return;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
@@ -739,11 +661,10 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
     const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
     const int r4 = a.real4;
     const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
-    const double lam = c_opt.wavelength_um[w], lam2 = c_opt.wavelength_um[lw ? w2 : w];
+    const double lam = c_opt.wavelength_um[w];
     const double pi = 3.14159265358979323846;
 
     double ext = 0., sca = 0., gsca = 0., bsc = 0.;   // 1/cm (bsc: 1/(cm sr))
-    double ext2 = 0., sca2 = 0.;                      // second band of a longwave pair
     for (int ib = 0; ib < a.nbin; ++ib) {
         double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
         double vdry = 0.;
@@ -771,56 +692,22 @@ __device__ __forceinline__ void optics_body(const OpticsKernelArgs &a, double2 *
         const cplx m = mix_index(vol, vwet, a.mix, w);
         double x = pi * dwet * frcp(lam);
         x = x > OPT_XMAX ? OPT_XMAX : x;
-        double qe, qs, g = 0., qb = 0., qe2 = 0., qs2 = 0.;
-        if (!lw) {
-            mie_sphere<true>(x, m, ck, qe, qs, g, qb);
-        } else {
-            const cplx mb = mix_index(vol, vwet, a.mix, w2);
-            double xb = pi * dwet * frcp(lam2);
-            xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            // the register-only small-size path for the particles that qualify (|mx| <= 4, <= 8 terms).  The choice is
-            // the particle's own -- a wave with both kinds runs both branches -- so that a cell's result does not
-            // depend on which cells share its wave, i.e. on the tiling of the domain
-            const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for both bands
-            const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
-            const bool small = t1.small && t2.small;
-            if (small || (mie_upward_ok(x, m) && mie_upward_ok(xb, mb))) {
-                mie_pair_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
-            } else {
-                const MieSetup s1 = mie_setup(x, m), s2 = mie_setup(xb, mb);
-                if (s1.nstop <= OPT_MB2 * OPT_NCK2 && s2.nstop <= OPT_MB2 * OPT_NCK2) {
-                    mie_pair(x, m, xb, mb, s1, s2, ck, qe, qs, qe2, qs2);
-                } else {   // size parameters beyond any aerosol at these wavelengths: one after the other
-                    const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
-                    qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
-                }
-            }
-        }
+        double qe, qs, g = 0., qb = 0.;
+        mie_sphere<true>(x, m, ck, qe, qs, g, qb);
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
         ext += cross * qe;
         sca += cross * qs;
         gsca += cross * qs * g;
         bsc += cross * qb * (0.25 / pi);
-        ext2 += cross * qe2;
-        sca2 += cross * qs2;
     }
-    if (!lw) {
-        if (a.tauaer[w]) {
-            str(a.tauaer[w], q, r4, ext * 100. * dz);
-            str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
-            str(a.gaer[w], q, r4, sca > 0. ? gsca * frcp(sca) : 0.);
-        }
-        if (a.extaer[w]) str(a.extaer[w], q, r4, ext * 1.e5);
-        if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
-    } else {
-        const int ib = w - OPT_NSW;
-        const double ab = fmax(ext - sca, 0.), ab2 = fmax(ext2 - sca2, 0.);
-        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
-        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
-        if (a.tauaerlw[ib + 1]) str(a.tauaerlw[ib + 1], q, r4, ab2 * 100. * dz);
-        if (a.extaerlw[ib + 1]) str(a.extaerlw[ib + 1], q, r4, ab2 * 1.e5);
+    if (a.tauaer[w]) {
+        str(a.tauaer[w], q, r4, ext * 100. * dz);
+        str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
+        str(a.gaer[w], q, r4, sca > 0. ? gsca * frcp(sca) : 0.);
     }
+    if (a.extaer[w]) str(a.extaer[w], q, r4, ext * 1.e5);
+    if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
 }
 
 // Longwave, fp64: one thread = one cell, all sixteen bands.  The particle geometry of a section (ten tracer loads, three
@@ -1202,7 +1089,7 @@ __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, doub
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
-    optics_body<false>(a, s_ck);
+    optics_sw_body(a, s_ck);
 }
 
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
