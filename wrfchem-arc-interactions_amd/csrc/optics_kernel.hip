@@ -972,7 +972,9 @@ __device__ __forceinline__ void optics_body_sw32(const OpticsKernelArgs &a, doub
     constexpr int NW = OPT_NSW / 2;
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
-    const int gl = s / NW, slot = s - gl * NW;
+    // pair-major, as the fp64 kernel is wavelength-major: workgroups of equal duration next to each other
+    const int ng8 = (int)(gridDim.x >> 3) / NW;
+    const int slot = s / ng8, gl = s - slot * ng8;
     const int w = 2 * slot, w2 = w + 1;
     double2 *ck = s_ck + threadIdx.x;
     const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
