@@ -13,10 +13,10 @@
 //   per cell: ext = sum_b N_b pi r_b^2 Qext, omega = sum sca / sum ext, g = sum g sca / sum sca,
 //     tau = ext * dz; longwave: absorption only (RRTMG-LW has no scattering term).
 //
-// Mapping: lanes = consecutive i of the (i,k,j) tile so that every tracer load is a unit-stride segment.  Shortwave:
-// one thread = one (cell, wavelength), workgroups wavelength-major (optics_sw_body).  Longwave: one thread = one cell
-// with all sixteen bands, two at a time (optics_lw_cell).  The fp32 kernels keep one thread per (cell, band pair) with
-// the pair-blocks of a cell group back-to-back on one XCD.  Compute-bound (fp64 VALU): ~10^5 flop per cell against
+// Mapping: lanes = consecutive i of the (i,k,j) tile so that every tracer load is a unit-stride segment.  fp64: one
+// thread = one cell -- all four shortwave wavelengths (optics_sw_cell), all sixteen longwave bands two at a time
+// (optics_lw_cell) -- with the cell's running sums in the thread's LDS column.  The fp32 kernels keep one thread per
+// (cell, wavelength pair / band pair).  Compute-bound (fp64 VALU): ~10^5 flop per cell against
 // 0.6 KB of tracer data.
 #include <hip/hip_runtime.h>
 
@@ -90,10 +90,11 @@ __device__ __forceinline__ void str(void *p, size_t idx, int real4, double v)
 // (ck[j][thread]); the upward pass rebuilds each block of OPT_MB values from its checkpoint in registers
 // (statically indexed) and consumes them.  D_n is recomputed once; nothing goes to scratch.
 constexpr int OPT_MB = 16, OPT_RB = 8;   // checkpoint spacing, register block
-// Checkpoints per thread: 12 cover a pass of 192 terms (size parameters up to ~165: a 15 um particle at 0.3 um);
-// beyond, the series is taken in segments of OPT_NCK * OPT_MB terms with one more downward pass each (mie_sphere).  12 slots and
-// the 8-value register block are what lets three waves per SIMD run (LDS: 6 workgroups x 24 KB per CU).
-constexpr int OPT_NCK = 12;
+// Checkpoints per thread: NCK of them cover a pass of NCK * OPT_MB terms; beyond, the series is taken in segments with
+// one more downward pass each (mie_sphere_down).  The downward path is the fallback (see mie_upward_ok), so the
+// kernels keep 4 (segments of 64 terms); few slots and the 8-value register block are what lets three waves per
+// SIMD run.
+constexpr int OPT_NCK = 12;   // default of the template parameter
 
 
 struct MieAcc {
@@ -316,12 +317,12 @@ __device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck
     return {qe, qs};
 }
 
-template <bool FULL>
+template <bool FULL, int NCK = OPT_NCK>
 __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck, double &qext, double &qsca, double &gasy,
                                            double &qback)
 {
     if (mie_upward_ok(x, m)) mie_sphere_up<FULL>(x, m, qext, qsca, gasy, qback);   // the particle's own choice: no vote
-    else mie_sphere_down<FULL>(x, m, ck, qext, qsca, gasy, qback);
+    else mie_sphere_down<FULL, NCK>(x, m, ck, qext, qsca, gasy, qback);
 }
 
 // Two longwave evaluations of one particle (neighbouring bands) travel side by side (mie_pair_su below; the fp32
@@ -636,24 +637,27 @@ __device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mi
     return m;
 }
 
-// Shortwave, fp64: one wavelength per workgroup (4 per cell group), one thread per (cell, wavelength).
-__device__ __forceinline__ void optics_sw_body(const OpticsKernelArgs &a, double2 *s_ck)
+// Shortwave, fp64: one thread = one cell with all four wavelengths, as the longwave kernel takes its bands: particle
+// geometry and tracers once per section, the sixteen running sums in the thread's LDS column, and every workgroup
+// costs the same.  (With one wavelength per workgroup and the four wavelengths of a cell group back-to-back the CUs
+// stayed half empty -- the wavelengths differ 2x in series length and workgroups of unequal duration interleaved
+// badly: 1.7 of 3 waves per SIMD resident; wavelength-major order fixed that, 5.38 -> 4.19 ms per 1.6 M cells; per
+// cell: 3.94 ms.)  The downward fallback keeps 4 checkpoints per thread (segments of 64 terms).
+constexpr int OPT_NCK_SWC = 4;
+__device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
 {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, s = b >> 3;
-    // Wavelength-major: all cell groups at 300 nm, then all at 400 nm, ...  The four wavelengths differ 2x in series
-    // length, and with workgroups of unequal duration interleaved (the four wavelengths of a cell group back-to-back
-    // on one XCD, tracers from HBM once) the CUs stayed half empty: 1.7 of 3 waves per SIMD resident.  With equal
-    // neighbours the kernel is 22 % faster although the tracers are now read four times (0.7 TB/s, hidden behind
-    // the arithmetic).
-    const int ng8 = (int)(gridDim.x >> 3) / OPT_NSW;
-    const int w = s / ng8, gl = s - w * ng8;
-    double2 *ck = s_ck + threadIdx.x;
-    const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
+    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
-    // nothing requested at this wavelength (output group absent): no work
-    if (!(a.tauaer[w] || a.extaer[w] || a.bscoef[w])) return;
+    unsigned want = 0;
+#pragma unroll
+    for (int w = 0; w < OPT_NSW; ++w)
+        if (a.tauaer[w] || a.extaer[w] || a.bscoef[w]) want |= 1u << w;
+    if (!want) return;
+    double2 *ck = s_ck + threadIdx.x;
+    double *acc = s_acc + threadIdx.x;   // [wavelength][ext, sca, g sca, bsc][thread]
+#pragma unroll
+    for (int i = 0; i < 4 * OPT_NSW; ++i) acc[i * OPT_THREADS] = 0.;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
@@ -661,10 +665,7 @@ __device__ __forceinline__ void optics_sw_body(const OpticsKernelArgs &a, double
     const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
     const int r4 = a.real4;
     const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
-    const double lam = c_opt.wavelength_um[w];
     const double pi = 3.14159265358979323846;
-
-    double ext = 0., sca = 0., gsca = 0., bsc = 0.;   // 1/cm (bsc: 1/(cm sr))
     for (int ib = 0; ib < a.nbin; ++ib) {
         double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
         double vdry = 0.;
@@ -679,7 +680,6 @@ __device__ __forceinline__ void optics_sw_body(const OpticsKernelArgs &a, double
         double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
         if (!(vdry > 1.e-25)) continue;
         const double vwet = vdry + vol[OS_WATER];
-        // dry diameter (um) from dry volume and number; clipped to the section, number follows (volume is kept)
         const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));   // cm3 per particle
         double ddry = 1.e4 * cbrt(vpart * (6. / pi));
         const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
@@ -689,25 +689,35 @@ __device__ __forceinline__ void optics_sw_body(const OpticsKernelArgs &a, double
             num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
         }
         const double dwet = ddry * cbrt(vwet * frcp(vdry));
-        const cplx m = mix_index(vol, vwet, a.mix, w);
-        double x = pi * dwet * frcp(lam);
-        x = x > OPT_XMAX ? OPT_XMAX : x;
-        double qe, qs, g = 0., qb = 0.;
-        mie_sphere<true>(x, m, ck, qe, qs, g, qb);
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
-        ext += cross * qe;
-        sca += cross * qs;
-        gsca += cross * qs * g;
-        bsc += cross * qb * (0.25 / pi);
+#pragma unroll 1
+        for (int w = 0; w < OPT_NSW; ++w) {
+            if (!((want >> w) & 1)) continue;
+            const cplx m = mix_index(vol, vwet, a.mix, w);
+            double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
+            x = x > OPT_XMAX ? OPT_XMAX : x;
+            double qe, qs, g = 0., qb = 0.;
+            mie_sphere<true, OPT_NCK_SWC>(x, m, ck, qe, qs, g, qb);
+            double *s = acc + (size_t)(4 * w) * OPT_THREADS;
+            s[0] += cross * qe;
+            s[OPT_THREADS] += cross * qs;
+            s[2 * OPT_THREADS] += cross * qs * g;
+            s[3 * OPT_THREADS] += cross * qb * (0.25 / pi);
+        }
     }
-    if (a.tauaer[w]) {
-        str(a.tauaer[w], q, r4, ext * 100. * dz);
-        str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
-        str(a.gaer[w], q, r4, sca > 0. ? gsca * frcp(sca) : 0.);
+#pragma unroll 1
+    for (int w = 0; w < OPT_NSW; ++w) {
+        const double *s = acc + (size_t)(4 * w) * OPT_THREADS;
+        const double ext = s[0], sca = s[OPT_THREADS], gsca = s[2 * OPT_THREADS], bsc = s[3 * OPT_THREADS];
+        if (a.tauaer[w]) {
+            str(a.tauaer[w], q, r4, ext * 100. * dz);
+            str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
+            str(a.gaer[w], q, r4, sca > 0. ? gsca * frcp(sca) : 0.);
+        }
+        if (a.extaer[w]) str(a.extaer[w], q, r4, ext * 1.e5);
+        if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
     }
-    if (a.extaer[w]) str(a.extaer[w], q, r4, ext * 1.e5);
-    if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
 }
 
 // Longwave, fp64: one thread = one cell, all sixteen bands.  The particle geometry of a section (ten tracer loads, three
@@ -1090,8 +1100,9 @@ __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, doub
 
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_kernel(const OpticsKernelArgs a)
 {
-    __shared__ double2 s_ck[OPT_NCK * OPT_THREADS];
-    optics_sw_body(a, s_ck);
+    __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
+    __shared__ double s_acc[4 * OPT_NSW * OPT_THREADS];
+    optics_sw_cell(a, s_ck, s_acc);
 }
 
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -1151,8 +1162,9 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
     if (any_sw && precision == 1)
         hipLaunchKernelGGL(optics_sw32_kernel, dim3((unsigned)(blocks / 2)), dim3(OPT_THREADS), 0, stream, a);
-    else if (any_sw)
-        hipLaunchKernelGGL(optics_kernel, dim3((unsigned)blocks), dim3(OPT_THREADS), 0, stream, a);
+    else if (any_sw)   // one thread per cell
+        hipLaunchKernelGGL(optics_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                           stream, a);
     if (any_lw && precision == 1)
         hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
     else if (any_lw)   // one thread per cell
