@@ -83,6 +83,35 @@ def test_optics_giant_wet_particles(hip_lib, wa):
     assert got["tauaer1"][mask].max() > 1e-3
 
 
+def test_optics_strong_absorbers_take_the_downward_path(hip_lib, wa):
+    """The device carries the logarithmic derivative upward where x >= 0.3 and Im(m) x < 10 and falls back to the
+    oracle's downward recurrence elsewhere (4 checkpoints per thread: series beyond 64 terms take more passes).  Soot
+    in the coarse sections of every second column puts Im(m) x between 3 and 70 at the shortwave wavelengths and
+    around the limit in the longwave, next to ordinary aerosol in the same waves; both Maxwell-Garnett and volume
+    mixing."""
+    _init(wa, 8)
+    st = wa.synth.make_wrf_state(8, 5, 12, seed=20260360)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260361)
+    names = ms.names
+    dry = ["so4", "no3", "cl", "nh4", "na", "oin", "oc"]
+    for b in (5, 6, 7, 8):
+        bc = names.index(f"bc_a{b:02d}")
+        for sp in dry:
+            i = names.index(f"{sp}_a{b:02d}")
+            moved = 0.97 * ms.chem[i][:, :, ::2]
+            ms.chem[bc][:, :, ::2] += moved * 1.7 / wa.synth_mosaic.DENSITY[sp]   # same volume as soot
+            ms.chem[i][:, :, ::2] -= moved
+        w = names.index(f"water_a{b:02d}")
+        ms.chem[w][:, :, ::2] *= 0.05
+    mask = tile_mask(st, ms.alt.shape)
+    for opt, mix in ((1, 0), (2, 1)):
+        got = run_hip_optics(wa, st, ms, aer_op_opt=opt)
+        ref = run_oracle_optics(wa, st, ms, mix=mix)
+        _compare(got, ref, mask, RTOL)
+        w1 = got["waer1"][mask]
+        assert w1.min() < 0.6          # soot columns absorb
+
+
 def test_optics_real4_state(hip_lib, wa):
     _init(wa, 4)
     st = wa.synth.make_wrf_state(6, 4, 24, seed=20260330)
