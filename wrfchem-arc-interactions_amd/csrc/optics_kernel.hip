@@ -1032,19 +1032,21 @@ __device__ __forceinline__ void optics_body_sw32(const OpticsKernelArgs &a, doub
     }
 }
 
-__device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, double2 *s_ck)
+// one thread = one cell, the eight band pairs in a loop, the cell's 32 running sums (fp32) in the thread's LDS column
+__device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, double2 *s_ck, float *s_acc)
 {
-    constexpr int NW = OPT_NLW / 2;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, s = b >> 3;
-    const int gl = s / NW, slot = s - gl * NW;
-    const int w = OPT_NSW + 2 * slot, w2 = w + 1;
-    double2 *ck = s_ck + threadIdx.x;
-    const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
+    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
-    const int ib0 = w - OPT_NSW;
-    if (!(a.tauaerlw[ib0] || a.extaerlw[ib0] || a.tauaerlw[ib0 + 1] || a.extaerlw[ib0 + 1])) return;
+    unsigned want = 0;
+#pragma unroll
+    for (int p = 0; p < OPT_NLW / 2; ++p)
+        if (a.tauaerlw[2 * p] || a.extaerlw[2 * p] || a.tauaerlw[2 * p + 1] || a.extaerlw[2 * p + 1]) want |= 1u << p;
+    if (!want) return;
+    double2 *ck = s_ck + threadIdx.x;
+    float *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
+#pragma unroll
+    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = 0.f;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
@@ -1053,9 +1055,7 @@ __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, doub
     const int r4 = a.real4;
     const float alt = (float)ldr(a.alt, q, r4), dz = (float)ldr(a.dz8w, q, r4);
     const float pi = 3.14159265358979323846f;
-    const float rlam = rcpf((float)c_opt.wavelength_um[w]), rlam2 = rcpf((float)c_opt.wavelength_um[w2]);
     const float ralt = rcpf(alt);
-    float ext = 0.f, sca = 0.f, ext2 = 0.f, sca2 = 0.f;   // 1/cm
     for (int ib = 0; ib < a.nbin; ++ib) {
         float vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
         float vdry = 0.f;
@@ -1079,23 +1079,33 @@ __device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, doub
             num = vdry * 1.e-6f * rcpf((pi / 6.f) * dcm * dcm * dcm);
         }
         const float dwet = ddry * cbrtf(vwet * rcpf(vdry));
-        const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
-        // size parameters capped so that the series fits the register blocks (nstop <= 64); no aerosol reaches
-        // x = 47 at wavelengths >= 3.3 um (diameter 50 um)
-        const float x1 = fminf(pi * dwet * rlam, (float)OPT_XMAX32), x2 = fminf(pi * dwet * rlam2, (float)OPT_XMAX32);
-        const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
-        float qe, qs, qe2, qs2;
-        mie_pair32(t12, ck, qe, qs, qe2, qs2);
         const float dcm = dwet * 1.e-4f;
         const float cross = (num * ralt * 1.e-6f) * (0.25f * pi * dcm * dcm);   // #/cm3 * cm2
-        ext += cross * qe; sca += cross * qs;
-        ext2 += cross * qe2; sca2 += cross * qs2;
+#pragma unroll 1
+        for (int p = 0; p < OPT_NLW / 2; ++p) {
+            if (!((want >> p) & 1)) continue;
+            const int w = OPT_NSW + 2 * p, w2 = w + 1;
+            const float rlam = rcpf((float)c_opt.wavelength_um[w]), rlam2 = rcpf((float)c_opt.wavelength_um[w2]);
+            const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
+            // size parameters capped so that the series fits the register blocks (nstop <= 64); no aerosol reaches
+            // x = 47 at wavelengths >= 3.3 um (diameter 50 um)
+            const float x1 = fminf(pi * dwet * rlam, (float)OPT_XMAX32), x2 = fminf(pi * dwet * rlam2, (float)OPT_XMAX32);
+            const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
+            float qe, qs, qe2, qs2;
+            mie_pair32(t12, ck, qe, qs, qe2, qs2);
+            float *s = acc + (size_t)(4 * p) * OPT_THREADS;
+            s[0] += cross * qe;
+            s[OPT_THREADS] += cross * qs;
+            s[2 * OPT_THREADS] += cross * qe2;
+            s[3 * OPT_THREADS] += cross * qs2;
+        }
     }
-    const float ab = fmaxf(ext - sca, 0.f), ab2 = fmaxf(ext2 - sca2, 0.f);
-    if (a.tauaerlw[ib0]) str(a.tauaerlw[ib0], q, r4, (double)(ab * 100.f * dz));
-    if (a.extaerlw[ib0]) str(a.extaerlw[ib0], q, r4, (double)(ab * 1.e5f));
-    if (a.tauaerlw[ib0 + 1]) str(a.tauaerlw[ib0 + 1], q, r4, (double)(ab2 * 100.f * dz));
-    if (a.extaerlw[ib0 + 1]) str(a.extaerlw[ib0 + 1], q, r4, (double)(ab2 * 1.e5f));
+#pragma unroll 1
+    for (int ib = 0; ib < OPT_NLW; ++ib) {
+        const float ab = fmaxf(acc[(size_t)(2 * ib) * OPT_THREADS] - acc[(size_t)(2 * ib + 1) * OPT_THREADS], 0.f);
+        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, (double)(ab * 100.f * dz));
+        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, (double)(ab * 1.e5f));
+    }
 }
 
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_kernel(const OpticsKernelArgs a)
@@ -1123,7 +1133,8 @@ __global__ void __launch_bounds__(OPT_THREADS) optics_sw32_kernel(const OpticsKe
 __global__ void __launch_bounds__(OPT_THREADS) optics_lw32_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
-    optics_body_lw32(a, s_ck);
+    __shared__ float s_acc[2 * OPT_NLW * OPT_THREADS];
+    optics_body_lw32(a, s_ck, s_acc);
 }
 
 }  // namespace
@@ -1154,8 +1165,8 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     if (ncell <= 0) return hipSuccess;
     const long groups = (ncell + OPT_THREADS - 1) / OPT_THREADS;
     const long groups8 = (groups + 7) / 8;
-    const long blocks = groups8 * 8 * OPT_NSW, blocks_lw = groups8 * 8 * (OPT_NLW / 2);
-    if (blocks_lw > 0x7fffffffL) return hipErrorInvalidValue;
+    const long blocks = groups8 * 8 * OPT_NSW;   // the fp32 shortwave kernel: one workgroup per (cell group, wavelength pair)
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
     // skip a kernel none of whose outputs were asked for
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
@@ -1166,7 +1177,8 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
         hipLaunchKernelGGL(optics_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
                            stream, a);
     if (any_lw && precision == 1)
-        hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)blocks_lw), dim3(OPT_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                           stream, a);
     else if (any_lw)   // one thread per cell
         hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
                            stream, a);
