@@ -168,7 +168,7 @@ def test_config3_500x500x50_8bin(hip_lib, wa, sw_table_file, lw_table_file, monk
     night = np.random.default_rng(1).uniform(size=(500, 500)) < 0.1
     st.a2["xcoszen"] = np.where(night, -0.3, st.a2["xcoszen"])
     ch = Chain(wa, sw_table_file, lw_table_file, st, ms)
-    out = ch.run()          # default caps: 32 GiB (SW) / 8 GiB (LW) of scratch -> several column batches
+    out = ch.run()          # default caps (a third / a sixth of the device memory): one launch per kernel
     _properties(st, out)
     _compare_row(out, _oracle_first_row(wa, sw_table_file, lw_table_file, st, ms), st, 1e-8, 1e-8)
     # a different batching (more, smaller launches) gives the same bits

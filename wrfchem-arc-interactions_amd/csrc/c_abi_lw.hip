@@ -289,12 +289,17 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     if (a->lwupflx && !(a->lwupflxc && a->lwupflxcln && a->lwdnflx && a->lwdnflxc && a->lwdnflxcln))
         return failw(err, "rrtmg_hip_lwrad: the six flux profile arrays must be passed together");
 
-    // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB (default 8192) holds
+    // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB holds (default: a sixth of the
+    // device's memory -- 48 GiB on an MI355X; grow-only, smaller batches when the device cannot spare it)
     const int ncol = ni_t * nj_t;
     double *scratch = nullptr;
     int cap_cols = 0;
     {
         size_t mb = 8192;
+        {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) mb = (tot / 6) >> 20;
+        }
         if (const char *e = std::getenv("RRTMG_HIP_LW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;
@@ -305,10 +310,18 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         cap_cols = (size_t)ncol < cols ? ncol : (int)cols;
         std::lock_guard<std::mutex> lock(st.scratch_mutex);
         LwState::Scratch &w = st.scratch[stream];
+        if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
         if (w.doubles < percol * (size_t)cap_cols) {
             if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
             void *p = nullptr;
-            HIPCHK(hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double)));
+            hipError_t e = hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double));
+            while (e == hipErrorOutOfMemory && cap_cols > 8) {   // halve the batch until it fits (down to 8 columns)
+                (void)hipGetLastError();
+                cap_cols = cap_cols / 2 < 8 ? 8 : cap_cols / 2;
+                w.limit = percol * (size_t)cap_cols;
+                e = hipMalloc(&p, percol * (size_t)cap_cols * sizeof(double));
+            }
+            HIPCHK(e);
             w.p = static_cast<double *>(p);
             w.doubles = percol * (size_t)cap_cols;
         }

@@ -30,7 +30,7 @@ struct LwState {
     // Scratch between the two kernels (taug, frac, column record), one grow-only buffer per stream: calls
     // on one stream run in order and may share it, calls on different streams (the OpenMP tile loop of
     // DRV:975-982) must not.
-    struct Scratch { double *p = nullptr; size_t doubles = 0; };
+    struct Scratch { double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */ };
     std::map<void *, Scratch> scratch;
     std::mutex scratch_mutex;
 };
