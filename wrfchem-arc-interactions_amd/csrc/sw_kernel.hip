@@ -188,7 +188,8 @@ __device__ __forceinline__ double fsqrt(double x)
 
 // transmittance by lookup table or small-argument expansion (SW:8459-8466, 2575-2581).  The index arithmetic is kept
 // out of FMA contraction: the reference rounds 1e4*tblind before it adds 0.5.
-__device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze1)
+// ... in two halves: the table read goes out as soon as its argument is known, the value is picked where it is used
+__device__ __forceinline__ double exp_issue(const SwDeviceTables &tb, double ze1)
 {
     int itind;
     {
@@ -198,10 +199,14 @@ __device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze
         itind = (int)(x + 0.5);
     }
     itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
-    double tv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.exp_tbl) + (uint32_t)itind * 8u);
-    double sv = 1. - ze1 + 0.5 * ze1 * ze1;
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.exp_tbl) + (uint32_t)itind * 8u);
+}
+__device__ __forceinline__ double exp_pick(double ze1, double tv)
+{
+    const double sv = 1. - ze1 + 0.5 * ze1 * ze1;
     return ze1 <= 0.06 ? sv : tv;
 }
+__device__ __forceinline__ double exp_lookup(const SwDeviceTables &tb, double ze1) { return exp_pick(ze1, exp_issue(tb, ze1)); }
 
 struct RT {
     double ref, refd, tra, trad, dbt;
@@ -222,6 +227,11 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
     double zgamma2 = 3. * (zw * (1. - zg)) * 0.25;
     double zgamma3 = (2. - zg3 * prmuz) * 0.25;
     double zgamma4 = 1. - zgamma3;
+    // the table read of the general branch goes out in front of the branch (a lane on the conservative side does
+    // not use it): the quotient and the choice below then cover part of its latency
+    const double zrk = fsqrt(fmax(zgamma1 * zgamma1 - zgamma2 * zgamma2, 0.));
+    const double ze1 = fmin(zrk * zto1, 500.);
+    const double tv1 = exp_issue(tb, ze1);
     double zq = fdiv(zg, 1. - zg);
     double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
     if (zw >= zwcrit * denom) {   // zwo = zw/denom >= zwcrit, SW:2557-2560
@@ -240,7 +250,6 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
     } else {
         double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
         double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
-        double zrk = fsqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
         double zrp = zrk * prmuz;
         double zrp1 = 1. + zrp;
         double zrm1 = 1. - zrp;
@@ -255,7 +264,7 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
         double zt1 = zrp1 * (za1 + zrk * zgamma4);
         double zt2 = zrm1 * (za1 - zrk * zgamma4);
         double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-        double zem1 = exp_lookup(tb, fmin(zrk * zto1, 500.));
+        double zem1 = exp_pick(ze1, tv1);
         double zemm = zem1 * zem1;
         double D = zr4 + zr5 * zemm;                 // zdenr * zem1
         double rD = frcp1(D);
@@ -590,6 +599,69 @@ __device__ __forceinline__ void layer_rt_clean(const SwDeviceTables &tb, double 
     const double zomcc = fdiv(taur, ztauc);
     o.dbt = exp_lookup(tb, ztauc * rprmu0);
     reftra_clean(tb, ztauc, zomcc, prmu0, o.dbt, o);
+}
+// ... with its two table reads issued ahead (right after the gas optics, in front of the stream with aerosol, whose
+// arithmetic then covers their latency): the arguments and the raw table values travel to the finishing half
+struct CleanPre { double e_1, tv_dbt, tv_1; };   // (the direct-beam argument is a sum and a product: formed again)
+__device__ __forceinline__ CleanPre layer_rt_clean_issue(const SwDeviceTables &tb, double taug, double taur, double rprmu0)
+{
+    CleanPre p;
+    const double ztauc = taur + taug;
+    const double zw = fdiv(taur, ztauc);
+    p.tv_dbt = exp_issue(tb, ztauc * rprmu0);
+    const double zgamma1 = (8. - zw * 5.) * 0.25, zgamma2 = 3. * zw * 0.25;
+    const double zrk = fsqrt(fmax(zgamma1 * zgamma1 - zgamma2 * zgamma2, 0.));   // unused where zw >= zwcrit
+    p.e_1 = fmin(zrk * ztauc, 500.);
+    p.tv_1 = exp_issue(tb, p.e_1);
+    return p;
+}
+__device__ __forceinline__ void layer_rt_clean_finish(double taug, double taur, double prmuz, double rprmu0,
+                                                      const CleanPre &p, RT &o)
+{
+    const double zto1 = taur + taug;
+    const double zw = fdiv(taur, zto1);
+    const double zem2 = exp_pick(zto1 * rprmu0, p.tv_dbt);
+    o.dbt = zem2;
+    // reftra_clean with the exponential of zrk * zto1 from the issued read
+    const double eps = 1.e-08, zwcrit = 0.9999995;
+    const double zgamma1 = (8. - zw * 5.) * 0.25;
+    const double zgamma2 = 3. * zw * 0.25;
+    if (zw >= zwcrit) {
+        const double za1 = zgamma1 * prmuz - 0.5;
+        const double zgt = zgamma1 * zto1;
+        const double rg = frcp1(1. + zgt);
+        const double r = (zgt - za1 * (1. - zem2)) * rg;
+        const double rd = zgt * rg;
+        const bool one = (zem2 == 1.0);
+        o.ref = one ? 0.0 : r;
+        o.tra = one ? 1.0 : 1. - r;
+        o.refd = one ? 0.0 : rd;
+        o.trad = one ? 1.0 : 1. - rd;
+    } else {
+        const double za = 0.5 * (zgamma1 + zgamma2);
+        const double zrk = fsqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+        const double zrp = zrk * prmuz;
+        const double zrp1 = 1. + zrp, zrm1 = 1. - zrp;
+        const double zrk2 = 2. * zrk;
+        const double zrpp = 1. - zrp * zrp;
+        const double zrkg = zrk + zgamma1;
+        const double hp = za + 0.5 * zrk, hm = za - 0.5 * zrk;
+        const double zr1 = zrm1 * hp, zr2 = zrp1 * hm, zr3 = zrk2 * (0.5 - za * prmuz);
+        const double zr4 = zrpp * zrkg, zr5 = zrpp * (zrk - zgamma1);
+        const double zt1 = zrp1 * hp, zt2 = zrm1 * hm, zt3 = zrk2 * (0.5 + za * prmuz);
+        const double zem1 = exp_pick(p.e_1, p.tv_1);
+        const double zemm = zem1 * zem1;
+        const double D = zr4 + zr5 * zemm;
+        const double rD = frcp1(D);
+        const bool small = fabs(D) <= eps * zem1;
+        const double r = zw * (zr1 - zr2 * zemm - zr3 * (zem2 * zem1)) * rD;
+        const double t = zem2 - zw * (zem2 * (zt1 - zt2 * zemm) - zt3 * zem1) * rD;
+        o.ref = small ? eps : r;
+        o.tra = small ? zem2 : t;
+        const double zdend = frcp1(zrkg - (zgamma1 - zrk) * zemm);
+        o.refd = zgamma2 * (1. - zemm) * zdend;
+        o.trad = zrk2 * zem1 * zdend;
+    }
 }
 
 // Two-stream properties of a stack of layers under a direct beam from above: reflectance to the beam (ref) and to
@@ -1158,6 +1230,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                     if (b) bad = b;
                 }
             }
+            // the cheap form of the S stream needs ta = 0 and no cloudy lane in this layer (wave-uniform choice); its two
+            // table reads go out here, in front of the P stream
+            const bool s_general = s_aer || (CLOUD && s_mask && __any(cloudy));
+            CleanPre cpre = {0., 0., 0.};
+            if (hasS && !s_general) cpre = layer_rt_clean_issue(tb, taug, taur, rprmu0);
             RT rtp;
             if (hasP) {
                 if ((k & (BLK - 1)) == 0) {
@@ -1178,13 +1255,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             if (hasS) {
                 gas_fetch(tb, c, L, kn, kn < laytrop, gp);
                 RT rt;
-                // the cheap form needs ta = 0 and no cloudy lane in this layer (wave-uniform choice)
-                const bool general = s_aer || (CLOUD && s_mask && __any(cloudy));
-                if (general) {
+                if (s_general) {
                     double dnl;
                     layer_rt(false, tb, taug, taur, s_aer ? ta : 0.0, wa, ga, prmu0, rprmu0, cloudy && s_mask, cl, rt, dnl);
                 } else {
-                    layer_rt_clean(tb, taug, taur, prmu0, rprmu0, rt);
+                    layer_rt_clean_finish(taug, taur, prmu0, rprmu0, cpre, rt);
                 }
                 add_on_top(st, rt);
             }
