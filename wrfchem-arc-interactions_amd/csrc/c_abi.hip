@@ -315,10 +315,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     {
         const int ncol_all = ni_t * nj_t;
         size_t mb = 32768;
-        {
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) mb = (tot / 3) >> 20;
-        }
+        if (const size_t tot = device_total_bytes()) mb = (tot / 3) >> 20;
         if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;

@@ -296,10 +296,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     int cap_cols = 0;
     {
         size_t mb = 8192;
-        {
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) mb = (tot / 6) >> 20;
-        }
+        if (const size_t tot = device_total_bytes()) mb = (tot / 6) >> 20;
         if (const char *e = std::getenv("RRTMG_HIP_LW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;

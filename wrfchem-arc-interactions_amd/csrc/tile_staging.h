@@ -16,6 +16,20 @@
 
 namespace rrtmg {
 
+// total memory of the device the engine runs on (asked once: the scratch caps of the two radiation entry points are
+// fractions of it)
+inline size_t device_total_bytes()
+{
+    static std::mutex m;
+    static size_t cached = 0;
+    std::lock_guard<std::mutex> lock(m);
+    if (!cached) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) cached = tot;
+    }
+    return cached;
+}
+
 struct TileGeom {
     int ni_m, nk_m, nj_m;   // memory extents of the caller's arrays (ims:ime, kms:kme, jms:jme)
     int i0, j0;             // tile origin inside memory (its - ims, jts - jms)
