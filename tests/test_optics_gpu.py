@@ -112,6 +112,38 @@ def test_optics_strong_absorbers_take_the_downward_path(hip_lib, wa):
         assert w1.min() < 0.6          # soot columns absorb
 
 
+def test_optics_longwave_fallback_with_a_replaced_material_table(hip_lib, wa):
+    """A material table handed over at init with a strongly absorbing "dust" (Im m = 2.5 in every longwave band) and
+    coarse sections swollen to tens of micrometres: Im(m) x exceeds 10 for most coarse particles, so the longwave
+    kernel leaves the upward recurrence and takes its downward fallback (two checkpoints per thread: series beyond
+    32 terms run in segments), next to ordinary particles in the same waves."""
+    wl, ref, den = wa.engine_optics.table_info()
+    ref = ref.copy()
+    oin = 5
+    ref[oin, 4:, 0] = 2.2
+    ref[oin, 4:, 1] = 2.5
+    try:
+        wa.engine_optics.optics_init(8, refindex=ref, density=den, device=0)
+        st = wa.synth.make_wrf_state(6, 4, 10, seed=20260370)
+        ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260371)
+        names = ms.names
+        rng = np.random.default_rng(20260372)
+        for b in (6, 7, 8):
+            for sp in ("so4", "no3", "cl", "nh4", "na", "oc", "bc"):
+                i = names.index(f"{sp}_a{b:02d}")
+                moved = 0.9 * ms.chem[i][:, :, ::2]
+                ms.chem[names.index(f"oin_a{b:02d}")][:, :, ::2] += moved * 2.6 / wa.synth_mosaic.DENSITY[sp]
+                ms.chem[i][:, :, ::2] -= moved
+            w = names.index(f"water_a{b:02d}")
+            ms.chem[w] *= 10.0 ** rng.uniform(0.0, 1.5, size=ms.chem[w].shape)
+        got = run_hip_optics(wa, st, ms)
+        ref_out = run_oracle_optics(wa, st, ms)      # the oracle reads the engine's table
+        _compare(got, ref_out, tile_mask(st, ms.alt.shape), RTOL)
+        assert got["tauaerlw16"][tile_mask(st, ms.alt.shape)].max() > 1e-3
+    finally:
+        wa.engine_optics.optics_init(8, device=0)    # the built-in table again
+
+
 def test_optics_real4_state(hip_lib, wa):
     _init(wa, 4)
     st = wa.synth.make_wrf_state(6, 4, 24, seed=20260330)

@@ -309,7 +309,7 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
 // ... as a real function call, for the longwave kernel: there only particles beyond any aerosol size come here, and
 // inlined twice (one per band of the pair) the code raises the register pressure of the whole kernel
 struct MieQ2 { double qext, qsca; };
-constexpr int OPT_NCK_LW = 4;   // checkpoint slots per thread of the longwave kernel (segments of 64 terms)
+constexpr int OPT_NCK_LW = 2;   // checkpoint slots per thread of the longwave kernel (segments of 32 terms; 36 KB of LDS with the sums: four workgroups per CU with room to spare)
 __device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck)
 {
     double qe, qs, g, b;
