@@ -199,6 +199,9 @@ __device__ __forceinline__ double exp_issue(const SwDeviceTables &tb, double ze1
         itind = (int)(x + 0.5);
     }
     itind = itind < 0 ? 0 : (itind > NTBL ? NTBL : itind);
+    // a lane that will take the small-argument expansion does not use the entry: let it read entry 0, so that the
+    // gather of the wave touches fewer cache lines
+    itind = ze1 <= 0.06 ? 0 : itind;
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(tb.exp_tbl) + (uint32_t)itind * 8u);
 }
 __device__ __forceinline__ double exp_pick(double ze1, double tv)
