@@ -7,7 +7,12 @@ north-star target is quoted on, BASELINE.json configs[3]: 500x500x50, MOSAIC 8-b
 `--config 1|2|4` select the other BASELINE configurations (1: 200x200x40 SW only, 2: 200x200x40 4-bin SW+LW,
 4: 1000x1000x60 mixed-precision optics); `--ni/--nj/--nk/--nbin/--mode/--optics-precision` override single items.
 
-With --gpus N (one rank per GPU, launched by torch.distributed.run) the SAME domain is cut into N j-slabs
+With --gpus N the SAME domain is cut into N j-slabs, one rank per GPU.  `python3 bench.py --gpus N` starts its own
+ranks: when no launcher environment is present (WORLD_SIZE unset) the parent -- before anything touches the GPU --
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (never an exec), relays
+its output and exit code.  Launched by torch.distributed.run directly (RANK/LOCAL_RANK/WORLD_SIZE set) it is a rank.
+`--dry-launch` walks the same launch path without a GPU (gloo): every rank reports its slab, rank 0 prints them.
+The domain is cut
 (tiles.slab_bounds, weighted by the cost of a row when --night > 0; reference tile model DRV:975-982): every rank builds
 only its slab, there is no data-path collective, and the one exchange is an all-reduce (RCCL) of the 32 per-tile flux
 sums -- "scaling": "strong".  `--scaling weak` gives every rank its own full domain instead.
@@ -258,6 +263,70 @@ def algorithmic_flops(wa, tab_sw, tab_lw, st, ms, mode, ncols=16):
     return flopcount.per_column(wa, tab_sw, tab_lw, st, ms, mode, ncols)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Parent of `python3 bench.py --gpus N`: starts the N ranks as a child process group through
+    torch.distributed.run (one rank per GPU of this node, rendezvous on 127.0.0.1) and returns its exit code.  The
+    parent has not imported torch or touched the GPU, and it does not exec: the ranks' stdout / stderr are inherited,
+    so rank 0's JSON line is this command's output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL (see README)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, cfg, world, rank):
+    """The launch path without a GPU: rendezvous over gloo, the slab of every rank (same cut rule as the timed path),
+    one all-reduce of the 32-vector in which every rank has put its column count, one JSON line on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    tiles = import_module("wrfchem-arc-interactions_amd.tiles")
+    ni, nj = cfg["ni"], cfg["nj"]
+    if world > 1:
+        dist.init_process_group("gloo")
+    night = night_rows(ni, nj, 20260009, args.night)
+    weights = None
+    if args.night > 0 and args.scaling == "strong":
+        weights = slab_row_cost(cfg["mode"]) * ni + SW_MS * (~night).sum(axis=1)
+    if args.scaling == "strong" or world == 1:
+        js, je = tiles.slab_bounds(1, nj, world, rank, weights=weights)
+    else:
+        js, je = 1, nj
+    mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "js": js, "je": je,
+            "columns": max(0, je - js + 1) * ni}
+    sums = torch.zeros(32, dtype=torch.float64)
+    sums[13] = mine["columns"]
+    tiles.allreduce_sums(sums)
+    slabs = [mine]
+    if world > 1:
+        slabs = [None] * world
+        dist.all_gather_object(slabs, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "scaling": args.scaling if world > 1 else "strong",
+                          "domain": [ni, nj, cfg["nk"]], "slabs": slabs, "columns_all_ranks": float(sums[13])}))
+
+
+# shares of the step measured at the north-star workload (ms per 250 000 columns): they weight the rows of a slab
+OPT_MS, LW_MS, SW_MS = 94.0, 59.0, 47.0
+
+
+def slab_row_cost(mode):
+    """Cost of a column that every column pays (longwave call, optical averaging); the shortwave call is paid by
+    daylit columns only."""
+    return (LW_MS if mode != "sw" else 0.0) + (OPT_MS if mode == "full" else 0.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +352,14 @@ def main():
     ap.add_argument("--host-path-rows", type=int, default=40,
                     help="rows of the domain pushed through the mem = 0 (host pointer) entry points; 0 = skip")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch path only (no GPU, gloo): every rank computes its slab, rank 0 prints them as JSON")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: this process only starts the ranks
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     cfg = dict(CONFIGS[args.config])
     for k, a in (("ni", args.ni), ("nj", args.nj), ("nk", args.nk), ("mode", args.mode), ("nbin", args.nbin),
                  ("prec", args.optics_precision)):
@@ -292,15 +368,18 @@ def main():
     ni, nj, nk, mode, nbin, prec = cfg["ni"], cfg["nj"], cfg["nk"], cfg["mode"], cfg["nbin"], cfg["prec"]
     is_config = all(cfg[k] == v for k, v in CONFIGS[args.config].items())
 
-    import torch
-    import torch.distributed as dist
-    import wrfchem_arc_amd as wa
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.dry_launch:
+        return dry_launch(args, cfg, world, rank)
+
+    import torch
+    import torch.distributed as dist
+    import wrfchem_arc_amd as wa
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -331,11 +410,10 @@ def main():
     if strong:
         night = night_rows(ni, nj, nseed, args.night)                   # cheap: any rank evaluates every row
         # cost of a row: every column pays the longwave call and the optics, only daylit columns the shortwave call
-        # (shares of the step measured at this workload: optics 94 ms, LW 59 ms, SW 47 ms per 250 000 columns)
+        # (OPT_MS / LW_MS / SW_MS above)
         weights = None
         if args.night > 0:
-            per_col = (59.0 if do_lw else 0.0) + (94.0 if do_opt else 0.0)
-            weights = per_col * ni + 47.0 * (~night).sum(axis=1)
+            weights = slab_row_cost(mode) * ni + SW_MS * (~night).sum(axis=1)
         js, je = wa.tiles.slab_bounds(1, nj, world, rank, weights=weights)   # WRF indices, inclusive
         j0, j1 = js - 1, je
     else:

@@ -159,3 +159,35 @@ def test_strong_scaling_slabs_reduce_to_the_single_process_sums(wa, sw_table_fil
     ref = wa.tiles.tile_sums_host(full, wa.tiles.SW12, 1, ni, 1, nj)
     np.testing.assert_allclose(v0[:13], ref[:13], rtol=1e-13, atol=1e-9)
     assert v0[13] == ni * nj
+
+
+def test_bench_starts_its_own_ranks_dry():
+    """`python3 bench.py --gpus 2` is how the driver starts a scaling run: with no launcher environment the parent
+    must start the ranks itself (child process, torch.distributed.run, rendezvous on 127.0.0.1) and relay rank 0's
+    line and the exit code.  --dry-launch walks that path without a GPU: gloo, slab of each rank, one all-reduce."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--night", "0.1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == 2 and out["scaling"] == "strong"
+    s0, s1 = out["slabs"]
+    assert (s0["rank"], s1["rank"]) == (0, 1) and (s0["local_rank"], s1["local_rank"]) == (0, 1)
+    assert s0["js"] == 1 and s1["js"] == s0["je"] + 1 and s1["je"] == 500      # disjoint, ordered, covering
+    assert out["columns_all_ranks"] == 250000.0 == s0["columns"] + s1["columns"]
+    # one rank: no launcher, same line shape
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-launch", "--config", "2"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["slabs"][0]["columns"] == 40000
+    # a failing rank's exit code comes back through the parent (no GPU here: the ranks refuse to run)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
+                       capture_output=True, text=True, env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""), timeout=300)
+    assert r.returncode != 0
