@@ -386,6 +386,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # one launch per kernel for the whole domain: an explicit opt-in (the engine's default scratch caps are modest,
+    # 32 / 16 GiB and at most a quarter of the free memory; larger tiles then run in column batches)
+    os.environ.setdefault("RRTMG_HIP_SW_SCRATCH_MB", "98304")
+    os.environ.setdefault("RRTMG_HIP_LW_SCRATCH_MB", "49152")
     import __graft_entry__ as ge
     if not os.path.exists(wa.engine.LIB_PATH):
         ge.build_product()

@@ -309,13 +309,12 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                       a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
         return fail(err, "rrtmg_hip_swrad: the twelve TOA/surface flux arrays must be passed together");
 
-    // scratch of this stream: as many columns per launch as RRTMG_HIP_SW_SCRATCH_MB holds (default: a third of the
-    // device's memory -- 96 GiB on an MI355X, one launch for 300 000 columns; the buffer only grows to what the
-    // largest tile so far needed, and a device that cannot spare it gets smaller batches)
+    // scratch of this stream: as many columns per launch as RRTMG_HIP_SW_SCRATCH_MB holds (default: 32 GiB, at most a
+    // quarter of the device's free memory; the buffer only grows to what the largest tile so far needed, and a
+    // device that cannot spare it gets smaller batches)
     {
         const int ncol_all = ni_t * nj_t;
-        size_t mb = 32768;
-        if (const size_t tot = device_total_bytes()) mb = (tot / 3) >> 20;
+        size_t mb = default_scratch_mb(32768);
         if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;

@@ -289,14 +289,13 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     if (a->lwupflx && !(a->lwupflxc && a->lwupflxcln && a->lwdnflx && a->lwdnflxc && a->lwdnflxcln))
         return failw(err, "rrtmg_hip_lwrad: the six flux profile arrays must be passed together");
 
-    // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB holds (default: a sixth of the
-    // device's memory -- 48 GiB on an MI355X; grow-only, smaller batches when the device cannot spare it)
+    // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB holds (default: 16 GiB, at most a
+    // quarter of the device's free memory; grow-only, smaller batches when the device cannot spare it)
     const int ncol = ni_t * nj_t;
     double *scratch = nullptr;
     int cap_cols = 0;
     {
-        size_t mb = 8192;
-        if (const size_t tot = device_total_bytes()) mb = (tot / 6) >> 20;
+        size_t mb = default_scratch_mb(16384);
         if (const char *e = std::getenv("RRTMG_HIP_LW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;

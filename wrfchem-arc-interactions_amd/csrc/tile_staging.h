@@ -16,18 +16,24 @@
 
 namespace rrtmg {
 
-// total memory of the device the engine runs on (asked once: the scratch caps of the two radiation entry points are
-// fractions of it)
-inline size_t device_total_bytes()
+// default cap (MiB) of a radiation entry point's layer scratch: a modest fixed size, and never more than a quarter of
+// what the device has FREE at the first call (other tenants -- a framework's allocator, other ranks, other streams --
+// keep their room).  One launch per kernel for a very large tile is an explicit opt-in through
+// RRTMG_HIP_SW_SCRATCH_MB / RRTMG_HIP_LW_SCRATCH_MB (bench.py sets them); larger tiles otherwise run in column batches.
+inline size_t default_scratch_mb(size_t modest_mb)
 {
     static std::mutex m;
-    static size_t cached = 0;
-    std::lock_guard<std::mutex> lock(m);
-    if (!cached) {
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) cached = tot;
+    static size_t free_at_first_call = 0;   // asked once per process
+    {
+        std::lock_guard<std::mutex> lock(m);
+        if (!free_at_first_call) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return modest_mb; }
+            free_at_first_call = fr ? fr : 1;
+        }
     }
-    return cached;
+    const size_t quarter = (free_at_first_call / 4) >> 20;
+    return quarter < modest_mb ? (quarter > 64 ? quarter : 64) : modest_mb;
 }
 
 struct TileGeom {
