@@ -21,9 +21,11 @@ struct LwKernelArgs {
     void *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;
     int *status;
     // scratch between the gas-optics kernel and the transfer kernel, per column slot of the batch:
-    // taug / frac [slot][layer][140]; rec [slot][lw_rec_doubles(nlayers)]
+    // taug / frac [slot][band][layer][ig] (band-major: the band's block starts at nlayers * g0(band), a layer's row
+    // of the band's ng g-points is contiguous, consecutive layers follow each other); rec [slot][lw_rec_doubles(nlayers)]
     double *taug, *frac, *rec;
     int col0;                           // first tile column of this batch
+    int nbatch;                         // columns of this batch
     // clouds (icloud != 0), as in SwKernelArgs
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
     int f_ice_phy, fer_hires;            // "MP option 5" split of snow; Ferrier-Aligo (qi3d = all frozen water)
@@ -49,6 +51,7 @@ inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_
 
 size_t lw_gas_lds_bytes(int nlayers);
 size_t lw_rt_lds_bytes(int nlayers, bool cloud = true);
+size_t lw_rt_fast_lds_bytes(int nlayers, bool cloud = true);   // the two-column kernel of calls without flux profiles
 hipError_t lw_upload_constants(const double *preflog, const double *tref);
 hipError_t lw_upload_segments(const LwGDesc *gdesc);   // [LW_NGPT] host descriptors
 // runs ncol columns in batches of at most cap_cols through the two kernels; `scratch` holds

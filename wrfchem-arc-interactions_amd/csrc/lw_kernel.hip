@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "lw_common.h"
 #include "lw_kernel.h"
@@ -1030,9 +1032,10 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             const int k = act ? kb + dk : kend - 1;
             double taug, plfrac;
             gas_optics(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
-            if (act) {
-                tg[(size_t)k * LW_NGPT + g0 + G.ig] = taug;
-                fr[(size_t)k * LW_NGPT + g0 + G.ig] = plfrac;
+            if (act) {   // band-major scratch [band][layer][ig]: an item's lanes store one contiguous run
+                const size_t q = (size_t)nl * g0 + (size_t)k * ng + G.ig;
+                tg[q] = taug;
+                fr[q] = plfrac;
             }
         }
     }
@@ -1085,7 +1088,10 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const double wgt = active ? 0.5 * gd->delwave : 0.;   // wtdiff * delwave(iband), LW:3366-3371
     const bool clean_on = a.clean > 0;
     const int nlev = nl + 1;
-    const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    // scratch of the column, band-major: [band][layer][ig] (lw_kernel.h)
+    const int ng = gd->ng;
+    const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
+    const double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
     const double secdiff = c.secdiff[band];
     double *fl = c.flux + (size_t)wave * nslot * nlev;   // down clean, down total, up clean, up total, down clear, up clear
@@ -1137,10 +1143,10 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
     bool iclddn = false;
     if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; if (nslot == 6) fl[4 * nlev + nl] = 0.; }
-    double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
+    double tnext = tg[(size_t)(nl - 1) * ng], fnext = fr[(size_t)(nl - 1) * ng];
     for (int k = nl - 1; k >= 0; --k) {
         const double taug = tnext, plfrac = fnext;
-        if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
+        if (k > 0) { tnext = tg[(size_t)(k - 1) * ng]; fnext = fr[(size_t)(k - 1) * ng]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
@@ -1199,7 +1205,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     // ---- upward sweep (surface -> top), LW:3331-3356 ----
     for (int k = 0; k < nl; ++k) {   // tnext / fnext hold layer 0 after the downward sweep
         const double taug = tnext, plfrac = fnext;
-        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
+        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * ng]; fnext = fr[(size_t)(k + 1) * ng]; }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
@@ -1287,55 +1293,104 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
 // SAME top-down sweep from the linearity of the upward recurrence (LW:3331-3356):
 //     radlu(top) = radlu(0) * prod_k (1 - A_k) + sum_k S_k * prod_{j > k} (1 - A_j)
 // with (A_k, S_k) = (atrans, bbugas*atrans) of a clear layer or (atrans + efclfrac*(1 - atrans), gassrc +
-// cldfmc*(bbutot*atot - gassrc)) of a cloudy one.  The upward sweep is left with one stream, and the spectral sums
-// (LW:3366-3377) are taken four levels at a time.
-template <bool DEEP>
+// cldfmc*(bbutot*atot - gassrc)) of a cloudy one.  The upward sweep is left with one stream, and it evaluates no
+// layer optics of its own: the downward sweep leaves (A_k, bbu_k) -- (A_k, S_k) in a cloudy layer -- of the call with
+// aerosol in the scratch slots the gas optics occupied (same bytes), and the way up is one relaxation per layer.
+// The spectral sums (LW:3366-3377) are taken four levels at a time.
+//
+// THREE columns per workgroup of eight waves.  A column's 140 g-points are five chunks of 28; a chunk sits on the
+// lower or the upper half of a wave (lanes 0..27 / 32..59), so 3 x 5 = 15 of the workgroup's 16 half-wave seats are
+// taken and 52.5 of 64 lanes work (a column alone on three waves: 47; two columns on five waves: 56, but a five-wave
+// workgroup puts two of its waves on one SIMD and only two such workgroups fit a CU -- measured 2.05 waves per SIMD).
+// Every spectral sum is taken per chunk, i.e. per half wave, and the five chunk sums of a column are added in chunk
+// order: a column's sums are formed the same way whichever seats it has (results do not depend on the tiling).
+// What the upward sweep works from: the (A, S) pairs the downward sweep stored in the scratch slots of the gas optics
+// (true: no second evaluation of the layer optics, but 2 x 35 GB more HBM traffic per 250 000 columns x 63 layers -- the
+// kernel then runs at the memory system's pace: measured 33.8 ms), or the gas optics read a second time with the
+// layer optics evaluated again (false: 4.4 G more wave-instructions, 49 GB less traffic).
+constexpr bool RTF_STORE_UP = false;
+constexpr int RTF_COLS = 3, RTF_WAVES = 8, RTF_THREADS = RTF_WAVES * 64, RTF_CHUNK = 28, RTF_NCHUNK = 5;
+static_assert(RTF_CHUNK * RTF_NCHUNK == LW_NGPT, "chunks must tile the g-points");
+
+// LDS per column: the in-cloud state of the column (McICA instantiations only) and the flux slots of its five chunks.
+// The per-band arrays of the column record (Planck functions, aerosol optical depth) are NOT staged: the lanes of a
+// band read the same address, a wave's load touches a handful of lines that the workgroup's other waves find in L1,
+// and without them two workgroups fit a CU whatever the layer count (staged, 3 x 25 KB at 63 layers left one).
+__host__ __device__ inline size_t rtf_cloud_doubles(int nl) { return (size_t)10 * nl + 4; }
+__host__ __device__ inline size_t rtf_col_doubles(int nl, bool cloud)
+{
+    return (cloud ? rtf_cloud_doubles(nl) : 0) + (size_t)RTF_NCHUNK * (2 * (nl + 1) + 8);
+}
+
+// sums of four values over each HALF of the wave: afterwards lane 16 r (r = 0..3) of qa holds the sum of v[r & 1] over
+// half r >> 1 (lanes 0..31 / 32..63), and of qb that of v[2 + (r & 1)].  The two halves are reduced by the same tree.
+__device__ __forceinline__ void half_sum4(double v0, double v1, double v2, double v3, double &qa, double &qb)
+{
+    double x = fold16(v0, v1), y = fold16(v2, v3);   // rows: v0 low half, v1 low half, v0 high half, v1 high half
+    x = dpp_add<0x140>(x); y = dpp_add<0x140>(y);   // row_mirror
+    x = dpp_add<0x141>(x); y = dpp_add<0x141>(y);   // row_half_mirror
+    x = dpp_add<0x4E>(x); y = dpp_add<0x4E>(y);     // quad_perm [2,3,0,1]
+    x = dpp_add<0xB1>(x); y = dpp_add<0xB1>(y);     // quad_perm [1,0,3,2]
+    qa = x; qb = y;
+}
+
+template <bool DEEP, bool CLOUD>   // CLOUD: McICA (icloud != 0); the cloud-free instantiation carries none of it
 __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 {
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
-    const int slot = batch_slot();
-    const int col = a.col0 + slot;
-    const bool cloud = a.icloud != 0;
-    LCol c = carve_rt(lds, nl, cloud);
-    {
-        const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
-        const int n = (int)(cloud ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
-        for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
-    }
-    const double *cb = lds + lw_rec_base_doubles(nl);
-    __shared__ unsigned long long s_lmask[2];
-    __shared__ unsigned long long s_cmhi[LW_THREADS];
-    if (tid == 0) { s_lmask[0] = 0ull; s_lmask[1] = 0ull; }
-    const int it = col % a.ni_t, jt = col / a.ni_t;
-    const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
-    const size_t i2 = j0 * a.ni_m + i0;
-    const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
-    const size_t base3 = j0 * sj + k0 * sk + i0;
-    const int r4 = a.real4;
-    const double semiss = ldr(a.emiss, i2, r4);
+    const int grp = batch_slot();
+    constexpr bool cloud = CLOUD;
+    const int ncols = a.nbatch - RTF_COLS * grp < RTF_COLS ? a.nbatch - RTF_COLS * grp : RTF_COLS;   // 1..3
+    const size_t recn = cloud ? rtf_cloud_doubles(nl) : 0;   // staged part of the record
+    const size_t cold = rtf_col_doubles(nl, cloud);
+    if (cloud)
+        for (int cc = 0; cc < ncols; ++cc) {
+            const double *rec = a.rec + (size_t)(RTF_COLS * grp + cc) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl);
+            double *dst = lds + cc * cold;
+            for (int q = tid; q < (int)recn; q += RTF_THREADS) dst[q] = rec[q];
+        }
+    __shared__ unsigned long long s_lmask[RTF_COLS][2];     // [column][layers 0..63, 64..127]
+    __shared__ unsigned long long s_cmhi[RTF_THREADS];
+    if (tid < 2 * RTF_COLS) s_lmask[tid >> 1][tid & 1] = 0ull;
 
-    const int gbeg = wave * LW_CHUNK;
-    const int gcnt = (LW_NGPT - gbeg) < LW_CHUNK ? (LW_NGPT - gbeg) : LW_CHUNK;
-    const bool active = lane < gcnt;
-    const int g = gbeg + (active ? lane : gcnt - 1);
+    // this lane's seat: half wave -> (column, chunk); lanes 28..31 of a half and the 16th seat are idle
+    const int seat = 2 * wave + (lane >> 5), l32 = lane & 31;
+    const int scol = seat / RTF_NCHUNK, chunk = seat - scol * RTF_NCHUNK;
+    const bool seat_on = scol < ncols;                        // uniform over the half wave
+    const bool live = seat_on && l32 < RTF_CHUNK;             // a lane with a g-point of an existing column
+    const int colsel = seat_on ? scol : 0;                    // idle seats shadow column 0 (no stores, nothing summed)
+    const int g = chunk * RTF_CHUNK + (l32 < RTF_CHUNK ? l32 : RTF_CHUNK - 1);
+    const int slot = RTF_COLS * grp + colsel;
+    const int col = a.col0 + slot;
+    const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: planklay planklev taua secdiff plankbnd pz
+    const double *cb = lds + colsel * cold;
+    const int r4 = a.real4;
+    double semiss;
+    {
+        const int it = col % a.ni_t, jt = col / a.ni_t;
+        const size_t i2 = (size_t)(a.jts - a.jms + jt) * a.ni_m + (size_t)(a.its - a.ims + it);
+        semiss = ldr(a.emiss, i2, r4);
+    }
     const LwGDesc *gd = tb.gdesc + g;
-    const int band = gd->band;
-    const double wgt = active ? 0.5 * gd->delwave : 0.;
+    const int band = gd->band, ng = gd->ng;
+    const double wgt = live ? 0.5 * gd->delwave : 0.;
     // the clean-sky call differs from the one with aerosol only if there is aerosol; without it the reference's
     // two calls are the same arithmetic on the same numbers, and the outputs are copies
     const bool clean_on = a.clean > 0, clean_own = clean_on && a.aer_ra_feedback == 1;
     const int nlev = nl + 1;
-    const double *tg = a.taug + (size_t)slot * nl * LW_NGPT + g, *fr = a.frac + (size_t)slot * nl * LW_NGPT + g;
+    // scratch of the column, band-major: [band][layer][ig] (lw_kernel.h)
+    const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
+    double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
-    const double secdiff = c.secdiff[band];
-    // per wave: downward and upward flux of the call with aerosol at every level, then the small sums
+    // per chunk: downward and upward flux of the call with aerosol at every level, then the small sums
     // [0..2] clean sky: surface down, surface up, top up; [4..6] clear sky alike
-    double *fl = c.flux + (size_t)wave * (2 * nlev + 8);
-    double *fsum = fl + 2 * nlev;
-    const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
+    const size_t ws = 2 * nlev + 8;
+    double *const fl = lds + colsel * cold + recn + (size_t)chunk * ws;   // this seat's slots
+    const double *pl = rec + band * nl, *pv = rec + LW_NBND * nl + band * nlev, *ta = rec + LW_NBND * (nl + nlev) + band * nl;
+    const double secdiff = rec[LW_NBND * (2 * nl + nlev) + band], plankbnd = rec[LW_NBND * (2 * nl + nlev) + LW_NBND + band];
 
     uint64_t cmask = 0;
     constexpr bool deep = DEEP;
@@ -1359,46 +1414,52 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             }
             prev = cur;
         }
-        uint64_t m = active ? cmask : 0;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
-        if (lane == 0 && m) atomicOr(&s_lmask[0], (unsigned long long)m);
+        if (live && cmask) atomicOr(&s_lmask[colsel][0], (unsigned long long)cmask);
         if (deep) {
             s_cmhi[tid] = cmhi;
-            m = active ? cmhi : 0;
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) m |= __shfl_xor(m, s, 64);
-            if (lane == 0 && m) atomicOr(&s_lmask[1], (unsigned long long)m);
+            if (live && cmhi) atomicOr(&s_lmask[colsel][1], (unsigned long long)cmhi);
         }
         __syncthreads();
     }
-    const uint64_t lmask = cloud ? (uint64_t)s_lmask[0] : 0;
-    const bool col_cloudy = lmask != 0 || (cloud && deep && s_lmask[1] != 0);
+    const uint64_t lmask = cloud ? (uint64_t)s_lmask[colsel][0] : 0;
+    const uint64_t lmask_hi = cloud && deep ? (uint64_t)s_lmask[colsel][1] : 0;
+    const bool col_cloudy = lmask != 0 || lmask_hi != 0;
     int bad = 0;
-    const bool writer = (lane & 15) == 0;
-    const int wrow = wsum_index(lane >> 4);
+    // the lanes 0 and 16 of a half wave hold the half's sums (half_sum4): of v[jw] in qa, of v[2 + jw] in qb
+    const bool writer = (lane & 15) == 0 && seat_on;
+    const int jw = (lane >> 4) & 1;
 
     // ---- downward sweep (top -> surface), LW:3207-3312, in blocks of four layers ----
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
     double ec = 0., trc = 1., ek = 0., trk = 1.;   // upward flux at the top of the clean / clear stream, see above
     bool iclddn = false;
-    if (lane == 0) fl[nl] = 0.;
+    if (writer && jw == 0) fl[nl] = 0.;
     const int nblk = (nl + 3) >> 2;
-    double tnext = tg[(size_t)(nl - 1) * LW_NGPT], fnext = fr[(size_t)(nl - 1) * LW_NGPT];
+    // the layer's inputs are fetched one layer ahead: gas optics from the scratch, Planck functions and aerosol
+    // optical depth of the lane's band from the column record
+    // (one layer ahead; two layers ahead, in either issue order, was measured slower: 30.2 against 28.0 ms)
+    double tnext = tg[(size_t)(nl - 1) * ng], fnext = fr[(size_t)(nl - 1) * ng];
+    double blnext = pl[nl - 1], pvnext = pv[nl - 1], tanext = ta[nl - 1], pvhi = pv[nl];
     for (int b = nblk - 1; b >= 0; --b) {
         double v[4] = {0., 0., 0., 0.};
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
             const int k = b * 4 + j;
             if (k < nl) {
-                const double taug = tnext, plfrac = fnext;
-                if (k > 0) { tnext = tg[(size_t)(k - 1) * LW_NGPT]; fnext = fr[(size_t)(k - 1) * LW_NGPT]; }
-                const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-                const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
+                const double taug = tnext, plfrac = fnext, blay = blnext, pvlo = pvnext, tak = tanext;
+                if (k > 0) {
+                    tnext = tg[(size_t)(k - 1) * ng]; fnext = fr[(size_t)(k - 1) * ng];
+                    blnext = pl[k - 1]; pvnext = pv[k - 1]; tanext = ta[k - 1];
+                }
+                const double dplankup = pvhi - blay, dplankdn = pvlo - blay;
+                pvhi = pvlo;
+                const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
+                double up_a, up_s;   // what the upward sweep needs of this layer
                 if (!lay_cld) {
                     double at, bbd, bbu;
-                    layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                    layer_src(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                     radld_t = relax(radld_t, bbd, at);
+                    up_a = at; up_s = bbu;
                     if (col_cloudy) {
                         radclr = iclddn ? relax(radclr, bbd, at) : radld_t;   // LW:3304-3311
                         ek = __builtin_fma(bbu * at, trk, ek);
@@ -1406,7 +1467,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     }
                     if (clean_own) {
                         // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-                        if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                        if (__any(tak != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                         radld_c = relax(radld_c, bbd, at);
                         ec = __builtin_fma(bbu * at, trc, ec);
                         trc = __builtin_fma(-trc, at, trc);
@@ -1421,9 +1482,14 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         efcl = 1. - exp_neg(odcld);
                     }
                     LwCldSrc s;
-                    layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                    layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                     double gassrc = s.bbd * s.atrans;
-                    radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+                    up_a = s.atrans + efcl * (1. - s.atrans);
+                    radld_t = radld_t - radld_t * up_a + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
+                    {
+                        const double gasu = s.bbugas * s.atrans;
+                        up_s = gasu + cfm * (s.bbutot * s.atot - gasu);
+                    }
                     radclr = radclr + (s.bbd - radclr) * s.atrans;
                     ek = __builtin_fma(s.bbugas * s.atrans, trk, ek);
                     trk = __builtin_fma(-trk, s.atrans, trk);
@@ -1437,105 +1503,165 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         trc = __builtin_fma(-trc, A, trc);
                     }
                 }
+                if (RTF_STORE_UP && live) { tg[(size_t)k * ng] = up_a; fr[(size_t)k * ng] = up_s; }
                 v[j] = wgt * radld_t;
                 frac0 = plfrac;
             }
         }
         // downward flux at the bottom of the block's layers = levels 4b .. 4b+3
-        const double q = wave_sum4(v[0], v[1], v[2], v[3]);
-        if (writer && b * 4 + wrow < nl) fl[b * 4 + wrow] = q;
+        double qa, qb;
+        half_sum4(v[0], v[1], v[2], v[3], qa, qb);
+        if (writer) {
+            if (b * 4 + jw < nl) fl[b * 4 + jw] = qa;
+            if (b * 4 + 2 + jw < nl) fl[b * 4 + 2 + jw] = qb;
+        }
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
-    const double rad0 = frac0 * c.plankbnd[band];
+    const double rad0 = frac0 * plankbnd;
     const double reflect = 1. - semiss;
     double radlu_t = __builtin_fma(reflect, radld_t, rad0);
     {
         const double radlu_c = __builtin_fma(reflect, radld_c, rad0), radclru = __builtin_fma(reflect, radclr, rad0);
         const double topc = __builtin_fma(trc, radlu_c, ec), topk = __builtin_fma(trk, radclru, ek);
-        const double q0 = wave_sum4(wgt * radld_c, wgt * radlu_c, wgt * topc, wgt * radlu_t);
-        const double q1 = wave_sum4(wgt * radclr, wgt * radclru, wgt * topk, 0.);
+        double q0a, q0b, q1a, q1b;
+        half_sum4(wgt * radld_c, wgt * radlu_c, wgt * topc, wgt * radlu_t, q0a, q0b);
+        half_sum4(wgt * radclr, wgt * radclru, wgt * topk, 0., q1a, q1b);
         if (writer) {
-            if (wrow < 3) { fsum[wrow] = q0; fsum[4 + wrow] = q1; }
-            else fl[nlev] = q0;   // upward flux of the call with aerosol at the surface
+            fl[2 * nlev + jw] = q0a; fl[2 * nlev + 4 + jw] = q1a;       // surface down (jw 0) / surface up (jw 1)
+            if (jw == 0) { fl[2 * nlev + 2] = q0b; fl[2 * nlev + 6] = q1b; }   // top up
+            else fl[nlev] = q0b;                                        // upward flux of the call with aerosol at the surface
         }
     }
     // ---- upward sweep (surface -> top), LW:3331-3356: the call with aerosol ----
-    for (int b = 0; b < nblk; ++b) {   // tnext / fnext hold layer 0 after the downward sweep
-        double v[4] = {0., 0., 0., 0.};
+    if (RTF_STORE_UP) {
+        // from the stored (A, bbu | S): each lane reads back what it stored itself (program order, no fence needed)
+        double anext = tg[0], snext = fr[0];
+        for (int b = 0; b < nblk; ++b) {
+            double v[4] = {0., 0., 0., 0.};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = b * 4 + j;
-            if (k < nl) {
-                const double taug = tnext, plfrac = fnext;
-                if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * LW_NGPT]; fnext = fr[(size_t)(k + 1) * LW_NGPT]; }
-                const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
-                const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
-                if (!lay_cld) {
-                    double at, bbd, bbu;
-                    layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
-                    radlu_t = relax(radlu_t, bbu, at);
-                } else {
-                    const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
-                    const double cfm = cl ? 1. : 0.;
-                    double odcld = 0., efcl = 0.;
-                    if (cl) {
-                        odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);
-                        efcl = 1. - exp_neg(odcld);
-                    }
-                    LwCldSrc s;
-                    layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
-                    const double gassrc = s.bbugas * s.atrans;
-                    radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
+            for (int j = 0; j < 4; ++j) {
+                const int k = b * 4 + j;
+                if (k < nl) {
+                    const double A = anext, S = snext;
+                    if (k + 1 < nl) { anext = tg[(size_t)(k + 1) * ng]; snext = fr[(size_t)(k + 1) * ng]; }
+                    const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
+                    if (!lay_cld) radlu_t = relax(radlu_t, S, A);
+                    else radlu_t = radlu_t - radlu_t * A + S;
+                    v[j] = live ? wgt * radlu_t : 0.;   // (an idle lane reads slots it does not own)
                 }
-                v[j] = wgt * radlu_t;
+            }
+            // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
+            double qa, qb;
+            half_sum4(v[0], v[1], v[2], v[3], qa, qb);
+            if (writer) {
+                if (b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qa;
+                if (b * 4 + 2 + jw < nl) fl[nlev + b * 4 + 3 + jw] = qb;
             }
         }
-        // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
-        const double q = wave_sum4(v[0], v[1], v[2], v[3]);
-        if (writer && b * 4 + wrow < nl) fl[nlev + b * 4 + 1 + wrow] = q;
-    }
-    if (bad) atomicMax(a.status, (bad << 28) | (1 + col));
-    __syncthreads();
-
-    // ======================= epilogue: lanes = levels =======================
-    const size_t ws = 2 * nlev + 8;
-    const double *f0 = c.flux, *f1 = c.flux + ws, *f2 = c.flux + 2 * ws;
-    auto dnl = [&](int lev) { return (f0[lev] + f1[lev] + f2[lev]) * tb.fluxfac; };
-    auto upl = [&](int lev) { return (f0[nlev + lev] + f1[nlev + lev] + f2[nlev + lev]) * tb.fluxfac; };
-    auto sm = [&](int q) { return (f0[2 * nlev + q] + f1[2 * nlev + q] + f2[2 * nlev + q]) * tb.fluxfac; };
-    for (int l = tid; l < nk; l += LW_THREADS) {
-        if (a.rthratenlw) {
-            // htr(l) = heatfac*(fnet(l)-fnet(l+1))/(pz(l)-pz(l+1)), LW:3402; then LW:12687-12690
-            const double fnet0 = upl(l) - dnl(l), fnet1 = upl(l + 1) - dnl(l + 1);
-            const double htr = tb.heatfac * (fnet0 - fnet1) / (c.pz[l] - c.pz[l + 1]);
-            const double tten = htr / 86400.;
-            str(a.rthratenlw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
+    } else {
+        // tnext / fnext / blnext / tanext hold layer 0 after the downward sweep, pvhi the level below it
+        double pvlo = pvhi;
+        pvnext = pv[1];
+        for (int b = 0; b < nblk; ++b) {
+            double v[4] = {0., 0., 0., 0.};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = b * 4 + j;
+                if (k < nl) {
+                    const double taug = tnext, plfrac = fnext, blay = blnext, tak = tanext, pvup = pvnext;
+                    if (k + 1 < nl) {
+                        tnext = tg[(size_t)(k + 1) * ng]; fnext = fr[(size_t)(k + 1) * ng];
+                        blnext = pl[k + 1]; pvnext = pv[k + 2]; tanext = ta[k + 1];
+                    }
+                    const double dplankup = pvup - blay, dplankdn = pvlo - blay;
+                    pvlo = pvup;
+                    const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
+                    if (!lay_cld) {
+                        double at, bbd, bbu;
+                        layer_src(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                        radlu_t = relax(radlu_t, bbu, at);
+                    } else {
+                        const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
+                        const double cfm = cl ? 1. : 0.;
+                        double odcld = 0., efcl = 0.;
+                        if (cl) {
+                            odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);
+                            efcl = 1. - exp_neg(odcld);
+                        }
+                        LwCldSrc s;
+                        layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                        const double gassrc = s.bbugas * s.atrans;
+                        radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
+                    }
+                    v[j] = wgt * radlu_t;
+                }
+            }
+            // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
+            double qa, qb;
+            half_sum4(v[0], v[1], v[2], v[3], qa, qb);
+            if (writer) {
+                if (b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qa;
+                if (b * 4 + 2 + jw < nl) fl[nlev + b * 4 + 3 + jw] = qb;
+            }
         }
     }
-    if (tid == 0) {
-        const double dnb = dnl(0), upb = upl(0), upt = upl(nl), dnt = dnl(nl);
-        // clean sky: own stream, a copy of the call with aerosol when there is no aerosol, zero when switched off
-        const double dnbc = clean_own ? sm(0) : (clean_on ? dnb : 0.), upbc = clean_own ? sm(1) : (clean_on ? upb : 0.),
-                     uptc = clean_own ? sm(2) : (clean_on ? upt : 0.), dntc = clean_on ? dnt : 0.;
-        // clear sky (aerosol call): own stream in a cloudy column, else the total-sky values (LW:3304-3311)
-        const double dnbk = col_cloudy ? sm(4) : dnb, upbk = col_cloudy ? sm(5) : upb, uptk = col_cloudy ? sm(6) : upt;
-        if (a.glw) str(a.glw, i2, r4, dnb);
-        if (a.olr) str(a.olr, i2, r4, upt);
-        if (a.lwcf) str(a.lwcf, i2, r4, uptk - upt);   // LW:12658
-        if (a.lwupt) {
-            str(a.lwupb, i2, r4, upb); str(a.lwupbc, i2, r4, upbk); str(a.lwdnb, i2, r4, dnb); str(a.lwdnbc, i2, r4, dnbk);
-            str(a.lwupbcln, i2, r4, upbc); str(a.lwdnbcln, i2, r4, dnbc);
-            str(a.lwupt, i2, r4, upt); str(a.lwuptc, i2, r4, uptk); str(a.lwdnt, i2, r4, dnt); str(a.lwdntc, i2, r4, dnt);
-            str(a.lwuptcln, i2, r4, uptc); str(a.lwdntcln, i2, r4, dntc);
+    if (bad && live) atomicMax(a.status, (bad << 28) | (1 + col));
+    __syncthreads();
+
+    // ======================= epilogue: lanes = levels; two waves per column =======================
+    const int ec_col = wave >> 1;
+    if (ec_col < ncols) {
+        const int etid = tid & 127;
+        const int ecol = a.col0 + RTF_COLS * grp + ec_col;
+        const int eit = ecol % a.ni_t, ejt = ecol / a.ni_t;
+        const size_t ei0 = (size_t)(a.its - a.ims + eit), ej0 = (size_t)(a.jts - a.jms + ejt), k0 = (size_t)(a.kts - a.kms);
+        const size_t ei2 = ej0 * a.ni_m + ei0;
+        const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
+        const size_t base3 = ej0 * sj + k0 * sk + ei0;
+        const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 1);
+        const double *f0 = lds + ec_col * cold + recn;
+        const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
+        // the five chunk sums in chunk order
+        auto tot = [&](size_t q) { return ((((f0[q] + f0[ws + q]) + f0[2 * ws + q]) + f0[3 * ws + q]) + f0[4 * ws + q]) * tb.fluxfac; };
+        auto dnl = [&](int lev) { return tot(lev); };
+        auto upl = [&](int lev) { return tot(nlev + lev); };
+        auto sm = [&](int q) { return tot(2 * nlev + q); };
+        for (int l = etid; l < nk; l += 128) {
+            if (a.rthratenlw) {
+                // htr(l) = heatfac*(fnet(l)-fnet(l+1))/(pz(l)-pz(l+1)), LW:3402; then LW:12687-12690
+                const double fnet0 = upl(l) - dnl(l), fnet1 = upl(l + 1) - dnl(l + 1);
+                const double htr = tb.heatfac * (fnet0 - fnet1) / (pz[l] - pz[l + 1]);
+                const double tten = htr / 86400.;
+                str(a.rthratenlw, base3 + (size_t)l * sk, r4, tten / ldr(a.pi3d, base3 + (size_t)l * sk, r4));
+            }
+        }
+        if (etid == 0) {
+            const double dnb = dnl(0), upb = upl(0), upt = upl(nl), dnt = dnl(nl);
+            // clean sky: own stream, a copy of the call with aerosol when there is no aerosol, zero when switched off
+            const double dnbc = clean_own ? sm(0) : (clean_on ? dnb : 0.), upbc = clean_own ? sm(1) : (clean_on ? upb : 0.),
+                         uptc = clean_own ? sm(2) : (clean_on ? upt : 0.), dntc = clean_on ? dnt : 0.;
+            // clear sky (aerosol call): own stream in a cloudy column, else the total-sky values (LW:3304-3311)
+            const double dnbk = e_cloudy ? sm(4) : dnb, upbk = e_cloudy ? sm(5) : upb, uptk = e_cloudy ? sm(6) : upt;
+            if (a.glw) str(a.glw, ei2, r4, dnb);
+            if (a.olr) str(a.olr, ei2, r4, upt);
+            if (a.lwcf) str(a.lwcf, ei2, r4, uptk - upt);   // LW:12658
+            if (a.lwupt) {
+                str(a.lwupb, ei2, r4, upb); str(a.lwupbc, ei2, r4, upbk); str(a.lwdnb, ei2, r4, dnb); str(a.lwdnbc, ei2, r4, dnbk);
+                str(a.lwupbcln, ei2, r4, upbc); str(a.lwdnbcln, ei2, r4, dnbc);
+                str(a.lwupt, ei2, r4, upt); str(a.lwuptc, ei2, r4, uptk); str(a.lwdnt, ei2, r4, dnt); str(a.lwdntc, ei2, r4, dnt);
+                str(a.lwuptcln, ei2, r4, uptc); str(a.lwdntcln, ei2, r4, dntc);
+            }
         }
     }
 }
 
 __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a) { lw_rt_body<false>(a); }
-__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false>(a); }
-__global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true>(a); }
+__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false, false>(a); }
+__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_cld_kernel(const LwKernelArgs a) { lw_rt_fast<false, true>(a); }
+__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true, true>(a); }
 __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
 
@@ -1545,6 +1671,10 @@ size_t lw_gas_lds_bytes(int nl)
     size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1 + LW_NBND) + 2 * (nl + 1);
     size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
+}
+size_t lw_rt_fast_lds_bytes(int nl, bool cloud)
+{
+    return RTF_COLS * rtf_col_doubles(nl, cloud) * sizeof(double);
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
@@ -1633,7 +1763,8 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
 {
     const int nl = a.nlayers;
     const size_t lds_gas = lw_gas_lds_bytes(nl), lds_rt = lw_rt_lds_bytes(nl, a.icloud != 0);
-    static size_t attr_gas = 0, attr_rt = 0;
+    const size_t lds_fast = lw_rt_fast_lds_bytes(nl, a.icloud != 0);
+    static size_t attr_gas = 0, attr_rt = 0, attr_fast = 0;
     if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_gas_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gas);
@@ -1646,27 +1777,46 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_deep_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_deep_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
         if (e != hipSuccess) return e;
         attr_rt = lds_rt;
     }
+    // the three-column transfer kernel holds three column records; beyond what a workgroup may have (very deep
+    // columns) the one-column kernel serves the call
+    const bool fast_fits = lds_fast <= 160 * 1024 - 2048;
+    if (fast_fits && lds_fast > attr_fast && lds_fast > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_cld_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_deep_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
+        if (e != hipSuccess) return e;
+        attr_fast = lds_fast;
+    }
     const bool deep = a.icloud != 0 && a.nk > 64;
     if (!scratch || cap_cols <= 0) return hipErrorInvalidValue;
+    if (std::getenv("RRTMG_HIP_DEBUG_OCC")) {   // development aid: what the runtime expects to keep resident per CU
+        int ng = 0, nf = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ng, lw_gas_kernel, LW_THREADS, lds_gas);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, lw_rt_fast_kernel, RTF_THREADS, lds_fast);
+        fprintf(stderr, "lw_gas_kernel: %d workgroups/CU (LDS %zu B); lw_rt_fast_kernel: %d workgroups/CU (LDS %zu B)\n",
+                ng, lds_gas, nf, lds_fast);
+    }
     a.taug = scratch;
     a.frac = a.taug + (size_t)cap_cols * nl * LW_NGPT;
     a.rec = a.frac + (size_t)cap_cols * nl * LW_NGPT;
     for (int c0 = 0; c0 < ncol; c0 += cap_cols) {
         const int n = ncol - c0 < cap_cols ? ncol - c0 : cap_cols;
         a.col0 = c0;
+        a.nbatch = n;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
-        if (!a.lwupflx) {   // no layer-flux profiles requested: what the radiation driver calls
-            if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
-            else hipLaunchKernelGGL(lw_rt_fast_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
+        if (!a.lwupflx && fast_fits) {   // no layer-flux profiles requested: what the radiation driver calls
+            const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
+            if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
+            else if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
+            else hipLaunchKernelGGL(lw_rt_fast_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
         } else if (deep) hipLaunchKernelGGL(lw_rt_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
         else hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
     }
