@@ -761,6 +761,21 @@ static inline double exp_lookup(const SwTables *t, double ze1)
     return t->exp_tbl[itind];
 }
 
+/* census of the two-stream branches taken (test aid: tests/test_sw_gpu.py checks that a case planted around the
+ * conservative-scattering threshold really has layers on both sides of it, and how close they come) */
+#ifndef ORACLE_COUNT_FLOPS
+static long g_reftra_conservative = 0, g_reftra_general = 0;
+static double g_reftra_closest_above = 1e300, g_reftra_closest_below = 1e300;
+void sw_oracle_reftra_census(long *conservative, long *general, double *closest_above, double *closest_below, int reset)
+{
+    if (conservative) *conservative = g_reftra_conservative;
+    if (general) *general = g_reftra_general;
+    if (closest_above) *closest_above = g_reftra_closest_above;
+    if (closest_below) *closest_below = g_reftra_closest_below;
+    if (reset) { g_reftra_conservative = g_reftra_general = 0; g_reftra_closest_above = g_reftra_closest_below = 1e300; }
+}
+#endif
+
 /* reftra_sw, SW:2422-2701 (kmodts = 2, PIFM) */
 static void reftra_sw(const SwTables *t, int nlayers, const int *lrtchk, const double *pgg, double prmuz,
                       const double *ptau, const double *pw, double *pref, double *prefd, double *ptra,
@@ -782,6 +797,10 @@ static void reftra_sw(const SwTables *t, int nlayers, const int *lrtchk, const d
         double zq = zg / (1. - zg);
         double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
         double zwo = zw / denom;
+#ifndef ORACLE_COUNT_FLOPS
+        if (zwo >= zwcrit) { ++g_reftra_conservative; if (zwo - zwcrit < g_reftra_closest_above) g_reftra_closest_above = zwo - zwcrit; }
+        else { ++g_reftra_general; if (zwcrit - zwo < g_reftra_closest_below) g_reftra_closest_below = zwcrit - zwo; }
+#endif
         if (zwo >= zwcrit) {
             /* conservative scattering, SW:2560-2600 */
             double za = zgamma1 * prmuz;

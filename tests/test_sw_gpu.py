@@ -180,3 +180,35 @@ def test_full_size_properties_200x200x40(eng, wa):
     got2 = run_hip_swrad(eng, st2, profiles=False)
     for n in ("swupt", "swdnb", "swuptcln", "swddir"):
         np.testing.assert_array_equal(got2[n], got[n][..., perm], err_msg=n)
+
+
+def test_conservative_scattering_threshold_both_sides(eng, sw_oracle, wa):
+    """reftra_sw switches to its conservative-scattering solution where the recovered single-scattering albedo
+    zwo = zw / denom reaches zwcrit = 0.9999995 (SW:2557-2560).  The device forms the same test on the same rounded
+    quotient.  Planted case: nearly white aerosol (1 - omega from 1e-9 to 3e-6, scanned over columns and layers) thick
+    enough to swamp the gases in the window g-points, so that layers land on BOTH sides of the threshold and close to
+    it -- the oracle's census says how many and how close -- and parity holds across it."""
+    import ctypes as C
+    from oracle import oracle as orc
+    ni, nj, nk = 16, 8, 40
+    st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260177, night_fraction=0.0)
+    rng = np.random.default_rng(20260178)
+    shape = st.a3["waer400"].shape
+    one_minus = 10.0 ** rng.uniform(-9.0, -5.5, size=shape)
+    for nm in ("300", "400", "600", "999"):
+        st.a3["waer" + nm] = 1.0 - one_minus
+        st.a3["gaer" + nm] = rng.uniform(0.0, 0.85, size=shape)
+        st.a3["tauaer" + nm] = np.full(shape, 5.9 / nk)          # column AOD just under the guard of 6 (SW:11024-11047)
+    lib = orc.lib()
+    lib.sw_oracle_reftra_census.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.c_int]
+    lib.sw_oracle_reftra_census(None, None, None, None, 1)
+    ref = run_oracle_swrad(sw_oracle, st, profiles=False)
+    ncons, ngen, above, below = C.c_long(), C.c_long(), C.c_double(), C.c_double()
+    lib.sw_oracle_reftra_census(C.byref(ncons), C.byref(ngen), C.byref(above), C.byref(below), 1)
+    assert ncons.value > 1000 and ngen.value > 1000            # both solutions are really taken ...
+    assert above.value < 1e-9 and below.value < 1e-9           # ... by layers within 1e-9 of the threshold
+    got = run_hip_swrad(eng, st, device=True, profiles=False)
+    _check(got, ref)
+    got = run_hip_swrad(eng, st, device=True, profiles=True)
+    _check(got, run_oracle_swrad(sw_oracle, st, profiles=True))

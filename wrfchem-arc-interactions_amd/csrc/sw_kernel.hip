@@ -56,6 +56,8 @@ namespace {
 constexpr int SW_SCR_VALS = 5;     // ref, refd, tra, trad, dbt per (layer, lane)
 constexpr int BLK = 4;            // levels between checkpoints of the upward sweep = layers per block on the way down
 constexpr int CHUNK = 56;         // g-points per wave (112 = 2 x 56)
+constexpr int SCR_ROW = CHUNK;    // lanes of a scratch row: 448 bytes = seven whole 64-byte lines, no dead bytes (the
+                                  // eight idle lanes of a wave neither store nor own a slot)
 constexpr int NTHREADS = 128;     // two waves: g-chunks 0 and 1
 constexpr int NWAVE = NTHREADS / 64;
 constexpr int SW_WAVES_PER_SIMD = 3; // register budget: 12 waves per CU
@@ -237,7 +239,14 @@ __device__ __forceinline__ void reftra_fast(const SwDeviceTables &tb, double zto
     const double tv1 = exp_issue(tb, ze1);
     double zq = fdiv(zg, 1. - zg);
     double denom = fmax((1. - (1. - zw) * (zq * zq)), 1.0E-30);
-    if (zw >= zwcrit * denom) {   // zwo = zw/denom >= zwcrit, SW:2557-2560
+    // zwo = zw / denom; if (zwo >= zwcrit): the reference's test, SW:2557-2560, on the ROUNDED quotient.  Away from the
+    // threshold the sign of zw - zwcrit*denom (one FMA) decides the same way -- the rounded quotient lies on the exact
+    // quotient's side of zwcrit as soon as they are more than an ulp apart --; a lane within 1e-12 of it forms the
+    // quotient as the reference does (fdiv is the correctly rounded one) and compares that.
+    const double zt = __builtin_fma(-zwcrit, denom, zw);
+    bool conservative = zt >= 0.;
+    if (fabs(zt) <= 1.e-12 * denom) conservative = fdiv(zw, denom) >= zwcrit;
+    if (conservative) {
         // conservative scattering, SW:2560-2600
         double za = zgamma1 * prmuz;
         double za1 = za - zgamma3;
@@ -1187,8 +1196,10 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
         albp = gd.uvband ? ldr(a.alswvisdir, i2, r4) : ldr(a.alswnirdir, i2, r4);
         albd = gd.uvband ? ldr(a.alswvisdif, i2, r4) : ldr(a.alswnirdif, i2, r4);
     }
-    double *ck = scr_block + (size_t)NWAVE * nlay * SW_SCR_VALS * 64 + (size_t)wave * nblk * 2 * 64 + lane;
-    double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * 64 + lane;
+    // (an idle lane points at the row's last slot: it reads that lane's values and stores nothing)
+    const int slane = active ? lane : CHUNK - 1;
+    double *ck = scr_block + (size_t)NWAVE * nlay * SW_SCR_VALS * SCR_ROW + (size_t)wave * nblk * 2 * SCR_ROW + slane;
+    double *scr = scr_block + (size_t)wave * nlay * SW_SCR_VALS * SCR_ROW + slane;
     int bad = 0;
     // the lanes that store wave sums: lane 16r holds row r, i.e. value wsum_index(r) of a wave_sum4
     const bool writer = (lane & 15) == 0;
@@ -1240,9 +1251,9 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             if (hasS && !s_general) cpre = layer_rt_clean_issue(tb, taug, taur, rprmu0);
             RT rtp;
             if (hasP) {
-                if ((k & (BLK - 1)) == 0) {
-                    ck[((k / BLK) * 2 + 0) * 64] = rup;
-                    ck[((k / BLK) * 2 + 1) * 64] = rupd;
+                if ((k & (BLK - 1)) == 0 && active) {
+                    ck[((k / BLK) * 2 + 0) * SCR_ROW] = rup;
+                    ck[((k / BLK) * 2 + 1) * SCR_ROW] = rupd;
                 }
                 RT rt;
                 double dnl = 1.;
@@ -1270,8 +1281,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
                 // keep the layer's two-stream result for the way down.  Last in the iteration: vector memory
                 // operations retire in order, and a table gather issued behind these stores would have its first
                 // use wait for their acknowledgement too -- here the next gather is a whole layer preparation away
-                double *s = scr + (size_t)k * SW_SCR_VALS * 64;
-                s[0] = rtp.ref; s[64] = rtp.refd; s[128] = rtp.tra; s[192] = rtp.trad; s[256] = rtp.dbt;
+                double *s = scr + (size_t)k * SW_SCR_VALS * SCR_ROW;
+                if (active) {
+                    s[0] = rtp.ref; s[SCR_ROW] = rtp.refd; s[2 * SCR_ROW] = rtp.tra; s[3 * SCR_ROW] = rtp.trad;
+                    s[4 * SCR_ROW] = rtp.dbt;
+                }
             }
         }
         if (hasS) {
@@ -1290,14 +1304,15 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
         for (int b = nblk - 1; b >= 0; --b) {
             RT rt[BLK];
             double ru[BLK + 1], rud[BLK + 1];
-            ru[0] = ck[(b * 2 + 0) * 64];
-            rud[0] = ck[(b * 2 + 1) * 64];
+            ru[0] = ck[(b * 2 + 0) * SCR_ROW];
+            rud[0] = ck[(b * 2 + 1) * SCR_ROW];
 #pragma unroll
             for (int j = 0; j < BLK; ++j) {
                 const int k = b * BLK + j;
                 if (k < nlay) {
-                    const double *s = scr + (size_t)k * SW_SCR_VALS * 64;
-                    rt[j].ref = s[0]; rt[j].refd = s[64]; rt[j].tra = s[128]; rt[j].trad = s[192]; rt[j].dbt = s[256];
+                    const double *s = scr + (size_t)k * SW_SCR_VALS * SCR_ROW;
+                    rt[j].ref = s[0]; rt[j].refd = s[SCR_ROW]; rt[j].tra = s[2 * SCR_ROW]; rt[j].trad = s[3 * SCR_ROW];
+                    rt[j].dbt = s[4 * SCR_ROW];
                 } else {
                     rt[j].ref = 0.; rt[j].refd = 0.; rt[j].tra = 1.; rt[j].trad = 1.; rt[j].dbt = 1.;
                 }
@@ -1450,8 +1465,8 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     }
 }
 
-// One workgroup per column of the launch; its scratch slice: the layers' two-stream results [2 waves][nlay][5][64]
-// and the upward sweep's checkpoints [2 waves][nblk][2][64].
+// One workgroup per column of the launch; its scratch slice: the layers' two-stream results [2 waves][nlay][5][56]
+// and the upward sweep's checkpoints [2 waves][nblk][2][56].
 template <bool CLOUD, bool PROF>
 __global__ void __launch_bounds__(NTHREADS, SW_WAVES_PER_SIMD) sw_column_kernel(const SwKernelArgs a)
 {
@@ -1463,7 +1478,7 @@ __global__ void __launch_bounds__(NTHREADS, SW_WAVES_PER_SIMD) sw_column_kernel(
 size_t sw_scratch_doubles_per_column(int nk)
 {
     const size_t nlay = nk + 1, nblk = (nlay + BLK - 1) / BLK;
-    return NWAVE * nlay * SW_SCR_VALS * 64 + NWAVE * nblk * 2 * 64;
+    return NWAVE * nlay * SW_SCR_VALS * SCR_ROW + NWAVE * nblk * 2 * SCR_ROW;
 }
 
 // ---------------------------------------------------------------------------
