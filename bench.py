@@ -152,7 +152,11 @@ def cpu_baseline(wa, tab_sw, tab_lw, st, ms, mode, ncol_1t, ncol_per_core, ncol_
     n1, sw1, lw1 = rate(ncol_1t, 1)
     nall, swa, lwa = rate(ncol_per_core * cores, cores)
     spc1, spca = (sw1 + lw1) / n1, (swa + lwa) / nall
-    res = {"unit": "columns/s", "cores": cores, "host_cpus": host_cpus, "kind": "reference",
+    # `value`: the reference Fortran alone (the radiation double call, the part the reference defines), all used cores
+    res = {"value": 1.0 / spca, "value_1_core": 1.0 / spc1,
+           "unit": "columns/s", "cores": cores, "host_cpus": host_cpus, "kind": "reference",
+           "what": "reference rrtmg_sw + rrtmg_lw double call only; the optical averaging (no reference arithmetic) is "
+                   "under `optics_port`, the two together under `whole_step_with_optics_port`",
            "threads_1": {"columns": n1, "sw_s": sw1, "lw_s": lw1},
            "threads_all": {"columns": nall, "processes": cores, "sw_s": swa, "lw_s": lwa}}
     sample = (f"reference rrtmg_sw{' + rrtmg_lw' if lwc is not None else ''} (oracle/_ref, flang -O2, fp64), solver time: "
@@ -173,14 +177,14 @@ def cpu_baseline(wa, tab_sw, tab_lw, st, ms, mode, ncol_1t, ncol_per_core, ncol_
         o1, no1 = opt_rate(1, ncol_optics)
         oa, noa = opt_rate(cores, ncol_optics * min(cores, 8))
         lib.omp_set_num_threads(1)
-        spc1 += o1
-        spca += oa
-        res["threads_1"]["optics_s_per_column"] = o1
-        res["threads_all"]["optics_s_per_column"] = oa
-        sample += (f"; optical averaging through the C port of the engine's own specification (no reference arithmetic "
-                   f"exists): {no1} columns on 1 thread, {noa} columns on {cores} OpenMP threads")
-    res["value"] = 1.0 / spca
-    res["value_1_thread"] = 1.0 / spc1
+        res["optics_port"] = {"kind": "port", "unit": "columns/s", "value": 1.0 / oa, "value_1_thread": 1.0 / o1,
+                              "threads": cores, "columns_1_thread": no1, "columns_all_threads": noa,
+                              "what": "oracle/optics_oracle.c, the C port of the engine's own specification (OpenMP over "
+                                      "columns): own-spec stage, never part of `value`"}
+        res["whole_step_with_optics_port"] = {"unit": "columns/s", "value": 1.0 / (spca + oa),
+                                              "value_1_thread": 1.0 / (spc1 + o1)}
+        sample += (f"; separately, optical averaging through the C port of the engine's own specification: {no1} columns on "
+                   f"1 thread, {noa} columns on {cores} OpenMP threads")
     res["sample"] = sample
     return res
 
@@ -352,6 +356,9 @@ def main():
     ap.add_argument("--host-path-rows", type=int, default=40,
                     help="rows of the domain pushed through the mem = 0 (host pointer) entry points; 0 = skip")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cloudy-pass", type=int, default=1,
+                    help="N = 1: after the timed region, one short pass of the same domain with the SURVEY 8d full-domain "
+                         "atmosphere (clouds in 20 %% of the columns, 10 %% night columns) -> key `cloudy`; 0 = skip")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only (no GPU, gloo): every rank computes its slab, rank 0 prints them as JSON")
     args = ap.parse_args()
@@ -561,7 +568,7 @@ def main():
             cand.append(("optics_lw_kernel", opt_part_ms["lw"], optics_bytes_per_column(nk, nbin, part="lw")))
         dom_name, dom_ms, dom_bpc = max(cand, key=lambda c: c[1])
         achieved = ncol * dom_bpc / (dom_ms * 1e-3) / 1e9
-        traffic, valu = None, {}
+        traffic, valu, traffic_source = None, {}, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tf):
             try:
@@ -570,6 +577,10 @@ def main():
                 if kd.get("hbm_bytes_per_launch") is not None and kd.get("columns_per_dispatch"):
                     # PMC bytes per dispatch of the profiled run scaled to the columns of one step here (same kernel)
                     traffic = kd["hbm_bytes_per_launch"] * ncol / kd["columns_per_dispatch"]
+                    traffic_source = {"file": tj.get("source"), "commit": tj.get("source_commit"),
+                                      "how": "imported: PMC bytes per dispatch of a builder-run profile of this command "
+                                             "(FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes), scaled by the column "
+                                             "count; not measured by this run"}
                 if kd.get("valu_issue_frac") is not None and kd.get("columns_per_dispatch"):   # what binds this kernel
                     valu = {"fp64_valu_issue_frac": kd["valu_issue_frac"],
                             "valu_wave_instructions_per_column": kd["valu_wave_instructions"] / kd["columns_per_dispatch"],
@@ -598,7 +609,7 @@ def main():
                        "parallelism": (f"one domain in {world} j-slab(s), one per GPU" if strong else
                                        f"{world} domains, one per GPU") + "; RCCL all-reduce of 32 flux sums"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dom_name, "kernel_ms": dom_ms,
                          "algorithmic_bytes_per_column": dom_bpc,
                          "sw_kernel_ms": sw_ms, "sw_algorithmic_bytes_per_column": bpc_sw,
@@ -613,9 +624,14 @@ def main():
             try:
                 fl = algorithmic_flops(wa, tab, tabl, st, ms, mode)
                 if fl:
+                    # the whole timed step: radiation + optical averaging, every operation of the CPU restatement
                     tf64 = value * fl["flops_per_column"] / 1e12
-                    line["roofline"]["fp64"] = dict(fl, achieved_TFLOPs=tf64, peak_TFLOPs=FP64_PEAK_TFLOPS,
-                                                    frac=tf64 / FP64_PEAK_TFLOPS)
+                    rad_s = (sw_ms + lw_ms) * 1e-3
+                    tf64_rad = ncol * fl["flops_per_column_radiation"] / rad_s / 1e12 if rad_s > 0 else None
+                    line["roofline"]["fp64"] = dict(
+                        fl, achieved_TFLOPs=tf64, peak_TFLOPs=FP64_PEAK_TFLOPS, frac=tf64 / FP64_PEAK_TFLOPS,
+                        radiation_only={"achieved_TFLOPs": tf64_rad, "frac": tf64_rad / FP64_PEAK_TFLOPS if tf64_rad else None,
+                                        "over": "the two radiation calls' own kernel time (rank 0)"})
             except Exception as e:
                 line["roofline"]["fp64"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu and args.clouds <= 0.0:
@@ -629,6 +645,59 @@ def main():
                 line["flux_rmse"] = flux_rmse(wa, tab, tabl, st, ms, sw_out, lw_out, max(1, min(st.nj, 500 // ni)), mode)
             except Exception as e:
                 line["flux_rmse"] = {"error": repr(e)}
+        if world == 1 and args.cloudy_pass and args.clouds <= 0.0 and not empty:
+            # SURVEY 8d's full-domain atmosphere (McICA clouds in 20 % of the columns, 10 % night columns): the same
+            # domain and kernels' cloudy instantiations, timed per stage; outside `value`
+            try:
+                import copy
+                stc = copy.copy(st)
+                stc.a2, stc.a3 = dict(st.a2), dict(st.a3)
+                nightc = night_rows(ni, nj, nseed, 0.1)[j0:j1]
+                stc.a2["xcoszen"] = np.where(nightc, -0.3, st.a2["xcoszen"])
+                cflags = wa.synth_clouds.add_clouds(stc, seed=cseed, cloudy_fraction=0.2)
+                cin = {n: dev(stc.a3[n]) for n in CLD3}
+                cin.update({n: dev(stc.a2[n]) for n in CLD2})
+                sw_in_c = dict(sw_in, xcoszen=dev(stc.a2["xcoszen"]))
+
+                def cstep(ev=None):
+                    if ev:
+                        ev[0].record()
+                    if do_opt:
+                        opt_call()
+                    if ev:
+                        ev[1].record()
+                    eng.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=1, clean_atm_diag=1, **cflags, **d, **sw_in_c, **cin, **sw_out)
+                    if ev:
+                        ev[2].record()
+                    if do_lw:
+                        engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, **cflags, **d, **lw_in, **cin, **lw_out)
+                    if ev:
+                        ev[3].record()
+                cstep()
+                torch.cuda.synchronize()
+                evs = []
+                tc0 = time.perf_counter()
+                for _ in range(2):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    cstep(ev)
+                    evs.append(ev)
+                torch.cuda.synchronize()
+                tc = (time.perf_counter() - tc0) / 2
+                eng.sw_status()
+                if do_lw:
+                    engl.lw_status()
+                line["cloudy"] = {
+                    "what": "same domain, SURVEY 8d full-domain atmosphere: McICA clouds (1-3 decks) in 20 % of the columns, "
+                            "10 % night columns; 2 steps after 1 warm-up, outside `value`",
+                    "ms_per_step": 1e3 * tc, "columns_per_s": ncol / tc,
+                    "optics_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
+                    "sw_ms": float(np.mean([e[1].elapsed_time(e[2]) for e in evs])),
+                    "lw_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in evs])),
+                    "cloudy_columns": int((stc.a3["cldfra3d"].max(axis=1) > 0).sum()),
+                    "night_columns": int(nightc.sum())}
+                del cin, sw_in_c
+            except Exception as e:
+                line["cloudy"] = {"error": repr(e)}
         if world == 1 and args.host_path_rows > 0 and args.clouds <= 0.0:
             # the call a WRF build makes (mem = 0: host arrays through the Fortran shim's entry points), PCIe included
             try:

@@ -82,7 +82,7 @@ ORACLE_MIXED(float)
 
 #define ORACLE_TRANS1(f) inline cdbl f(cdbl a) { ++oracle_flops.trans; return cdbl(::f(a.v)); }
 ORACLE_TRANS1(exp) ORACLE_TRANS1(log) ORACLE_TRANS1(sin) ORACLE_TRANS1(cos) ORACLE_TRANS1(atan) ORACLE_TRANS1(cbrt)
-ORACLE_TRANS1(erf) ORACLE_TRANS1(log10) ORACLE_TRANS1(tan) ORACLE_TRANS1(expm1) ORACLE_TRANS1(asin) ORACLE_TRANS1(acos)
+ORACLE_TRANS1(erf) ORACLE_TRANS1(erfc) ORACLE_TRANS1(log10) ORACLE_TRANS1(tan) ORACLE_TRANS1(expm1) ORACLE_TRANS1(asin) ORACLE_TRANS1(acos)
 #undef ORACLE_TRANS1
 inline cdbl pow(cdbl a, cdbl b) { ++oracle_flops.trans; return cdbl(::pow(a.v, b.v)); }
 inline cdbl atan2(cdbl a, cdbl b) { ++oracle_flops.trans; return cdbl(::atan2(a.v, b.v)); }
@@ -108,5 +108,53 @@ inline void sincos(cdbl a, cdbl *s, cdbl *c) { oracle_flops.trans += 2; ::sincos
 inline bool isnan(cdbl a) { return __builtin_isnan(a.v); }
 inline bool isfinite(cdbl a) { return __builtin_isfinite(a.v); }
 inline bool isinf(cdbl a) { return __builtin_isinf(a.v); }
+
+/* complex numbers of the optical-averaging oracle (optics_oracle.c uses C99 <complex.h> in the plain build): pairs of
+ * the counting type, every operation spelled out in real operations (a complex product = 4 mul + 2 add, a complex
+ * quotient = 6 mul + 3 add + 2 div, |z| = 2 mul + 1 add + 1 sqrt), so that the Mie series is counted like the rest */
+struct oracle_cplx {
+    cdbl re, im;
+    oracle_cplx() = default;
+    oracle_cplx(cdbl r, cdbl i) : re(r), im(i) {}
+    oracle_cplx &operator+=(oracle_cplx o) { re += o.re; im += o.im; return *this; }
+};
+inline oracle_cplx operator+(oracle_cplx a, oracle_cplx b) { return {a.re + b.re, a.im + b.im}; }
+inline oracle_cplx operator-(oracle_cplx a, oracle_cplx b) { return {a.re - b.re, a.im - b.im}; }
+inline oracle_cplx operator-(oracle_cplx a) { return {-a.re, -a.im}; }
+inline oracle_cplx operator*(oracle_cplx a, oracle_cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+inline oracle_cplx operator/(oracle_cplx a, oracle_cplx b)
+{
+    const cdbl d = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+inline oracle_cplx operator+(oracle_cplx a, cdbl b) { return {a.re + b, a.im}; }
+inline oracle_cplx operator+(cdbl a, oracle_cplx b) { return {a + b.re, b.im}; }
+inline oracle_cplx operator-(oracle_cplx a, cdbl b) { return {a.re - b, a.im}; }
+inline oracle_cplx operator-(cdbl a, oracle_cplx b) { return {a - b.re, -b.im}; }
+inline oracle_cplx operator*(oracle_cplx a, cdbl b) { return {a.re * b, a.im * b}; }
+inline oracle_cplx operator*(cdbl a, oracle_cplx b) { return {a * b.re, a * b.im}; }
+inline oracle_cplx operator/(oracle_cplx a, cdbl b) { return {a.re / b, a.im / b}; }
+inline oracle_cplx operator/(cdbl a, oracle_cplx b)
+{
+    const cdbl d = b.re * b.re + b.im * b.im;
+    return {(a * b.re) / d, -(a * b.im) / d};
+}
+#define ORACLE_CMIXED(T)                                                                                     \
+    inline oracle_cplx operator+(oracle_cplx a, T b) { return a + cdbl(b); } inline oracle_cplx operator+(T a, oracle_cplx b) { return cdbl(a) + b; } \
+    inline oracle_cplx operator-(oracle_cplx a, T b) { return a - cdbl(b); } inline oracle_cplx operator-(T a, oracle_cplx b) { return cdbl(a) - b; } \
+    inline oracle_cplx operator*(oracle_cplx a, T b) { return a * cdbl(b); } inline oracle_cplx operator*(T a, oracle_cplx b) { return cdbl(a) * b; } \
+    inline oracle_cplx operator/(oracle_cplx a, T b) { return a / cdbl(b); } inline oracle_cplx operator/(T a, oracle_cplx b) { return cdbl(a) / b; }
+ORACLE_CMIXED(oracle_real_t)
+ORACLE_CMIXED(int)
+#undef ORACLE_CMIXED
+inline cdbl creal(oracle_cplx a) { return a.re; }
+inline cdbl cimag(oracle_cplx a) { return a.im; }
+inline cdbl cabs(oracle_cplx a) { return sqrt(a.re * a.re + a.im * a.im); }
+inline oracle_cplx csqrt(oracle_cplx a)   /* principal root */
+{
+    const cdbl mod = cabs(a);
+    const cdbl re = sqrt(0.5 * (mod + a.re)), im = sqrt(fmax(0.5 * (mod - a.re), cdbl(0.0)));
+    return {re, a.im < 0.0 ? -im : im};
+}
 
 #define double cdbl

@@ -10,7 +10,24 @@
  * Bohren & Huffman (1983) appendix A test case, Wiscombe (1979) / Du (2004) efficiency tables, the Rayleigh and
  * geometric-optics limits, and an independent formulation with scipy's spherical Bessel functions.
  */
+#ifdef ORACLE_COUNT_FLOPS
+/* the operation-counting build (oracle/count, C++): complex numbers are pairs of the counting type, flop_count.hpp */
+typedef oracle_cplx cplx_t;
+#define CPLX(re, im) oracle_cplx((re), (im))
+extern "C" {
+void optics_oracle_mie(double x, double mre, double mim, double *out4);
+struct optics_oracle_tables;
+void optics_oracle_cell(const struct optics_oracle_tables *t, int mix, const double *mass, const double *numb, double alt,
+                        double dz, double *out_sw, double *out_lw);
+void optics_oracle_tile(const struct optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0, int j0,
+                        int ni_t, int nk_t, int nj_t, int num_chem, const int *idx, const double *chem, const double *alt,
+                        const double *dz8w, double *sw5, double *lw2);
+}
+#else
 #include <complex.h>
+typedef double complex cplx_t;
+#define CPLX(re, im) ((re) + I * (im))
+#endif
 #include <math.h>
 #include <stddef.h>
 
@@ -31,37 +48,37 @@
  * equals the converged value to the last bit in a 20 000-case sweep. */
 void optics_oracle_mie(double x, double mre, double mim, double *out4)
 {
-    static _Thread_local double complex D[4096];
-    const double complex m = mre + I * mim;
-    const double complex y = x * m;
+    static _Thread_local cplx_t D[4096];
+    const cplx_t m = CPLX(mre, mim);
+    const cplx_t y = x * m;
     const double xstop = x + 4. * cbrt(x) + 2.;
     const int nstop = (int)xstop;
     const double base = fmax(xstop, cabs(y));
     int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
     if (nmx > 4095) nmx = 4095;
-    D[nmx] = 0.;
+    D[nmx] = CPLX(0., 0.);
     for (int n = nmx; n >= 2; --n) {
-        const double complex ny = (double)n / y;
+        const cplx_t ny = (double)n / y;
         D[n - 1] = ny - 1. / (D[n] + ny);
     }
     double psi0 = cos(x), psi1 = sin(x), chi0 = -sin(x), chi1 = cos(x);
-    double complex an1 = 0., bn1 = 0., xb = 0.;
+    cplx_t an1 = CPLX(0., 0.), bn1 = CPLX(0., 0.), xb = CPLX(0., 0.);
     double qs = 0., qe = 0., gs = 0., sgn = -1.;
     for (int n = 1; n <= nstop; ++n) {
         const double en = (double)n;
         const double psi = (2. * en - 1.) * psi1 / x - psi0;
         const double chi = (2. * en - 1.) * chi1 / x - chi0;
-        const double complex xi = psi - I * chi, xi1 = psi1 - I * chi1;
-        const double complex ta = D[n] / m + en / x, tb = m * D[n] + en / x;
-        const double complex an = (ta * psi - psi1) / (ta * xi - xi1);
-        const double complex bn = (tb * psi - psi1) / (tb * xi - xi1);
+        const cplx_t xi = CPLX(psi, -chi), xi1 = CPLX(psi1, -chi1);
+        const cplx_t ta = D[n] / m + en / x, tb = m * D[n] + en / x;
+        const cplx_t an = (ta * psi - psi1) / (ta * xi - xi1);
+        const cplx_t bn = (tb * psi - psi1) / (tb * xi - xi1);
         qs += (2. * en + 1.) * (creal(an) * creal(an) + cimag(an) * cimag(an) + creal(bn) * creal(bn) + cimag(bn) * cimag(bn));
         qe += (2. * en + 1.) * (creal(an) + creal(bn));
         gs += ((2. * en + 1.) / (en * (en + 1.))) * (creal(an) * creal(bn) + cimag(an) * cimag(bn));
         if (n > 1)
             gs += ((en - 1.) * (en + 1.) / en) *
                   (creal(an1) * creal(an) + cimag(an1) * cimag(an) + creal(bn1) * creal(bn) + cimag(bn1) * cimag(bn));
-        xb += sgn * (2. * en + 1.) * (an - bn);
+        xb += (sgn * (2. * en + 1.)) * (an - bn);
         sgn = -sgn;
         psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
         an1 = an; bn1 = bn;
@@ -105,7 +122,7 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
                 num = vdry * 1.e-6 / ((pi / 6.) * dcm * dcm * dcm);
             }
             const double dwet = ddry * cbrt(vwet / vdry);
-            double complex m;
+            cplx_t m;
             double sr = 0., si = 0.;
             for (int s = 0; s < NSPEC; ++s) {
                 if (mix == 1 && s == S_BC) continue;
@@ -113,17 +130,17 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
                 si += vol[s] * t->refi[s][w];
             }
             if (mix == 0) {
-                m = (sr + I * si) / vwet;
+                m = CPLX(sr, si) / vwet;
             } else {
                 const double vbc = vol[S_BC], vmat = vwet - vbc;
-                const double complex mbc = t->refr[S_BC][w] + I * t->refi[S_BC][w];
+                const cplx_t mbc = CPLX(t->refr[S_BC][w], t->refi[S_BC][w]);
                 if (!(vmat > 1.e-30 * vwet)) m = mbc;
                 else {
-                    const double complex mm = (sr + I * si) / vmat;
+                    const cplx_t mm = CPLX(sr, si) / vmat;
                     if (!(vbc > 0.)) m = mm;
                     else {
                         const double f = vbc / vwet;
-                        const double complex em = mm * mm, ei = mbc * mbc;
+                        const cplx_t em = mm * mm, ei = mbc * mbc;
                         m = csqrt(em * (ei + 2. * em + 2. * f * (ei - em)) / (ei + 2. * em - f * (ei - em)));
                     }
                 }

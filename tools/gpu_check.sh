@@ -8,7 +8,7 @@ if [ -n "$tests" ]; then
   rc=$?; echo "tests rc=$rc"; tail -5 gpurun_out/${tag}_tests.log
   [ $rc -ne 0 ] && exit $rc
 fi
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { echo "bench failed"; tail -5 gpurun_out/${tag}_bench.err; exit 1; }
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { echo "bench failed"; tail -5 gpurun_out/${tag}_bench.err; exit 1; }
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${tag}_bench.json")); r = d["roofline"]

@@ -4,7 +4,7 @@ tag=$1; shift
 out=gpurun_out/ks_${tag}
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 "$@" > $out/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 "$@" > $out/log.txt 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

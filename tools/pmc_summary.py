@@ -84,7 +84,14 @@ def main():
                 v["columns_per_dispatch"] = cols / per_step
         except Exception:
             pass
-        out = {"source": f"profiles/{tag}_pmc.txt", "columns_per_launch": cols, "kernels": traffic,
+        try:   # the commit whose build was profiled (this script runs in the build container, where .git exists)
+            import subprocess
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
+        out = {"source": f"profiles/{tag}_pmc.txt", "source_commit": commit,
+               "collected": "builder-run rocprofv3 --pmc passes of bench.py (tools/profile_gpu.sh), not by the run that prints it",
+               "columns_per_launch": cols, "kernels": traffic,
                "hbm_bytes_per_launch": sw.get("hbm_bytes_per_launch"),
                "fetch_size_kb": sw.get("fetch_size_kb"), "write_size_kb": sw.get("write_size_kb")}
         # traffic_latest.json is what bench.py reads: keep it on the default workload (pass --keep-latest for others)

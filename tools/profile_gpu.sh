@@ -12,7 +12,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 # the bench workload to profile: default = bench.py's default (BASELINE configs[3]); extra arguments are passed on,
 # e.g.  bash tools/profile_gpu.sh r02_c2 --config 2
-cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 "$@")
+cmd=(python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 "$@")
 "${cmd[@]}" > "$out/bench.json" 2> "$out/bench.err" || echo "plain bench run failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o trace -- "${cmd[@]}" > "$out/trace.log" 2>&1
 echo "trace done"
