@@ -724,8 +724,27 @@ def main():
                 hs = (time.perf_counter() - t1) / 2
                 line["host_path"] = {"columns_per_s": rows * ni / hs, "columns": rows * ni, "seconds_per_call_pair": hs,
                                      "what": "rrtmg_hip_swrad" + (" + rrtmg_hip_lwrad" if do_lw else "") +
-                                             " with mem = 0 (host arrays, staged over PCIe per call: the call the "
+                                             " with mem = 0 (host arrays: packed in j-chunks, staged over PCIe and "
+                                             "run on the calling thread's stream, chunks overlapping -- the call the "
                                              "Fortran shim makes); radiation only, never `value`"}
+                if do_opt:
+                    # the optical-averaging entry module_optical_averaging_hip.F90 calls, host arrays as well
+                    oh_in = dict(chem=np.ascontiguousarray(ms.chem), alt=np.ascontiguousarray(ms.alt),
+                                 dz8w=np.ascontiguousarray(ms.dz8w))
+                    oh_out = {n: np.zeros((st.nj, nk + 1, ni)) for n in opt_out}
+
+                    def host_opt():
+                        wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **dh, **oh_in, **oh_out)
+                    host_opt()
+                    t1 = time.perf_counter()
+                    for _ in range(2):
+                        host_opt()
+                    ho = (time.perf_counter() - t1) / 2
+                    line["host_path"]["optics"] = {
+                        "columns_per_s": rows * ni / ho, "seconds_per_call": ho,
+                        "what": "rrtmg_hip_optical_averaging with mem = 0 on the same rows: the section tracers of every "
+                                "cell over PCIe in, 28 fields per cell out"}
+                    line["host_path"]["whole_step_columns_per_s"] = rows * ni / (hs + ho)
             except Exception as e:
                 line["host_path"] = {"error": repr(e)}
         print(json.dumps(line))

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "rrtmg_state.h"
 #include "sw_kernel.h"
 #include "tile_staging.h"
+#include "lw_state.h"
 
 namespace rrtmg {
 
@@ -21,6 +23,14 @@ SwState &sw_state()
 {
     static SwState s;
     return s;
+}
+
+// The staging buffers and streams of the host threads (tile_staging.h) serve all three entry-point families: they are
+// released by whichever finalize comes last.
+bool optics_ready();   // c_abi_optics.hip
+void stage_pools_release_if_idle()
+{
+    if (!sw_state().ready && !lw_state().ready && !optics_ready()) stage_pools_release();
 }
 
 namespace {
@@ -297,13 +307,14 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         stg.out(a->swupflx, nk_m + 2, 1, &k.swupflx); stg.out(a->swupflxc, nk_m + 2, 1, &k.swupflxc);
         stg.out(a->swupflxcln, nk_m + 2, 1, &k.swupflxcln); stg.out(a->swdnflx, nk_m + 2, 1, &k.swdnflx);
         stg.out(a->swdnflxc, nk_m + 2, 1, &k.swdnflxc); stg.out(a->swdnflxcln, nk_m + 2, 1, &k.swdnflxcln);
-        HIPCHK(stg.upload(stream));
-        k.status = stg.status_word();
+        // chunks of the tile, all on this thread's own stream (tile_staging.h)
+        HIPCHK(stg.begin(stage_chunk_columns()));
+        stream = stg.stream();
 #undef OUT2
 #undef IN2
 #undef IN3
     }
-    if (!(k.xcoszen && k.albedo && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
+    if (!(a->xcoszen && a->albedo && a->t3d && a->t8w && a->p3d && a->p8w && a->pi3d && a->qv3d))
         return fail(err, "rrtmg_hip_swrad: a required input array is NULL");
     if (a->swupt && !(a->swuptc && a->swuptcln && a->swdnt && a->swdntc && a->swdntcln && a->swupb && a->swupbc &&
                       a->swupbcln && a->swdnb && a->swdnbc && a->swdnbcln))
@@ -313,7 +324,12 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
     // quarter of the device's free memory; the buffer only grows to what the largest tile so far needed, and a
     // device that cannot spare it gets smaller batches)
     {
-        const int ncol_all = ni_t * nj_t;
+        const int nchunk = a->mem == 1 ? 1 : stg.nchunks();
+        int ncol_all = ni_t * nj_t;     // columns of the largest launch unit: the tile, or its largest chunk
+        if (a->mem != 1) {
+            ncol_all = 0;
+            for (int c = 0; c < nchunk; ++c) ncol_all = std::max(ncol_all, ni_t * stg.chunk_nj(c));
+        }
         size_t mb = default_scratch_mb(32768);
         if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
             const long v = std::atol(e);
@@ -324,7 +340,7 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
         if (cols < 8) cols = 8;
         int cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
         {
-            std::lock_guard<std::mutex> lock(st.jump_mutex);
+            std::unique_lock<std::mutex> lock(st.jump_mutex);
             SwState::Scratch &w = st.scratch[stream];
             if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
             if (w.doubles < percol * (size_t)cap_cols) {
@@ -345,24 +361,38 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                 cap_cols = (int)(w.doubles / percol);
             }
             k.scratch = w.p;
-            // launched under the lock: another host thread on this stream may not resize the buffer in between
             k.scratch_stride = percol;
-            for (int c0 = 0; c0 < ncol_all; c0 += cap_cols) {
-                k.col0 = c0;
-                k.ncol = ncol_all - c0 < cap_cols ? ncol_all - c0 : cap_cols;
-                HIPCHK(sw_launch(k, stream));
+            // mem = 1: launched under the lock -- another host thread on the caller's stream may not resize the buffer
+            // in between.  mem = 0: the stream and its scratch belong to this thread alone; the lock is dropped so
+            // that concurrent tiles pack and enqueue side by side.
+            if (a->mem != 1) lock.unlock();
+            for (int c = 0; c < nchunk; ++c) {
+                int ncol_c = ni_t * nj_t;
+                if (a->mem != 1) {
+                    HIPCHK(stg.stage(c));          // pack + H2D of this chunk; sets the array pointers of k
+                    k.jms = k.jts = a->jts + stg.chunk_j0(c);
+                    k.nj_m = k.nj_t = stg.chunk_nj(c);
+                    k.status = stg.status_word(c);
+                    ncol_c = ni_t * k.nj_t;
+                }
+                for (int c0 = 0; c0 < ncol_c; c0 += cap_cols) {
+                    k.col0 = c0;
+                    k.ncol = ncol_c - c0 < cap_cols ? ncol_c - c0 : cap_cols;
+                    HIPCHK(sw_launch(k, stream));
+                }
+                if (a->mem != 1) HIPCHK(stg.fetch(c));
             }
         }
     }
 
     if (a->mem != 1) {
-        int status = 0;
-        HIPCHK(stg.download(stream, &status));
+        int status = 0, chunk = 0;
+        HIPCHK(stg.finish(&status, &chunk));
         if (status != 0) {
-            const int col = (status & 0x0fffffff) - 1;
+            const int col = (status & 0x0fffffff) - 1;   // column of the chunk that raised it
             char m[RRTMG_HIP_ERRLEN];
             std::snprintf(m, sizeof m, "%s at point i,j=%5d%5d", sw_status_text(status >> 28),
-                          a->its + col % ni_t, a->jts + col / ni_t);   // SW:11031-11033, SW:2169-2173
+                          a->its + col % ni_t, a->jts + stg.chunk_j0(chunk) + col / ni_t);   // SW:11031-11033, SW:2169-2173
             return fail(err, m);
         }
     }
@@ -399,7 +429,7 @@ extern "C" int rrtmg_hip_finalize(void)
     for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     st.scratch.clear();
     st.dK = st.dExp = st.dG = st.dStatus = st.dCld = nullptr;
-    stage_pools_release();
     st.ready = false;
+    stage_pools_release_if_idle();
     return 0;
 }

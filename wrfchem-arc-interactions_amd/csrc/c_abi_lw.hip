@@ -1,6 +1,8 @@
 // Longwave entry points of the C ABI (include/rrtmg_hip.h).  No CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -274,14 +276,15 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         OUT2(lwupt); OUT2(lwuptc); OUT2(lwuptcln); OUT2(lwdnt); OUT2(lwdntc); OUT2(lwdntcln);
         OUT2(lwupb); OUT2(lwupbc); OUT2(lwupbcln); OUT2(lwdnb); OUT2(lwdnbc); OUT2(lwdnbcln);
         OUTF(lwupflx); OUTF(lwupflxc); OUTF(lwupflxcln); OUTF(lwdnflx); OUTF(lwdnflxc); OUTF(lwdnflxcln);
-        HIPCHK(stg.upload(stream));
-        k.status = stg.status_word();
+        // chunks of the tile, all on this thread's own stream (tile_staging.h)
+        HIPCHK(stg.begin(stage_chunk_columns()));
+        stream = stg.stream();
 #undef OUT2
 #undef OUTF
 #undef IN2
 #undef IN3
     }
-    if (!(k.emiss && k.tsk && k.t3d && k.t8w && k.p3d && k.p8w && k.pi3d && k.qv3d))
+    if (!(a->emiss && a->tsk && a->t3d && a->t8w && a->p3d && a->p8w && a->pi3d && a->qv3d))
         return failw(err, "rrtmg_hip_lwrad: a required input array is NULL");
     if (a->lwupt && !(a->lwuptc && a->lwuptcln && a->lwdnt && a->lwdntc && a->lwdntcln && a->lwupb && a->lwupbc &&
                       a->lwupbcln && a->lwdnb && a->lwdnbc && a->lwdnbcln))
@@ -291,7 +294,12 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
 
     // scratch of this stream: as many columns per batch as RRTMG_HIP_LW_SCRATCH_MB holds (default: 16 GiB, at most a
     // quarter of the device's free memory; grow-only, smaller batches when the device cannot spare it)
-    const int ncol = ni_t * nj_t;
+    const int nchunk = a->mem == 1 ? 1 : stg.nchunks();
+    int ncol = ni_t * nj_t;     // columns of the largest launch unit: the tile, or its largest chunk
+    if (a->mem != 1) {
+        ncol = 0;
+        for (int c = 0; c < nchunk; ++c) ncol = std::max(ncol, ni_t * stg.chunk_nj(c));
+    }
     double *scratch = nullptr;
     int cap_cols = 0;
     {
@@ -304,7 +312,7 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
         size_t cols = (mb << 20) / (percol * sizeof(double));
         if (cols < 8) cols = 8;
         cap_cols = (size_t)ncol < cols ? ncol : (int)cols;
-        std::lock_guard<std::mutex> lock(st.scratch_mutex);
+        std::unique_lock<std::mutex> lock(st.scratch_mutex);
         LwState::Scratch &w = st.scratch[stream];
         if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
         if (w.doubles < percol * (size_t)cap_cols) {
@@ -322,19 +330,33 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             w.doubles = percol * (size_t)cap_cols;
         }
         scratch = w.p;
-        // the gas and transfer kernels of one call hand their batch over through this buffer: host threads that
-        // share a stream enqueue their kernel sequences one call at a time
-        HIPCHK(lw_launch(k, ncol, scratch, cap_cols, stream));
+        // the gas and transfer kernels of one call hand their batch over through this buffer.  mem = 1: host threads
+        // that share the caller's stream enqueue their kernel sequences one call at a time, under the lock.  mem = 0:
+        // stream and scratch belong to this thread alone; the lock is dropped so that concurrent tiles pack and
+        // enqueue side by side.
+        if (a->mem != 1) lock.unlock();
+        for (int c = 0; c < nchunk; ++c) {
+            int ncol_c = ni_t * nj_t;
+            if (a->mem != 1) {
+                HIPCHK(stg.stage(c));          // pack + H2D of this chunk; sets the array pointers of k
+                k.jms = k.jts = a->jts + stg.chunk_j0(c);
+                k.nj_m = k.nj_t = stg.chunk_nj(c);
+                k.status = stg.status_word(c);
+                ncol_c = ni_t * k.nj_t;
+            }
+            HIPCHK(lw_launch(k, ncol_c, scratch, cap_cols, stream));
+            if (a->mem != 1) HIPCHK(stg.fetch(c));
+        }
     }
 
     if (a->mem != 1) {
-        int status = 0;
-        HIPCHK(stg.download(stream, &status));
+        int status = 0, chunk = 0;
+        HIPCHK(stg.finish(&status, &chunk));
         if (status != 0) {
-            const int col = (status & 0x0fffffff) - 1;
+            const int col = (status & 0x0fffffff) - 1;   // column of the chunk that raised it
             char m[RRTMG_HIP_ERRLEN];
             std::snprintf(m, sizeof m, "%s at point i,j=%5d%5d", lw_status_text(status >> 28),
-                          a->its + col % ni_t, a->jts + col / ni_t);   // LW:12613-12615, LW:2831-2836
+                          a->its + col % ni_t, a->jts + stg.chunk_j0(chunk) + col / ni_t);   // LW:12613-12615, LW:2831-2836
             return failw(err, m);
         }
     }
@@ -371,5 +393,6 @@ extern "C" int rrtmg_hip_lw_finalize(void)
         st.scratch.clear();
     }
     st.ready = false;
+    stage_pools_release_if_idle();
     return 0;
 }

@@ -178,12 +178,24 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
         for (int b = 0; b < OPT_NLW; ++b) {
             stg.out(a->tauaerlw[b], nk_m, 1, &k.tauaerlw[b]); stg.out(a->extaerlw[b], nk_m, 1, &k.extaerlw[b]);
         }
-        HIPCHK(stg.upload(stream));
+        // chunks of the tile, all on this thread's own stream (tile_staging.h): this stage moves the most bytes per
+        // column of the three (80 tracers in, 28 fields out per cell), so the overlap of packing, copies and kernels
+        // matters most here
+        HIPCHK(stg.begin(stage_chunk_columns()));
+        stream = stg.stream();
     }
-    HIPCHK(optics_launch(k, stream, g_opt.precision));
+    const int nchunk = a->mem == 1 ? 1 : stg.nchunks();
+    for (int c = 0; c < nchunk; ++c) {
+        if (a->mem != 1) {
+            HIPCHK(stg.stage(c));
+            k.nj_m = k.nj_t = stg.chunk_nj(c);
+        }
+        HIPCHK(optics_launch(k, stream, g_opt.precision));
+        if (a->mem != 1) HIPCHK(stg.fetch(c));
+    }
     if (a->mem != 1) {
         int status = 0;
-        HIPCHK(stg.download(stream, &status));
+        HIPCHK(stg.finish(&status, nullptr));
     }
     return 0;
 }
@@ -198,7 +210,10 @@ extern "C" int rrtmg_hip_optics_precision(int mode, char *err)
 
 extern "C" int rrtmg_hip_optics_finalize(void)
 {
-    std::lock_guard<std::mutex> lock(g_opt_mutex);
-    g_opt.ready = false;
+    {
+        std::lock_guard<std::mutex> lock(g_opt_mutex);
+        g_opt.ready = false;
+    }
+    stage_pools_release_if_idle();
     return 0;
 }

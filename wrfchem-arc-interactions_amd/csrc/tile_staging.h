@@ -1,15 +1,36 @@
 // Staging of a mem = 0 call (host arrays, what the Fortran shims pass): only the tile its:ite x jts:jte of every array
-// travels.  The host side packs the tile of each array into ONE pinned buffer ([block][j][k][i] with the tile's own
-// extents), one H2D copy brings it to the device, the kernels run on the packed arrays (memory dimensions = tile
-// dimensions), one D2H copy brings the output region back and the host side scatters it into the tile of the
-// caller's arrays.  Nothing outside the tile is read or written, so OpenMP tile loops that share their WRF arrays
-// (DRV:975-982) can call concurrently: tiles are disjoint, and every host thread owns its pinned and device buffers
-// (grow-only, reused from call to call -- no hipMalloc / hipFree per call) and its status word.
+// travels, and it travels in j-CHUNKS so that the stages of neighbouring chunks overlap:
+//
+//     host thread     pack 0 | pack 1 | pack 2 | ...                             | scatter outputs
+//     copy-in stream      H2D 0 | H2D 1 | H2D 2 | ...
+//     compute stream            kernels 0 | kernels 1 | kernels 2 | ...
+//     copy-out stream                       D2H 0 |     D2H 1 |     D2H 2 | ...
+//
+// The host side packs the rows of a chunk of each array into the chunk's block of ONE pinned buffer ([block][j][k][i]
+// with the chunk's own extents), one asynchronous H2D copy brings the block to the device, the kernels run on the
+// packed arrays (memory dimensions = chunk dimensions), one asynchronous D2H copy brings the chunk's output region
+// back; while the device works on chunk c the host packs chunk c + 1 and the link carries chunk c + 1 in and chunk
+// c - 1 out (three non-blocking streams per calling thread, chained by events: on ONE stream the copies and kernels
+// of successive chunks would run one after the other -- measured: 19.4 ms per call pair for 20 000 columns against
+// 5.8 ms of link time and 8.4 ms of kernel time).  Concurrent OpenMP tiles (DRV:975-982) do not serialise on the null
+// stream, and the call returns after one wait on the copy-out stream and the scatter of the outputs into the
+// caller's tile.
+// Nothing outside the tile is read or written; tiles of concurrent callers are disjoint, and every host thread owns
+// its pinned and device buffers (grow-only, reused from call to call -- no hipMalloc / hipFree per call; a thread
+// that ends hands its buffers to the next new thread) and its status words (one per chunk).
+// The packing itself is plain memory copying (a patch of a production domain is hundreds of MB per call, one core
+// moves about 5 GB/s): a small persistent pool of helper threads shares the (array, row) items of a chunk with the
+// caller; when several tiles call at once only one of them gets the helpers, the others pack alone.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -43,9 +64,98 @@ struct TileGeom {
     size_t rb;              // bytes per element (4 or 8)
 };
 
+// ---- helper threads for the packing (persistent; RRTMG_HIP_PACK_THREADS = helpers besides the caller, default up
+// to 7, 0 = none) ----
+class PackPool {
+public:
+    static PackPool &instance()
+    {
+        static PackPool p;
+        return p;
+    }
+    // fn(i) for i in [0, n): shared with the helpers when they are free, else done by the caller alone
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (workers_.empty() || n < 4 || !busy_.try_lock()) {
+            for (int i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            fn_ = &fn; n_ = n; next_.store(0); pending_ = (int)workers_.size(); ++gen_;
+        }
+        cv_.notify_all();
+        work(fn, n);
+        {
+            std::unique_lock<std::mutex> lock(m_);
+            done_.wait(lock, [&] { return pending_ == 0; });
+            fn_ = nullptr;
+        }
+        busy_.unlock();
+    }
+
+private:
+    PackPool()
+    {
+        int n = (int)std::thread::hardware_concurrency() / 2 - 1;
+        if (n > 7) n = 7;
+        if (const char *e = std::getenv("RRTMG_HIP_PACK_THREADS")) n = std::atoi(e);
+        if (n < 0) n = 0;
+        if (n > 31) n = 31;
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~PackPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true; ++gen_;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void work(const std::function<void(int)> &fn, int n)
+    {
+        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) fn(i);
+    }
+    void loop()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_; n = n_;
+            }
+            if (fn) work(*fn, n);
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (--pending_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, busy_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, pending_ = 0;
+    std::atomic<int> next_{0};
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
+// ---- per-thread staging buffers and stream ----
 struct StagePool {
     void *pin = nullptr, *dev = nullptr;
     size_t pin_cap = 0, dev_cap = 0;
+    // non-blocking streams, created at the pool's first use on the engine's device: kernels; copies in; copies out
+    hipStream_t stream = nullptr, h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_in[16] = {}, ev_k[16] = {};   // chunk c is on the device / chunk c's kernels are done
+    bool in_use = false;            // owned by a live thread (guarded by stage_pools_mutex)
 };
 
 // all pools ever created, so that the finalize entry points can release them
@@ -59,54 +169,130 @@ inline std::mutex &stage_pools_mutex()
     static std::mutex m;
     return m;
 }
+struct StagePoolHolder {
+    StagePool *p = nullptr;
+    ~StagePoolHolder()
+    {
+        // the thread ends (possibly long after the HIP runtime): no HIP call here, the pool -- buffers and stream --
+        // goes back to the list and the next new thread takes it over
+        if (!p) return;
+        std::lock_guard<std::mutex> lock(stage_pools_mutex());
+        p->in_use = false;
+    }
+};
 inline StagePool &thread_stage_pool()
 {
-    static thread_local StagePool *p = nullptr;
-    if (!p) {
-        p = new StagePool();   // lives until stage_pools_release(): a thread may end long after the HIP runtime
+    static thread_local StagePoolHolder h;
+    if (!h.p) {
         std::lock_guard<std::mutex> lock(stage_pools_mutex());
-        stage_pools().push_back(p);
+        for (StagePool *q : stage_pools())
+            if (!q->in_use) { h.p = q; break; }
+        if (!h.p) {
+            h.p = new StagePool();   // lives until the process ends; its buffers until stage_pools_release()
+            stage_pools().push_back(h.p);
+        }
+        h.p->in_use = true;
     }
-    return *p;
+    return *h.p;
 }
+// Frees the buffers and streams of every pool.  Called by the finalize entry points once no engine is initialised any
+// more (c_abi.hip: stage_pools_release_if_idle); a host must not finalize while other threads are inside a call.
 inline void stage_pools_release()
 {
     std::lock_guard<std::mutex> lock(stage_pools_mutex());
     for (StagePool *p : stage_pools()) {
+        for (hipStream_t *q : {&p->stream, &p->h2d, &p->d2h})
+            if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+        for (int i = 0; i < 16; ++i) {
+            if (p->ev_in[i]) { (void)hipEventDestroy(p->ev_in[i]); p->ev_in[i] = nullptr; }
+            if (p->ev_k[i]) { (void)hipEventDestroy(p->ev_k[i]); p->ev_k[i] = nullptr; }
+        }
         if (p->pin) (void)hipHostFree(p->pin);
         if (p->dev) (void)hipFree(p->dev);
         p->pin = p->dev = nullptr;
         p->pin_cap = p->dev_cap = 0;
     }
 }
+void stage_pools_release_if_idle();   // c_abi.hip: when the SW, LW and optics engines are all finalized
+
+// columns a chunk of a mem = 0 call should hold: enough to fill the device a few times over, small enough that four
+// or more chunks overlap on a production patch (RRTMG_HIP_CHUNK_COLS overrides)
+inline long stage_chunk_columns()
+{
+    static const long v = [] {
+        long n = 4096;
+        if (const char *e = std::getenv("RRTMG_HIP_CHUNK_COLS")) { const long q = std::atol(e); if (q > 0) n = q; }
+        return n;
+    }();
+    return v;
+}
 
 class TileStager {
 public:
-    explicit TileStager(const TileGeom &g) : g_(g) { used_ = 64; }   // [0, 64): the call's status word (+ padding)
+    static constexpr int MAX_CHUNKS = 16;   // one status word each in the first 64 bytes of the buffers
+    explicit TileStager(const TileGeom &g) : g_(g) {}
 
     // kext: extent of the k dimension in memory (1 for a 2-D array, nk_m, nk_m + 2 for the flux profiles);
-    // nblk: leading blocks of a 4-D array (i,k,j,block).  target receives the device address in upload().
+    // nblk: leading blocks of a 4-D array (i,k,j,block).  target receives the chunk's device address in stage().
     void in(const void *host, int kext, int nblk, const void **target)
     {
         *target = nullptr;
         if (!host) return;
-        reqs_.push_back({host, nullptr, kext, nblk, used_, target, nullptr});
-        used_ += bytes(kext, nblk);
+        reqs_.push_back({host, nullptr, kext, nblk, target, nullptr});
     }
     void out(void *host, int kext, int nblk, void **target)
     {
         *target = nullptr;
         if (!host) return;
-        if (out_begin_ == SIZE_MAX) out_begin_ = used_;
-        reqs_.push_back({host, host, kext, nblk, used_, nullptr, target});
-        used_ += bytes(kext, nblk);
+        reqs_.push_back({host, host, kext, nblk, nullptr, target});
     }
 
-    // pack inputs (and the current contents of the outputs: INOUT semantics, the routines leave night columns and
-    // unwritten fields as they were), copy to the device, hand out the device addresses
-    hipError_t upload(hipStream_t s)
+    // The calling thread's streams: the kernels of the call go to stream(), the copies to its two companions.
+    hipError_t open()
     {
-        StagePool &p = thread_stage_pool();
+        pool_ = &thread_stage_pool();
+        StagePool &p = *pool_;
+        if (p.stream) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking);
+        for (int i = 0; i < MAX_CHUNKS && e == hipSuccess; ++i) {
+            e = hipEventCreateWithFlags(&p.ev_in[i], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev_k[i], hipEventDisableTiming);
+        }
+        return e;
+    }
+    hipStream_t stream() const { return pool_->stream; }
+
+    // Cuts the tile into j-chunks of about `cols_per_chunk` columns (at most MAX_CHUNKS, at least one row each) and
+    // sizes the buffers for the whole tile; the inputs of a chunk precede its outputs in the chunk's block.
+    hipError_t begin(long cols_per_chunk)
+    {
+        if (!pool_) { hipError_t e = open(); if (e != hipSuccess) return e; }
+        std::stable_partition(reqs_.begin(), reqs_.end(), [](const Req &r) { return r.hout == nullptr; });
+        long rows = cols_per_chunk / (g_.ni_t > 0 ? g_.ni_t : 1);
+        if (rows < 1) rows = 1;
+        int nc = (int)((g_.nj_t + rows - 1) / rows);
+        if (nc > MAX_CHUNKS) nc = MAX_CHUNKS;
+        if (nc < 1) nc = 1;
+        chunks_.clear();
+        size_t off = 64;   // [0, 64): the status words
+        for (int c = 0; c < nc; ++c) {
+            Chunk ch;
+            ch.j0 = (int)((long)g_.nj_t * c / nc);
+            ch.nj = (int)((long)g_.nj_t * (c + 1) / nc) - ch.j0;
+            ch.off = off;
+            ch.out_off = SIZE_MAX;
+            for (const Req &r : reqs_) {
+                if (r.hout && ch.out_off == SIZE_MAX) ch.out_off = off;
+                ch.req_off.push_back(off);
+                off += bytes(r.kext, r.nblk, ch.nj);
+            }
+            ch.end = off;
+            chunks_.push_back(ch);
+        }
+        used_ = off;
+        StagePool &p = *pool_;
         if (p.pin_cap < used_) {
             if (p.pin) (void)hipHostFree(p.pin);
             p.pin = nullptr; p.pin_cap = 0;
@@ -115,37 +301,65 @@ public:
             p.pin_cap = used_ + used_ / 4;
         }
         if (p.dev_cap < used_) {
-            if (p.dev) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e; (void)hipFree(p.dev); }
+            if (p.dev) (void)hipFree(p.dev);   // the previous call on these buffers ended with a wait for all of its work
             p.dev = nullptr; p.dev_cap = 0;
             hipError_t e = hipMalloc(&p.dev, used_ + used_ / 4);
             if (e != hipSuccess) return e;
             p.dev_cap = used_ + used_ / 4;
         }
-        pool_ = &p;
         std::memset(p.pin, 0, 64);
-        for (const Req &r : reqs_) {
-            copy_tile(r, true);
-            char *d = static_cast<char *>(p.dev) + r.off;
-            if (r.in_target) *r.in_target = d;
-            if (r.out_target) *r.out_target = d;
-        }
-        return hipMemcpyAsync(p.dev, p.pin, used_, hipMemcpyHostToDevice, s);
+        return hipMemcpyAsync(p.dev, p.pin, 64, hipMemcpyHostToDevice, p.h2d);   // in front of chunk 0 on that stream
     }
-    int *status_word() const { return static_cast<int *>(pool_->dev); }
+    int nchunks() const { return (int)chunks_.size(); }
+    int chunk_j0(int c) const { return chunks_[c].j0; }
+    int chunk_nj(int c) const { return chunks_[c].nj; }
+    int *status_word(int c) const { return static_cast<int *>(pool_->dev) + c; }
 
-    // bring the output region and the status word back, wait, scatter into the caller's tiles
-    hipError_t download(hipStream_t s, int *status)
+    // pack the rows of chunk c (inputs, and the current contents of the outputs: INOUT semantics, the routines leave
+    // night columns and unwritten fields as they were), enqueue its H2D copy, hand out its device addresses
+    hipError_t stage(int c)
+    {
+        const Chunk &ch = chunks_[c];
+        StagePool &p = *pool_;
+        copy_chunk(ch, true, false);
+        for (size_t r = 0; r < reqs_.size(); ++r) {
+            char *d = static_cast<char *>(p.dev) + ch.req_off[r];
+            if (reqs_[r].in_target) *reqs_[r].in_target = d;
+            if (reqs_[r].out_target) *reqs_[r].out_target = d;
+        }
+        hipError_t e = hipMemcpyAsync(static_cast<char *>(p.dev) + ch.off, static_cast<char *>(p.pin) + ch.off,
+                                      ch.end - ch.off, hipMemcpyHostToDevice, p.h2d);
+        if (e == hipSuccess) e = hipEventRecord(p.ev_in[c], p.h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p.stream, p.ev_in[c], 0);   // the chunk's kernels wait for it
+        return e;
+    }
+    // behind the chunk's kernels: the D2H copy of its output region, on the copy-out stream
+    hipError_t fetch(int c)
+    {
+        const Chunk &ch = chunks_[c];
+        StagePool &p = *pool_;
+        hipError_t e = hipEventRecord(p.ev_k[c], p.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p.d2h, p.ev_k[c], 0);
+        if (e != hipSuccess || ch.out_off == SIZE_MAX) return e;
+        return hipMemcpyAsync(static_cast<char *>(p.pin) + ch.out_off, static_cast<char *>(p.dev) + ch.out_off,
+                              ch.end - ch.out_off, hipMemcpyDeviceToHost, p.d2h);
+    }
+    // status words back, one wait on the stream, outputs scattered into the caller's tile.  *status = the first
+    // non-zero status word, *chunk the chunk that raised it.
+    hipError_t finish(int *status, int *chunk)
     {
         StagePool &p = *pool_;
-        hipError_t e = hipMemcpyAsync(p.pin, p.dev, 64, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && out_begin_ != SIZE_MAX)
-            e = hipMemcpyAsync(static_cast<char *>(p.pin) + out_begin_, static_cast<char *>(p.dev) + out_begin_,
-                               used_ - out_begin_, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // the copy-out stream has waited for every chunk's kernels (fetch), so its end is the call's end
+        hipError_t e = hipMemcpyAsync(p.pin, p.dev, 64, hipMemcpyDeviceToHost, p.d2h);
+        if (e == hipSuccess) e = hipStreamSynchronize(p.d2h);
         if (e != hipSuccess) return e;
-        *status = *static_cast<int *>(p.pin);
-        for (const Req &r : reqs_)
-            if (r.hout) copy_tile(r, false);
+        *status = 0;
+        if (chunk) *chunk = 0;
+        for (int c = 0; c < nchunks(); ++c) {
+            const int s = static_cast<const int *>(p.pin)[c];
+            if (s != 0) { *status = s; if (chunk) *chunk = c; break; }
+        }
+        for (const Chunk &ch : chunks_) copy_chunk(ch, false, true);
         return hipSuccess;
     }
     size_t staged_bytes() const { return used_; }
@@ -155,46 +369,50 @@ private:
         const void *hin;
         void *hout;
         int kext, nblk;
-        size_t off;
         const void **in_target;
         void **out_target;
     };
-    size_t bytes(int kext, int nblk) const
+    struct Chunk {
+        int j0, nj;
+        size_t off, out_off, end;
+        std::vector<size_t> req_off;
+    };
+    size_t bytes(int kext, int nblk, int nj) const
     {
-        const size_t b = (size_t)nblk * g_.nj_t * kext * g_.ni_t * g_.rb;
+        const size_t b = (size_t)nblk * nj * kext * g_.ni_t * g_.rb;
         return (b + 63) & ~size_t(63);
     }
-    void copy_rows(const Req &r, bool to_pinned, int j0, int j1) const
+    // one (request, row) item: the row's kext x nblk segments of ni_t elements
+    void copy_row(const Chunk &ch, size_t ri, int j, bool to_pinned) const
     {
+        const Req &r = reqs_[ri];
         const size_t row = (size_t)g_.ni_t * g_.rb;
-        char *pk = static_cast<char *>(pool_->pin) + r.off;
+        char *pk = static_cast<char *>(pool_->pin) + ch.req_off[ri];
         for (int b = 0; b < r.nblk; ++b)
-            for (int j = j0; j < j1; ++j)
-                for (int k = 0; k < r.kext; ++k) {
-                    const size_t h = ((((size_t)b * g_.nj_m + (g_.j0 + j)) * r.kext + k) * g_.ni_m + g_.i0) * g_.rb;
-                    const size_t q = (((size_t)b * g_.nj_t + j) * r.kext + k) * row;
-                    if (to_pinned) std::memcpy(pk + q, static_cast<const char *>(r.hin) + h, row);
-                    else std::memcpy(static_cast<char *>(r.hout) + h, pk + q, row);
-                }
+            for (int k = 0; k < r.kext; ++k) {
+                const size_t h = ((((size_t)b * g_.nj_m + (g_.j0 + ch.j0 + j)) * r.kext + k) * g_.ni_m + g_.i0) * g_.rb;
+                const size_t q = (((size_t)b * ch.nj + j) * r.kext + k) * row;
+                if (to_pinned) std::memcpy(pk + q, static_cast<const char *>(r.hin) + h, row);
+                else std::memcpy(static_cast<char *>(r.hout) + h, pk + q, row);
+            }
     }
-    // the packing is plain memory copying; large arrays are split over a few helper threads by rows (a patch of a
-    // production domain is hundreds of MB per call, one core moves about 5 GB/s)
-    void copy_tile(const Req &r, bool to_pinned) const
+    void copy_chunk(const Chunk &ch, bool to_pinned, bool outputs_only) const
     {
-        const size_t total = (size_t)r.nblk * g_.nj_t * r.kext * g_.ni_t * g_.rb;
-        unsigned nt = total >= (size_t(4) << 20) ? std::thread::hardware_concurrency() : 1;
-        if (nt > 8) nt = 8;
-        if (nt > (unsigned)g_.nj_t) nt = (unsigned)g_.nj_t;
-        if (nt <= 1) { copy_rows(r, to_pinned, 0, g_.nj_t); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t)
-            th.emplace_back([=, &r] { copy_rows(r, to_pinned, (int)((size_t)g_.nj_t * t / nt), (int)((size_t)g_.nj_t * (t + 1) / nt)); });
-        copy_rows(r, to_pinned, 0, (int)((size_t)g_.nj_t / nt));
-        for (auto &x : th) x.join();
+        size_t first = 0;
+        if (outputs_only)
+            while (first < reqs_.size() && !reqs_[first].hout) ++first;
+        const int nreq = (int)(reqs_.size() - first), nj = ch.nj;
+        if (nreq <= 0) return;
+        size_t total = 0;
+        for (size_t r = first; r < reqs_.size(); ++r) total += (size_t)reqs_[r].nblk * nj * reqs_[r].kext * g_.ni_t * g_.rb;
+        const std::function<void(int)> item = [&](int it) { copy_row(ch, first + (size_t)(it / nj), it % nj, to_pinned); };
+        if (total < (size_t(2) << 20)) { for (int it = 0; it < nreq * nj; ++it) item(it); }
+        else PackPool::instance().run(nreq * nj, item);
     }
     TileGeom g_;
     std::vector<Req> reqs_;
-    size_t used_ = 0, out_begin_ = SIZE_MAX;
+    std::vector<Chunk> chunks_;
+    size_t used_ = 0;
     StagePool *pool_ = nullptr;
 };
 
