@@ -117,6 +117,7 @@ extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, dou
     st.host = std::move(host);
     st.device = device;
     st.nlayers = lw_nlayers_of(kme, p_top_pa, data_real_bytes);
+    st.kme = kme; st.p_top_pa = p_top_pa;
     st.ready = true;
     return 0;
 }
@@ -193,7 +194,9 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     if (nk < 2 || a->its < a->ims || a->ite > a->ime || a->jts < a->jms ||
         a->jte > a->jme || a->kts < a->kms || a->kte + 1 > a->kme)
         return failw(err, "rrtmg_hip_lwrad: inconsistent tile / memory dimensions");
-    const int nl = st.nlayers;
+    // NLAYERS in the precision of THIS call's REAL (LW:12861 evaluates it in default REAL): the same number as at init
+    // unless the quotient sits next to .5 and the table file's width differs from the arrays'
+    const int nl = lw_nlayers_of(st.kme, st.p_top_pa, a->real_bytes);
     if (nl < nk + 1 || nl > 200) return failw(err, "rrtmg_hip_lwrad: NLAYERS from rrtmg_hip_lw_init does not fit this tile");
     if (lw_gas_lds_bytes(nl) > 160 * 1024 - 64 || lw_rt_lds_bytes(nl) > 160 * 1024 - 64)
         return failw(err, "rrtmg_hip_lwrad: column does not fit LDS");

@@ -20,7 +20,9 @@ int lw_build_tables(const char *path, int real_bytes, double cpdair, LwHostTable
 struct LwState {
     bool ready = false;
     int device = 0;
-    int nlayers = 0;         // module variable NLAYERS of rrtmg_lwinit (LW:12861)
+    int nlayers = 0;         // module variable NLAYERS of rrtmg_lwinit (LW:12861), in the REAL of the table file
+    int kme = 0;             // what NLAYERS was formed from: a call whose arrays have the other REAL width forms it
+    double p_top_pa = 0.;    // again in its own precision (rrtmg_hip_lwrad)
     LwHostTables host;
     LwDeviceTables dev{};
     void *dK = nullptr, *dExp = nullptr, *dTfn = nullptr, *dPlk = nullptr, *dChi = nullptr, *dG = nullptr,

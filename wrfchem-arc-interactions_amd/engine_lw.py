@@ -44,6 +44,7 @@ def _lib():
     if not _ready:
         lib.rrtmg_hip_lw_init.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char_p]
         lib.rrtmg_hip_lw_nlayers.argtypes = [C.c_int, C.c_double]
+        lib.rrtmg_hip_lw_nlayers_real.argtypes = [C.c_int, C.c_double, C.c_int]
         lib.rrtmg_hip_lwrad.argtypes = [C.POINTER(LwradArgs), C.c_char_p]
         lib.rrtmg_hip_lw_status.argtypes = [C.c_char_p]
         lib.rrtmg_hip_lw_reduce_tables.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_void_p, C.c_longlong,
@@ -53,8 +54,10 @@ def _lib():
     return lib
 
 
-def lw_nlayers(kme, p_top):
-    return _lib().rrtmg_hip_lw_nlayers(int(kme), float(p_top))
+def lw_nlayers(kme, p_top, real_bytes=8):
+    """NLAYERS of rrtmg_lwinit (LW:12861) with the quotient evaluated in the caller's REAL (real_bytes 4 or 8), as
+    rrtmg_hip_lwrad forms it for the arrays it is handed."""
+    return _lib().rrtmg_hip_lw_nlayers_real(int(kme), float(p_top), int(real_bytes))
 
 
 def rrtmg_lwinit(p_top, data_path: str, kme: int, data_real_bytes: int = 8, cpdair: float = CP, device: int = 0):
