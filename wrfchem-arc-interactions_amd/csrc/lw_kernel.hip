@@ -32,6 +32,18 @@ namespace {
 constexpr int LW_THREADS = 192;
 constexpr int LW_CHUNK = 47;
 
+// Per-layer results of the pre-pass over the layers of a binary-species segment (lw_gas_kernel): everything that
+// depends on (band, regime, layer) but not on the g-point -- the reference forms these once per layer around its ig
+// loop (e.g. LW:5199-5301, 5354-5355); the (layer, g) lanes only gather and sum.  A wave's area holds PP_LAYERS layers:
+//   doubles [field][layer]: 0..5 weights of the major-species stencil for the reference level jp (3 points x 2
+//   temperatures, already times fac00 / fac10), 6 speccomb; 7..12, 13 the same for jp + 1; 14..16 interpolation
+//   fraction of the three minor species; 17 of the Planck fraction
+//   ints [field][layer]: row offsets (in doubles) of the first stencil point for jp, jp + 1; of the three minor
+//   species' tables; of the Planck-fraction table
+constexpr int PP_LAYERS = 16, PP_NDBL = 18, PP_NINT = 6;
+constexpr int PP_DOUBLES = PP_NDBL * PP_LAYERS + PP_NINT * PP_LAYERS / 2;
+
+
 __constant__ double c_lw_preflog[59];
 __constant__ double c_lw_tref[59];
 __constant__ double c_lw_o3ann[31];
@@ -185,7 +197,7 @@ struct LCol {   // LDS image of the column
     double *wrk;       // [2][nl] scratch for the column sums
     double *tz;        // [nl+1] level temperatures
     double *tav;       // [nl] t3d of the layer (the layers kte-1.. take the level mean instead)
-    double *taul;      // [16][nl] LDS copy of taua for the column sums
+    double *pp;        // [3 waves][PP_DOUBLES] per-layer results of the binary-species pre-pass (gas kernel)
     double *flux;      // [3 waves][4][nl+1]: down clean, down total, up clean, up total
     int *rb0, *rb1, *inds, *indf, *indm;
     int nl;
@@ -207,7 +219,7 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
     c.wrk = p; p += 2 * nl;
     c.tz = p; p += nl + 1;
     c.tav = p; p += nl;
-    c.taul = p; p += LW_NBND * nl;
+    c.pp = p; p += 3 * PP_DOUBLES;
     int *q = reinterpret_cast<int *>(p);
     c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
     double *r = rec;
@@ -259,52 +271,31 @@ struct LaneG {
     double fracconst, halo0, halo1, postscale;
 };
 
-// gaseous optical depth and Planck fraction of layer k for this lane's g-point: the 16 taugbNN routines
-// (LW:4712-7828) as one data-driven expression.  R is the regime of the wave's band -- the same for every lane, so
-// every feature test (binary species, edge stencils, continua, each minor species, Planck fraction mode) is a
-// scalar branch and no lane pays for another band's terms.  The kernel waits on dependent gathers (LDS -> index
-// arithmetic -> table rows -> sums), so the item is written in two passes: first every index is formed and every
-// table read issued (up to 30 gathers in flight), then the sums are taken in the reference's order.
-__device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
-                                           const int off_self, const int off_for, const LaneG &G, const int k,
-                                           double &taug, double &frac)
+// The 16 taugbNN routines (LW:4712-7828) as data-driven expressions.  R is the regime of the wave's band -- the same
+// for every lane, so every feature test (continua, each minor species, halocarbon terms, pressure corrections, Planck
+// fraction mode) is a scalar branch and no lane pays for another band's terms.  The kernel waits on dependent
+// gathers (LDS -> index arithmetic -> table rows -> sums), so an item is written in two passes: first every table read
+// is issued, then the sums are taken in the reference's order.  Two kinds of regime (lw_upload_segments checks that
+// the descriptors fall into them): one key species or none (gas_item_single; minor species and Planck fractions then
+// depend on temperature only), and two key species (gas_prepass + gas_item_binary below).
+__device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
+                                                const int off_self, const int off_for, const LaneG &G, const int k,
+                                                double &taug, double &frac)
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ig = G.ig;
     const int type = (cf >> LC_TYPE_SHIFT) & 3;
-    const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
+    const int spa = (cf >> LC_SPA_SHIFT) & 15;
     const int nsp = (cf >> LC_NSP_SHIFT) & 15;
-    const bool binary = type == 2, edges = cf & LC_EDGES;
-    const double mult = (cf & LC_MULT4) ? 4. : 8.;
-    const int ts = (binary ? nsp : 1) * ng;
     const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
-    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
-    // ---- pass 1: indices and table reads ----
-    double sc[2] = {colA, colA}, wm1[2] = {0., 0.}, w0[2] = {1., 1.}, w1[2] = {0., 0.}, w2[2] = {0., 0.};
-    double v[2][4] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}}, e[2][4] = {{0., 0., 0., 0.}, {0., 0., 0., 0.}};
-    const double *Kp[2] = {tb.K, tb.K};
+    // ---- pass 1: table reads ----
+    double va[2] = {0., 0.}, vb[2] = {0., 0.};
     if (type != 0) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            int jsi = 0;
-            if (binary) {
-                double specparm, fs;
-                spec_idx(colA, c.rat[(rs * 2 + m) * nl + k], colB, mult, tb.oneminus, sc[m], specparm, jsi, fs);
-                w0[m] = 1. - fs; w1[m] = fs;
-                if (edges) {   // LW:5231-5290
-                    const bool lo = specparm < 0.125, hi = specparm > 0.875;
-                    double p = lo ? fs - 1 : -fs;
-                    double p4 = (p * p) * (p * p);
-                    double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-                    wm1[m] = hi ? fk2 : 0.;
-                    w0[m] = lo ? fk0 : (hi ? fk1 : w0[m]);
-                    w1[m] = lo ? fk1 : (hi ? fk0 : w1[m]);
-                    w2[m] = lo ? fk2 : 0.;
-                }
-            }
             const int rb = m == 0 ? c.rb0[k] : c.rb1[k];
-            Kp[m] = tb.K + R.off_major + ig + (size_t)(rb * nsp + jsi) * ng;
-            v[m][0] = Kp[m][0]; v[m][1] = Kp[m][ng]; v[m][2] = Kp[m][ts]; v[m][3] = Kp[m][ts + ng];
+            const double *Kp = tb.K + R.off_major + ig + (size_t)(rb * nsp) * ng;
+            va[m] = Kp[0]; vb[m] = Kp[ng];   // the two temperatures of this reference level
         }
     }
     double s0 = 0., s1 = 0., f0 = 0., f1 = 0.;
@@ -316,51 +307,22 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
             s0 = Sf[0]; s1 = Sf[ng];
         }
     }
-    double ma0[3], ma1[3], mb0[3], mb1[3], fm[3];
+    double ma[3], mb[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
-        ma0[m] = ma1[m] = mb0[m] = mb1[m] = fm[m] = 0.;
+        ma[m] = mb[m] = 0.;
         if (M.slot != LS_ZERO) {
-            const int tm = M.nsp * ng;
-            int jm = 0;
-            if (M.nsp > 1) {
-                double scb, spp;
-                spec_idx(colA, M.refrat, colB, mult, tb.oneminus, scb, spp, jm, fm[m]);
-            }
-            const double *Km = tb.K + M.off + ig + (size_t)(c.indm[k] * M.nsp + jm) * ng;
-            ma0[m] = Km[0]; ma1[m] = Km[ng]; mb0[m] = Km[tm]; mb1[m] = Km[tm + ng];
-        }
-    }
-    double fr0 = 0., fr1 = 0., fpl = 0.;
-    if (fmode == 2) {   // LW:5354-5355
-        double scb, spp;
-        int jpl;
-        spec_idx(colA, R.planck_ratio, colB, mult, tb.oneminus, scb, spp, jpl, fpl);
-        const double *Fp = tb.K + R.off_frac + ig + (size_t)jpl * ng;
-        fr0 = Fp[0]; fr1 = Fp[ng];
-    }
-    // the outer points of the 3-point edge stencil are read only by the lanes that sit on an edge: elsewhere their
-    // weights are exact zeros and the products drop out
-    if (edges) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            if (wm1[m] != 0.) { e[m][0] = Kp[m][-ng]; e[m][1] = Kp[m][ts - ng]; }
-            if (w2[m] != 0.) { e[m][2] = Kp[m][2 * ng]; e[m][3] = Kp[m][ts + 2 * ng]; }
+            const double *Km = tb.K + M.off + ig + (size_t)c.indm[k] * ng;
+            ma[m] = Km[0]; mb[m] = Km[ng];
         }
     }
     // ---- pass 2: sums ----
     double tau = 0.;
     if (type != 0) {
-        double maj[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const double fTa = m == 0 ? c.fac00[k] : c.fac01[k], fTb = m == 0 ? c.fac10[k] : c.fac11[k];
-            maj[m] = (wm1[m] * fTa) * e[m][0] + (w0[m] * fTa) * v[m][0] + (w1[m] * fTa) * v[m][1] + (w2[m] * fTa) * e[m][2] +
-                     (wm1[m] * fTb) * e[m][1] + (w0[m] * fTb) * v[m][2] + (w1[m] * fTb) * v[m][3] + (w2[m] * fTb) * e[m][3];
-        }
-        if (type == 2) tau = sc[0] * maj[0] + sc[1] * maj[1];
-        else tau = colA * (maj[0] + maj[1]);
+        const double maj0 = c.fac00[k] * va[0] + c.fac10[k] * vb[0];
+        const double maj1 = c.fac01[k] * va[1] + c.fac11[k] * vb[1];
+        tau = c.mul[spa * nl + k] * (maj0 + maj1);
     }
     // continua (selffac / forfac already carry colh2o, LW:3806-3807)
     if (cf & (LC_SELF | LC_FOR)) {
@@ -368,14 +330,12 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
         tau = tau + tauself + taufor;
     }
-    // minor species, e.g. LW:5297-5301, 5877-5878
+    // minor species, e.g. LW:4880-4885, 5877-5878
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
         if (M.slot != LS_ZERO) {
-            const double m1 = ma0[m] + fm[m] * (ma1[m] - ma0[m]);
-            const double m2 = mb0[m] + fm[m] * (mb1[m] - mb0[m]);
-            const double absm = m1 + c.minorfrac[k] * (m2 - m1);
+            const double absm = ma[m] + c.minorfrac[k] * (mb[m] - ma[m]);
             tau = tau + c.mul[M.slot * nl + k] * absm;
         }
     }
@@ -391,7 +351,157 @@ __device__ __forceinline__ void gas_optics(const LwDeviceTables &tb, const LCol 
         t = corradj * t;
     }
     taug = t * G.postscale;
-    frac = fmode == 2 ? fr0 + fpl * (fr1 - fr0) : (fmode == 1 ? G.fracconst : 0.);
+    frac = fmode == 1 ? G.fracconst : 0.;
+}
+
+// ---- binary-species segments: pre-pass (lanes = layers x jobs) and item (lanes = layers x g-points) ----
+// Pre-pass over up to PP_LAYERS layers starting at kc.  Lane = (layer l = lane & 15, job slot = lane >> 4 [+ 4 in a
+// second round]): slots 0 / 1 the major species at reference levels jp / jp + 1, slot 2 the first minor species, slot
+// 3 the Planck fraction, slots 4 / 5 the other two minor species (band 13 only) -- each lane forms ONE species index
+// (the division of spec_idx) where a lane of the old item formed up to six.
+__device__ __forceinline__ void gas_prepass(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
+                                            double *ppd, int *ppi, const int kc, const int kend, const int lane)
+{
+    const uint32_t cf = R.cfg;
+    const int nl = c.nl;
+    const int spa = (cf >> LC_SPA_SHIFT) & 15, spb = (cf >> LC_SPB_SHIFT) & 15, rs = (cf >> LC_RAT_SHIFT) & 7;
+    const int nsp = (cf >> LC_NSP_SHIFT) & 15;
+    const bool edges = cf & LC_EDGES;
+    const double mult = (cf & LC_MULT4) ? 4. : 8.;
+    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    const int l = lane & 15;
+    const int k = kc + l < kend ? kc + l : kend - 1;
+    const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
+    const bool more = R.minor[1].slot != LS_ZERO || R.minor[2].slot != LS_ZERO;   // wave-uniform (band 13)
+    for (int round = 0; round < (more ? 2 : 1); ++round) {
+        const int slot = (lane >> 4) + 4 * round;
+        // the job's species ratio
+        double ratio = R.planck_ratio;                                   // slot 3
+        if (slot <= 1) ratio = c.rat[(rs * 2 + slot) * nl + k];
+        else if (slot == 2) ratio = R.minor[0].refrat;
+        else if (slot == 4) ratio = R.minor[1].refrat;
+        else if (slot == 5) ratio = R.minor[2].refrat;
+        double speccomb, specparm, f;
+        int j;
+        spec_idx(colA, ratio, colB, mult, tb.oneminus, speccomb, specparm, j, f);
+        if (slot <= 1) {
+            // stencil of the major species: two points (1 - fs, fs) or, next to the ends of the species axis, three
+            // (LW:5231-5290); the first point's row and the weights times the temperature / pressure factors
+            double w0 = 1. - f, w1 = f, w2 = 0.;
+            int base = j;
+            if (edges) {
+                const bool lo = specparm < 0.125, hi = specparm > 0.875;
+                const double p = lo ? f - 1 : -f;
+                const double p4 = (p * p) * (p * p);
+                const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+                w0 = lo ? fk0 : (hi ? fk2 : w0);
+                w1 = lo ? fk1 : (hi ? fk1 : w1);
+                w2 = lo ? fk2 : (hi ? fk0 : 0.);
+                base = hi ? j - 1 : j;
+            }
+            const double fTa = slot == 0 ? c.fac00[k] : c.fac01[k], fTb = slot == 0 ? c.fac10[k] : c.fac11[k];
+            const int rb = slot == 0 ? c.rb0[k] : c.rb1[k];
+            double *d = ppd + (slot * 7) * PP_LAYERS + l;
+            d[0 * PP_LAYERS] = w0 * fTa; d[1 * PP_LAYERS] = w1 * fTa; d[2 * PP_LAYERS] = w2 * fTa;
+            d[3 * PP_LAYERS] = w0 * fTb; d[4 * PP_LAYERS] = w1 * fTb; d[5 * PP_LAYERS] = w2 * fTb;
+            d[6 * PP_LAYERS] = speccomb;
+            ppi[slot * PP_LAYERS + l] = (rb * nsp + base) * ng;
+        } else if (slot == 3) {
+            if (fmode == 2) { ppd[17 * PP_LAYERS + l] = f; ppi[5 * PP_LAYERS + l] = j * ng; }
+        } else {
+            const int m = slot == 2 ? 0 : slot - 3;
+            if (m < 3) {
+                const LwMinor &M = R.minor[m];
+                const bool bin = M.nsp > 1;
+                ppd[(14 + m) * PP_LAYERS + l] = bin ? f : 0.;
+                ppi[(2 + m) * PP_LAYERS + l] = (c.indm[k] * M.nsp + (bin ? j : 0)) * ng;
+            }
+        }
+    }
+}
+
+// The item of a binary-species segment: gaseous optical depth and Planck fraction of layer k (pre-pass slot l) for
+// this lane's g-point.  Indices, fractions and stencil weights come from the pre-pass; the lane gathers and sums.
+__device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
+                                                const int off_self, const int off_for, const LaneG &G,
+                                                const double *ppd, const int *ppi, const int k, const int l,
+                                                double &taug, double &frac)
+{
+    const uint32_t cf = R.cfg;
+    const int nl = c.nl, ig = G.ig;
+    const int nsp = (cf >> LC_NSP_SHIFT) & 15;
+    const bool edges = cf & LC_EDGES;
+    const int ts = nsp * ng;
+    const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    // ---- pass 1: table reads ----
+    double v[2][6];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const double *Kp = tb.K + R.off_major + ig + ppi[m * PP_LAYERS + l];
+        v[m][0] = Kp[0]; v[m][1] = Kp[ng]; v[m][3] = Kp[ts]; v[m][4] = Kp[ts + ng];
+        v[m][2] = 0.; v[m][5] = 0.;
+        if (edges) { v[m][2] = Kp[2 * ng]; v[m][5] = Kp[ts + 2 * ng]; }   // (weight 0 away from the ends of the axis)
+    }
+    double s0 = 0., s1 = 0., f0 = 0., f1 = 0.;
+    if (cf & (LC_SELF | LC_FOR)) {
+        const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
+        f0 = Ff[0]; f1 = Ff[ng];
+        if (cf & LC_SELF) {
+            const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
+            s0 = Sf[0]; s1 = Sf[ng];
+        }
+    }
+    double ma0[3], ma1[3], mb0[3], mb1[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const LwMinor &M = R.minor[m];
+        ma0[m] = ma1[m] = mb0[m] = mb1[m] = 0.;
+        if (M.slot != LS_ZERO) {
+            const double *Km = tb.K + M.off + ig + ppi[(2 + m) * PP_LAYERS + l];
+            const int tm = M.nsp * ng;
+            ma0[m] = Km[0]; mb0[m] = Km[tm];
+            if (M.nsp > 1) { ma1[m] = Km[ng]; mb1[m] = Km[tm + ng]; }
+        }
+    }
+    double fr0 = 0., fr1 = 0.;
+    if (fmode == 2) {
+        const double *Fp = tb.K + R.off_frac + ig + ppi[5 * PP_LAYERS + l];
+        fr0 = Fp[0]; fr1 = Fp[ng];
+    }
+    // ---- pass 2: sums ----
+    double maj[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const double *d = ppd + (m * 7) * PP_LAYERS + l;
+        double sum = d[0 * PP_LAYERS] * v[m][0] + d[1 * PP_LAYERS] * v[m][1] + d[3 * PP_LAYERS] * v[m][3] + d[4 * PP_LAYERS] * v[m][4];
+        if (edges) sum = sum + d[2 * PP_LAYERS] * v[m][2] + d[5 * PP_LAYERS] * v[m][5];
+        maj[m] = sum;
+    }
+    double tau = ppd[6 * PP_LAYERS + l] * maj[0] + ppd[13 * PP_LAYERS + l] * maj[1];
+    // continua (selffac / forfac already carry colh2o, LW:3806-3807)
+    if (cf & (LC_SELF | LC_FOR)) {
+        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
+        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
+        tau = tau + tauself + taufor;
+    }
+    // minor species, e.g. LW:5297-5301, 5877-5878
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const LwMinor &M = R.minor[m];
+        if (M.slot != LS_ZERO) {
+            double m1 = ma0[m], m2 = mb0[m];
+            if (M.nsp > 1) {
+                const double fm = ppd[(14 + m) * PP_LAYERS + l];
+                m1 = ma0[m] + fm * (ma1[m] - ma0[m]);
+                m2 = mb0[m] + fm * (mb1[m] - mb0[m]);
+            }
+            const double absm = m1 + c.minorfrac[k] * (m2 - m1);
+            tau = tau + c.mul[M.slot * nl + k] * absm;
+        }
+    }
+    const double t = tau + c.mul[R.halo_slot[0] * nl + k] * G.halo0 + c.mul[R.halo_slot[1] * nl + k] * G.halo1;
+    taug = t * G.postscale;
+    frac = fmode == 2 ? fr0 + ppd[17 * PP_LAYERS + l] * (fr1 - fr0) : (fmode == 1 ? G.fracconst : 0.);
 }
 
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
@@ -644,7 +754,6 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (t0 > 1.e-9 && t15 > 1.e-9) tau = tn;
             }
             c.taua[item] = tau;
-            c.taul[item] = tau;
         }
     }
     LW_STAMP(1);
@@ -986,13 +1095,17 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         c.secdiff[ib] = sd;
     }
-    if (a.aer_ra_feedback == 1 && tid >= 64 && tid < 64 + LW_NBND) {
-        // negative column aerosol optical depth is fatal, LW:12607-12615
-        const int nb = tid - 64;
-        double slope = 0.;
-#pragma unroll 8
-        for (int k = 0; k < nk; ++k) slope = slope + c.taul[nb * nl + k];
-        if (slope < 0.) atomicMax(a.status, 1 + col);
+    if (a.aer_ra_feedback == 1 && wave == 1) {
+        // negative column aerosol optical depth is fatal, LW:12607-12615: the column sums of the 16 bands, lanes =
+        // layers (the optical depths were written to the column record in phase A; a sum of the same numbers in
+        // another order decides the same way unless it is zero to rounding)
+        for (int nb = 0; nb < LW_NBND; ++nb) {
+            double v = 0.;
+            for (int k = lane; k < nk; k += 64) v += c.taua[nb * nl + k];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0 && v < 0.) atomicMax(a.status, 1 + col);
+        }
     }
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
@@ -1026,12 +1139,40 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             const LwRegime *rg = upper ? &gd->up : &gd->lo;
             G.fracconst = rg->fracconst; G.halo0 = rg->halo_coef[0]; G.halo1 = rg->halo_coef[1]; G.postscale = rg->postscale;
         }
+        const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
+        if (type == 2) {
+            // binary-species regime: per-layer pre-pass into this wave's LDS area, then the items of the same layers
+            double *ppd = c.pp + (size_t)wave * PP_DOUBLES;
+            int *ppi = reinterpret_cast<int *>(ppd + PP_NDBL * PP_LAYERS);
+            const int lpe = lpi < PP_LAYERS ? lpi : PP_LAYERS;
+            const bool lane_on = dk < lpe;
+            for (int kc = kbeg; kc < kend; kc += PP_LAYERS) {
+                const int nin = kend - kc < PP_LAYERS ? kend - kc : PP_LAYERS;
+                gas_prepass(tb, c, R, B.stride, ppd, ppi, kc, kend, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int kb = 0; kb < nin; kb += lpe) {
+                    const bool act = lane_on && kb + dk < nin;
+                    const int l = act ? kb + dk : nin - 1;
+                    const int k = kc + l;
+                    double taug, plfrac;
+                    gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, taug, plfrac);
+                    if (act) {   // band-major scratch [band][layer][ig]: an item's lanes store one contiguous run
+                        const size_t q = (size_t)nl * g0 + (size_t)k * ng + G.ig;
+                        tg[q] = taug;
+                        fr[q] = plfrac;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
         const bool lane_on = dk < lpi;
         for (int kb = kbeg; kb < kend; kb += lpi) {
             const bool act = lane_on && kb + dk < kend;
             const int k = act ? kb + dk : kend - 1;
             double taug, plfrac;
-            gas_optics(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
+            gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
             if (act) {   // band-major scratch [band][layer][ig]: an item's lanes store one contiguous run
                 const size_t q = (size_t)nl * g0 + (size_t)k * ng + G.ig;
                 tg[q] = taug;
@@ -1668,7 +1809,7 @@ lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
 // ---------------------------------------------------------------------------
 size_t lw_gas_lds_bytes(int nl)
 {
-    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1 + LW_NBND) + 2 * (nl + 1);
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1) + 2 * (nl + 1) + 3 * PP_DOUBLES;
     size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
@@ -1698,6 +1839,13 @@ hipError_t lw_upload_segments(const LwGDesc *gdesc)
             // rough relative cost: blocks of a 2:1 lower / upper split x the table reads of one item
             const LwRegime &R = up ? gdesc[g].up : gdesc[g].lo;
             const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
+            // the two item kinds of the gas kernel: a regime without a second key species has no species-indexed
+            // minor table, no interpolated Planck fraction and no pressure correction together with two key species
+            if (type != 2) {
+                for (int m = 0; m < 3; ++m)
+                    if (R.minor[m].slot != LS_ZERO && R.minor[m].nsp != 1) return hipErrorInvalidValue;
+                if (((R.cfg >> LC_FRAC_SHIFT) & 3) == 2) return hipErrorInvalidValue;
+            } else if ((R.cfg >> LC_CORR_SHIFT) & 3) return hipErrorInvalidValue;
             double w = 1. + (type == 2 ? 10. : (type == 1 ? 8. : 0.));
             if (R.cfg & LC_EDGES) w += 3.;
             if (R.cfg & LC_SELF) w += 2.;
