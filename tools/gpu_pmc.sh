@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i + 1))
   timeout -k 5 150 rocprofv3 --pmc $set --kernel-include-regex "$re" --output-format csv -d $out/p$i -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 "$@" > $out/p$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i done"

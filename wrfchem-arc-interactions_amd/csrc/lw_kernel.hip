@@ -265,11 +265,20 @@ __constant__ LwGDesc c_lwband[LW_NBND];
 __constant__ int c_lwband_g0[LW_NBND];
 __constant__ int c_lwseg_order[2 * LW_NBND];
 
-// what differs between the g-points of a band besides the table column
+// A lane of the gas optics owns TWO neighbouring g-points (ig, ig + 1; every band has an even number): each of its
+// table reads is then one 16-byte load -- the kernel is bound by the rate at which the vector cache takes gather
+// instructions (r02: 1.4e10 cache accesses per launch = 23 of its 28 ms), and a 16-byte gather costs it what an
+// 8-byte one does -- and the per-layer weights, fractions and row offsets are fetched once for two points.
+// What differs between the g-points of a band besides the table column:
 struct LaneG {
-    int ig;
-    double fracconst, halo0, halo1, postscale;
+    int ig;                                       // the even one of the pair
+    double2 fracconst, halo0, halo1, postscale;
 };
+__device__ __forceinline__ double2 ld2(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ __forceinline__ double2 mul2(double w, double2 v) { return make_double2(w * v.x, w * v.y); }
+__device__ __forceinline__ double2 add2(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 sub2(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 mad2(double w, double2 v, double2 a) { return make_double2(a.x + w * v.x, a.y + w * v.y); }
 
 // The 16 taugbNN routines (LW:4712-7828) as data-driven expressions.  R is the regime of the wave's band -- the same
 // for every lane, so every feature test (continua, each minor species, halocarbon terms, pressure corrections, Planck
@@ -280,7 +289,7 @@ struct LaneG {
 // depend on temperature only), and two key species (gas_prepass + gas_item_binary below).
 __device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
                                                 const int off_self, const int off_for, const LaneG &G, const int k,
-                                                double &taug, double &frac)
+                                                double2 &taug, double2 &frac)
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ig = G.ig;
@@ -288,58 +297,56 @@ __device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const 
     const int spa = (cf >> LC_SPA_SHIFT) & 15;
     const int nsp = (cf >> LC_NSP_SHIFT) & 15;
     const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    const double2 zero = make_double2(0., 0.);
     // ---- pass 1: table reads ----
-    double va[2] = {0., 0.}, vb[2] = {0., 0.};
+    double2 va[2] = {zero, zero}, vb[2] = {zero, zero};
     if (type != 0) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int rb = m == 0 ? c.rb0[k] : c.rb1[k];
             const double *Kp = tb.K + R.off_major + ig + (size_t)(rb * nsp) * ng;
-            va[m] = Kp[0]; vb[m] = Kp[ng];   // the two temperatures of this reference level
+            va[m] = ld2(Kp); vb[m] = ld2(Kp + ng);   // the two temperatures of this reference level
         }
     }
-    double s0 = 0., s1 = 0., f0 = 0., f1 = 0.;
+    double2 s0 = zero, s1 = zero, f0 = zero, f1 = zero;
     if (cf & (LC_SELF | LC_FOR)) {
         const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
-        f0 = Ff[0]; f1 = Ff[ng];
+        f0 = ld2(Ff); f1 = ld2(Ff + ng);
         if (cf & LC_SELF) {
             const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
-            s0 = Sf[0]; s1 = Sf[ng];
+            s0 = ld2(Sf); s1 = ld2(Sf + ng);
         }
     }
-    double ma[3], mb[3];
+    double2 ma[3], mb[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
-        ma[m] = mb[m] = 0.;
+        ma[m] = mb[m] = zero;
         if (M.slot != LS_ZERO) {
             const double *Km = tb.K + M.off + ig + (size_t)c.indm[k] * ng;
-            ma[m] = Km[0]; mb[m] = Km[ng];
+            ma[m] = ld2(Km); mb[m] = ld2(Km + ng);
         }
     }
     // ---- pass 2: sums ----
-    double tau = 0.;
+    double2 tau = zero;
     if (type != 0) {
-        const double maj0 = c.fac00[k] * va[0] + c.fac10[k] * vb[0];
-        const double maj1 = c.fac01[k] * va[1] + c.fac11[k] * vb[1];
-        tau = c.mul[spa * nl + k] * (maj0 + maj1);
+        const double2 maj0 = mad2(c.fac10[k], vb[0], mul2(c.fac00[k], va[0]));
+        const double2 maj1 = mad2(c.fac11[k], vb[1], mul2(c.fac01[k], va[1]));
+        tau = mul2(c.mul[spa * nl + k], add2(maj0, maj1));
     }
     // continua (selffac / forfac already carry colh2o, LW:3806-3807)
     if (cf & (LC_SELF | LC_FOR)) {
-        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
-        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
-        tau = tau + tauself + taufor;
+        if (cf & LC_SELF) tau = mad2(c.selffac[k], mad2(c.selffrac[k], sub2(s1, s0), s0), tau);
+        if (cf & LC_FOR) tau = mad2(c.forfac[k], mad2(c.forfrac[k], sub2(f1, f0), f0), tau);
     }
     // minor species, e.g. LW:4880-4885, 5877-5878
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
-        if (M.slot != LS_ZERO) {
-            const double absm = ma[m] + c.minorfrac[k] * (mb[m] - ma[m]);
-            tau = tau + c.mul[M.slot * nl + k] * absm;
-        }
+        if (M.slot != LS_ZERO) tau = mad2(c.mul[M.slot * nl + k], mad2(c.minorfrac[k], sub2(mb[m], ma[m]), ma[m]), tau);
     }
-    double t = tau + c.mul[R.halo_slot[0] * nl + k] * G.halo0 + c.mul[R.halo_slot[1] * nl + k] * G.halo1;
+    const double h0 = c.mul[R.halo_slot[0] * nl + k], h1 = c.mul[R.halo_slot[1] * nl + k];
+    double2 t = make_double2(tau.x + h0 * G.halo0.x + h1 * G.halo1.x, tau.y + h0 * G.halo0.y + h1 * G.halo1.y);
     // pressure corrections of bands 1 and 2, LW:4873-4876, 4906, 5016
     const int corr = (cf >> LC_CORR_SHIFT) & 3;
     if (corr) {
@@ -348,10 +355,10 @@ __device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const 
         if (corr == 1) corradj = pp < 250. ? 1. - 0.15 * (250. - pp) / 154.4 : 1.;
         else if (corr == 2) corradj = 1. - 0.15 * (pp / 95.6);
         else corradj = 1. - .05 * (pp - 100.) / 900.;
-        t = corradj * t;
+        t = mul2(corradj, t);
     }
-    taug = t * G.postscale;
-    frac = fmode == 1 ? G.fracconst : 0.;
+    taug = make_double2(t.x * G.postscale.x, t.y * G.postscale.y);
+    frac = fmode == 1 ? G.fracconst : zero;
 }
 
 // ---- binary-species segments: pre-pass (lanes = layers x jobs) and item (lanes = layers x g-points) ----
@@ -425,7 +432,7 @@ __device__ __forceinline__ void gas_prepass(const LwDeviceTables &tb, const LCol
 __device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
                                                 const int off_self, const int off_for, const LaneG &G,
                                                 const double *ppd, const int *ppi, const int k, const int l,
-                                                double &taug, double &frac)
+                                                double2 &taug, double2 &frac)
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ig = G.ig;
@@ -433,75 +440,78 @@ __device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const 
     const bool edges = cf & LC_EDGES;
     const int ts = nsp * ng;
     const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
+    const double2 zero = make_double2(0., 0.);
     // ---- pass 1: table reads ----
-    double v[2][6];
+    double2 v[2][6];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const double *Kp = tb.K + R.off_major + ig + ppi[m * PP_LAYERS + l];
-        v[m][0] = Kp[0]; v[m][1] = Kp[ng]; v[m][3] = Kp[ts]; v[m][4] = Kp[ts + ng];
-        v[m][2] = 0.; v[m][5] = 0.;
-        if (edges) { v[m][2] = Kp[2 * ng]; v[m][5] = Kp[ts + 2 * ng]; }   // (weight 0 away from the ends of the axis)
+        v[m][0] = ld2(Kp); v[m][1] = ld2(Kp + ng); v[m][3] = ld2(Kp + ts); v[m][4] = ld2(Kp + ts + ng);
+        v[m][2] = zero; v[m][5] = zero;
+        if (edges) { v[m][2] = ld2(Kp + 2 * ng); v[m][5] = ld2(Kp + ts + 2 * ng); }   // (weight 0 away from the ends)
     }
-    double s0 = 0., s1 = 0., f0 = 0., f1 = 0.;
+    double2 s0 = zero, s1 = zero, f0 = zero, f1 = zero;
     if (cf & (LC_SELF | LC_FOR)) {
         const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
-        f0 = Ff[0]; f1 = Ff[ng];
+        f0 = ld2(Ff); f1 = ld2(Ff + ng);
         if (cf & LC_SELF) {
             const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
-            s0 = Sf[0]; s1 = Sf[ng];
+            s0 = ld2(Sf); s1 = ld2(Sf + ng);
         }
     }
-    double ma0[3], ma1[3], mb0[3], mb1[3];
+    double2 ma0[3], ma1[3], mb0[3], mb1[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
-        ma0[m] = ma1[m] = mb0[m] = mb1[m] = 0.;
+        ma0[m] = ma1[m] = mb0[m] = mb1[m] = zero;
         if (M.slot != LS_ZERO) {
             const double *Km = tb.K + M.off + ig + ppi[(2 + m) * PP_LAYERS + l];
             const int tm = M.nsp * ng;
-            ma0[m] = Km[0]; mb0[m] = Km[tm];
-            if (M.nsp > 1) { ma1[m] = Km[ng]; mb1[m] = Km[tm + ng]; }
+            ma0[m] = ld2(Km); mb0[m] = ld2(Km + tm);
+            if (M.nsp > 1) { ma1[m] = ld2(Km + ng); mb1[m] = ld2(Km + tm + ng); }
         }
     }
-    double fr0 = 0., fr1 = 0.;
+    double2 fr0 = zero, fr1 = zero;
     if (fmode == 2) {
         const double *Fp = tb.K + R.off_frac + ig + ppi[5 * PP_LAYERS + l];
-        fr0 = Fp[0]; fr1 = Fp[ng];
+        fr0 = ld2(Fp); fr1 = ld2(Fp + ng);
     }
     // ---- pass 2: sums ----
-    double maj[2];
+    double2 maj[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const double *d = ppd + (m * 7) * PP_LAYERS + l;
-        double sum = d[0 * PP_LAYERS] * v[m][0] + d[1 * PP_LAYERS] * v[m][1] + d[3 * PP_LAYERS] * v[m][3] + d[4 * PP_LAYERS] * v[m][4];
-        if (edges) sum = sum + d[2 * PP_LAYERS] * v[m][2] + d[5 * PP_LAYERS] * v[m][5];
+        double2 sum = mul2(d[0 * PP_LAYERS], v[m][0]);
+        sum = mad2(d[1 * PP_LAYERS], v[m][1], sum);
+        sum = mad2(d[3 * PP_LAYERS], v[m][3], sum);
+        sum = mad2(d[4 * PP_LAYERS], v[m][4], sum);
+        if (edges) { sum = mad2(d[2 * PP_LAYERS], v[m][2], sum); sum = mad2(d[5 * PP_LAYERS], v[m][5], sum); }
         maj[m] = sum;
     }
-    double tau = ppd[6 * PP_LAYERS + l] * maj[0] + ppd[13 * PP_LAYERS + l] * maj[1];
+    double2 tau = mad2(ppd[13 * PP_LAYERS + l], maj[1], mul2(ppd[6 * PP_LAYERS + l], maj[0]));
     // continua (selffac / forfac already carry colh2o, LW:3806-3807)
     if (cf & (LC_SELF | LC_FOR)) {
-        double tauself = (cf & LC_SELF) ? c.selffac[k] * (s0 + c.selffrac[k] * (s1 - s0)) : 0.;
-        double taufor = (cf & LC_FOR) ? c.forfac[k] * (f0 + c.forfrac[k] * (f1 - f0)) : 0.;
-        tau = tau + tauself + taufor;
+        if (cf & LC_SELF) tau = mad2(c.selffac[k], mad2(c.selffrac[k], sub2(s1, s0), s0), tau);
+        if (cf & LC_FOR) tau = mad2(c.forfac[k], mad2(c.forfrac[k], sub2(f1, f0), f0), tau);
     }
     // minor species, e.g. LW:5297-5301, 5877-5878
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const LwMinor &M = R.minor[m];
         if (M.slot != LS_ZERO) {
-            double m1 = ma0[m], m2 = mb0[m];
+            double2 m1 = ma0[m], m2 = mb0[m];
             if (M.nsp > 1) {
                 const double fm = ppd[(14 + m) * PP_LAYERS + l];
-                m1 = ma0[m] + fm * (ma1[m] - ma0[m]);
-                m2 = mb0[m] + fm * (mb1[m] - mb0[m]);
+                m1 = mad2(fm, sub2(ma1[m], ma0[m]), ma0[m]);
+                m2 = mad2(fm, sub2(mb1[m], mb0[m]), mb0[m]);
             }
-            const double absm = m1 + c.minorfrac[k] * (m2 - m1);
-            tau = tau + c.mul[M.slot * nl + k] * absm;
+            tau = mad2(c.mul[M.slot * nl + k], mad2(c.minorfrac[k], sub2(m2, m1), m1), tau);
         }
     }
-    const double t = tau + c.mul[R.halo_slot[0] * nl + k] * G.halo0 + c.mul[R.halo_slot[1] * nl + k] * G.halo1;
-    taug = t * G.postscale;
-    frac = fmode == 2 ? fr0 + ppd[17 * PP_LAYERS + l] * (fr1 - fr0) : (fmode == 1 ? G.fracconst : 0.);
+    const double h0 = c.mul[R.halo_slot[0] * nl + k], h1 = c.mul[R.halo_slot[1] * nl + k];
+    taug = make_double2((tau.x + h0 * G.halo0.x + h1 * G.halo1.x) * G.postscale.x,
+                        (tau.y + h0 * G.halo0.y + h1 * G.halo1.y) * G.postscale.y);
+    frac = fmode == 2 ? mad2(ppd[17 * PP_LAYERS + l], sub2(fr1, fr0), fr0) : (fmode == 1 ? G.fracconst : zero);
 }
 
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
@@ -1130,15 +1140,22 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         const LwGDesc &B = c_lwband[ib];
         const LwRegime &R = upper ? B.up : B.lo;
         const int ng = B.ng, g0 = c_lwband_g0[ib];
-        const int lpi = 64 / ng;
-        const int dk = lane / ng;
+        const int np = ng >> 1;                 // g-point pairs of the band: a lane owns one pair of one layer
+        const int lpi = 64 / np;
+        const int dk = lane / np;
         LaneG G;
-        G.ig = lane - dk * ng;
+        G.ig = 2 * (lane - dk * np);
         {
             const LwGDesc *gd = tb.gdesc + g0 + G.ig;
-            const LwRegime *rg = upper ? &gd->up : &gd->lo;
-            G.fracconst = rg->fracconst; G.halo0 = rg->halo_coef[0]; G.halo1 = rg->halo_coef[1]; G.postscale = rg->postscale;
+            const LwRegime *r0 = upper ? &gd[0].up : &gd[0].lo, *r1 = upper ? &gd[1].up : &gd[1].lo;
+            G.fracconst = make_double2(r0->fracconst, r1->fracconst);
+            G.halo0 = make_double2(r0->halo_coef[0], r1->halo_coef[0]);
+            G.halo1 = make_double2(r0->halo_coef[1], r1->halo_coef[1]);
+            G.postscale = make_double2(r0->postscale, r1->postscale);
         }
+        // band-major scratch [band][layer][ig]: a lane stores its pair with one 16-byte store, an item's lanes one
+        // contiguous run
+        double *tgb = tg + (size_t)nl * g0 + G.ig, *frb = fr + (size_t)nl * g0 + G.ig;
         const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
         if (type == 2) {
             // binary-species regime: per-layer pre-pass into this wave's LDS area, then the items of the same layers
@@ -1155,12 +1172,11 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                     const bool act = lane_on && kb + dk < nin;
                     const int l = act ? kb + dk : nin - 1;
                     const int k = kc + l;
-                    double taug, plfrac;
+                    double2 taug, plfrac;
                     gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, taug, plfrac);
-                    if (act) {   // band-major scratch [band][layer][ig]: an item's lanes store one contiguous run
-                        const size_t q = (size_t)nl * g0 + (size_t)k * ng + G.ig;
-                        tg[q] = taug;
-                        fr[q] = plfrac;
+                    if (act) {
+                        *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
+                        *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1171,12 +1187,11 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int kb = kbeg; kb < kend; kb += lpi) {
             const bool act = lane_on && kb + dk < kend;
             const int k = act ? kb + dk : kend - 1;
-            double taug, plfrac;
+            double2 taug, plfrac;
             gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
-            if (act) {   // band-major scratch [band][layer][ig]: an item's lanes store one contiguous run
-                const size_t q = (size_t)nl * g0 + (size_t)k * ng + G.ig;
-                tg[q] = taug;
-                fr[q] = plfrac;
+            if (act) {
+                *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
+                *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
             }
         }
     }
