@@ -754,16 +754,26 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
     } else {
-        // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers)
-        for (int item = tid - 64; item < LW_NBND * nl; item += LW_THREADS - 64) {
-            const int nb = item / nl, k = item - nb * nl;
-            double tau = 0.;
+        // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers): lanes = layers, the sixteen
+        // bands of a layer by one lane (bands 1 and 16, which gate the copy, are read once; the REAL width is decided
+        // outside the loads so that the sixteen of a layer go out together)
+        for (int k = tid - 64; k < nl; k += LW_THREADS - 64) {
+            double t[LW_NBND];
+#pragma unroll
+            for (int nb = 0; nb < LW_NBND; ++nb) t[nb] = 0.;
             if (a.aer_ra_feedback == 1 && k < nk) {
                 const size_t q = base3 + (size_t)k * sk;
-                const double t0 = ldr(a.tauaerlw[0], q, r4), t15 = ldr(a.tauaerlw[15], q, r4), tn = ldr(a.tauaerlw[nb], q, r4);
-                if (t0 > 1.e-9 && t15 > 1.e-9) tau = tn;
+                if (r4) {
+#pragma unroll
+                    for (int nb = 0; nb < LW_NBND; ++nb) t[nb] = (double)reinterpret_cast<const float *>(a.tauaerlw[nb])[q];
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < LW_NBND; ++nb) t[nb] = reinterpret_cast<const double *>(a.tauaerlw[nb])[q];
+                }
             }
-            c.taua[item] = tau;
+            const bool on = t[0] > 1.e-9 && t[15] > 1.e-9;
+#pragma unroll
+            for (int nb = 0; nb < LW_NBND; ++nb) c.taua[nb * nl + k] = on ? t[nb] : 0.;
         }
     }
     LW_STAMP(1);
