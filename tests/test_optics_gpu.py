@@ -47,6 +47,32 @@ def test_optics_matches_oracle(hip_lib, wa, nbin, ni, nj, nk, opt):
     assert (w2 > 0.2).all() and (w2 <= 1.0).all()
 
 
+def test_optics_without_backscatter_outputs(hip_lib, wa):
+    """What the radiation path asks for: tauaer / waer / gaer and tauaerlw only (bench.py, the Fortran driver shim).
+    Without a bscoef output the shortwave kernel runs its instantiation without the backscatter sums of the series;
+    the fields it does write must equal the full call's bit for bit and match the oracle, also for the strongly
+    absorbing particles that take the downward recurrence."""
+    _init(wa, 8)
+    st = wa.synth.make_wrf_state(7, 4, 16, seed=20260370)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260371)
+    names = ms.names
+    for b in (6, 7, 8):   # soot-rich coarse sections in every second column: Im(m) x beyond the upward window
+        bc = names.index(f"bc_a{b:02d}")
+        for sp in ("so4", "oin", "oc"):
+            i = names.index(f"{sp}_a{b:02d}")
+            moved = 0.95 * ms.chem[i][:, :, ::2]
+            ms.chem[bc][:, :, ::2] += moved * 1.7 / wa.synth_mosaic.DENSITY[sp]
+            ms.chem[i][:, :, ::2] -= moved
+    rad = [n for n in SW_NAMES if n.startswith(("tauaer", "waer", "gaer"))] + [n for n in LW_NAMES if n.startswith("tauaerlw")]
+    full = run_hip_optics(wa, st, ms)
+    part = run_hip_optics(wa, st, ms, names=rad)
+    assert set(part) == set(rad)
+    for n in rad:
+        np.testing.assert_array_equal(part[n], full[n], err_msg=n)
+    ref = run_oracle_optics(wa, st, ms)
+    _compare(part, {n: ref[n] for n in rad}, tile_mask(st, ms.alt.shape), RTOL)
+
+
 def test_optics_tile_subset_and_host_mode(hip_lib, wa):
     _init(wa, 4)
     st = wa.synth.make_wrf_state(8, 6, 16, seed=20260320)

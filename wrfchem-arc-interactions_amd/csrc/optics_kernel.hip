@@ -102,8 +102,9 @@ struct MieAcc {
     cplx an1, bn1, xb;
 };
 
-// FULL = false: only the extinction and scattering sums (longwave bands use absorption alone)
-template <bool FULL>
+// FULL = false: only the extinction and scattering sums (longwave bands use absorption alone); BSC = false: no
+// backscatter sum (the radiation calls take tau, omega and g; bscoef is a diagnostic that is evaluated when asked for)
+template <bool FULL, bool BSC = FULL>
 __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv, double2 gw)
 {
     const double en = (double)n;
@@ -129,9 +130,11 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
         A.gs += gw.x * (an.re * bn.re + an.im * bn.im);
         if (n > 1)
             A.gs += gw.y * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
-        A.xb.re += A.sgn * w2 * (an.re - bn.re);
-        A.xb.im += A.sgn * w2 * (an.im - bn.im);
-        A.sgn = -A.sgn;
+        if (BSC) {
+            A.xb.re += A.sgn * w2 * (an.re - bn.re);
+            A.xb.im += A.sgn * w2 * (an.im - bn.im);
+            A.sgn = -A.sgn;
+        }
         A.an1 = an; A.bn1 = bn;
     }
     A.psi0 = A.psi1; A.psi1 = psi; A.chi0 = A.chi1; A.chi1 = chi;
@@ -171,13 +174,13 @@ __device__ __forceinline__ cplx ccot(cplx y)
     return {sa * ca * r, -(sh * ch) * r};
 }
 
-template <bool FULL>
+template <bool FULL, bool BSC = FULL>
 __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
 {
-    mie_term<FULL>(A, n, D, m, minv, xinv, FULL ? c_gw[n] : make_double2(0., 0.));
+    mie_term<FULL, BSC>(A, n, D, m, minv, xinv, FULL ? c_gw[n] : make_double2(0., 0.));
 }
 
-template <bool FULL>
+template <bool FULL, bool BSC = FULL>
 __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, double &qsca, double &gasy, double &qback)
 {
     const cplx y = {x * m.re, x * m.im};
@@ -206,7 +209,7 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
                 const double en = (double)n;
                 const cplx ny = {en * yinv.re, en * yinv.im};
                 d = csub(crecip(csub(ny, d)), ny);
-                mie_term<FULL>(A, n, d, m, minv, xinv, gw[i - 1]);
+                mie_term<FULL, BSC>(A, n, d, m, minv, xinv, gw[i - 1]);
             }
         }
 #pragma unroll
@@ -216,11 +219,11 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
     qsca = 2. * x2inv * A.qs;
     qext = 2. * x2inv * A.qe;
     gasy = FULL && A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
-    qback = FULL ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
+    qback = BSC ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
 }
 
 // the downward evaluation (strongly absorbing or very small particles)
-template <bool FULL, int NCK = OPT_NCK>
+template <bool FULL, int NCK = OPT_NCK, bool BSC = FULL>
 __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /* LDS [NCK][OPT_THREADS], this thread's column */,
                                                 double &qext, double &qsca, double &gasy, double &qback)
 {
@@ -282,7 +285,7 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
 #pragma unroll
         for (int i = 0; i < OPT_RB; ++i) {
             const int n = n0 + i + 1;
-            if (n <= nstop) mie_term<FULL>(A, n, dd[i], m, minv, xinv);
+            if (n <= nstop) mie_term<FULL, BSC>(A, n, dd[i], m, minv, xinv);
         }
         if (n0 + OPT_RB < nstop) {
             dd[OPT_RB - 1] = {c.x, c.y};
@@ -295,7 +298,7 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
 #pragma unroll
             for (int i = 0; i < OPT_RB; ++i) {
                 const int n = n0 + OPT_RB + i + 1;
-                if (n <= nstop) mie_term<FULL>(A, n, dd[i], m, minv, xinv);
+                if (n <= nstop) mie_term<FULL, BSC>(A, n, dd[i], m, minv, xinv);
             }
         }
     }
@@ -304,7 +307,7 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
     qsca = 2. * x2inv * A.qs;
     qext = 2. * x2inv * A.qe;
     gasy = FULL && A.qs > 0. ? 2. * A.gs * frcp(A.qs) : 0.;
-    qback = FULL ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
+    qback = BSC ? x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im) : 0.;
 }
 // ... as a real function call, for the longwave kernel: there only particles beyond any aerosol size come here, and
 // inlined twice (one per band of the pair) the code raises the register pressure of the whole kernel
@@ -317,12 +320,12 @@ __device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck
     return {qe, qs};
 }
 
-template <bool FULL, int NCK = OPT_NCK>
+template <bool FULL, int NCK = OPT_NCK, bool BSC = FULL>
 __device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck, double &qext, double &qsca, double &gasy,
                                            double &qback)
 {
-    if (mie_upward_ok(x, m)) mie_sphere_up<FULL>(x, m, qext, qsca, gasy, qback);   // the particle's own choice: no vote
-    else mie_sphere_down<FULL, NCK>(x, m, ck, qext, qsca, gasy, qback);
+    if (mie_upward_ok(x, m)) mie_sphere_up<FULL, BSC>(x, m, qext, qsca, gasy, qback);   // the particle's own choice: no vote
+    else mie_sphere_down<FULL, NCK, BSC>(x, m, ck, qext, qsca, gasy, qback);
 }
 
 // Two longwave evaluations of one particle (neighbouring bands) travel side by side (mie_pair_su below; the fp32
@@ -644,6 +647,7 @@ __device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mi
 // badly: 1.7 of 3 waves per SIMD resident; wavelength-major order fixed that, 5.38 -> 4.19 ms per 1.6 M cells; per
 // cell: 3.94 ms.)  The downward fallback keeps 4 checkpoints per thread (segments of 64 terms).
 constexpr int OPT_NCK_SWC = 4;
+template <bool BSC>   // BSC: a backscatter output (bscoef) is requested
 __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
 {
     const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
@@ -698,7 +702,7 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
             double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
             x = x > OPT_XMAX ? OPT_XMAX : x;
             double qe, qs, g = 0., qb = 0.;
-            mie_sphere<true, OPT_NCK_SWC>(x, m, ck, qe, qs, g, qb);
+            mie_sphere<true, OPT_NCK_SWC, BSC>(x, m, ck, qe, qs, g, qb);
             double *s = acc + (size_t)(4 * w) * OPT_THREADS;
             s[0] += cross * qe;
             s[OPT_THREADS] += cross * qs;
@@ -1112,7 +1116,14 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
 {
     __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
     __shared__ double s_acc[4 * OPT_NSW * OPT_THREADS];
-    optics_sw_cell(a, s_ck, s_acc);
+    optics_sw_cell<false>(a, s_ck, s_acc);
+}
+// the same with the backscatter sums of the series (a bscoef output is requested)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_bsc_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
+    __shared__ double s_acc[4 * OPT_NSW * OPT_THREADS];
+    optics_sw_cell<true>(a, s_ck, s_acc);
 }
 
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -1173,9 +1184,16 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
     if (any_sw && precision == 1)
         hipLaunchKernelGGL(optics_sw32_kernel, dim3((unsigned)(blocks / 2)), dim3(OPT_THREADS), 0, stream, a);
-    else if (any_sw)   // one thread per cell
-        hipLaunchKernelGGL(optics_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
-                           stream, a);
+    else if (any_sw) {   // one thread per cell; the backscatter sums only when a bscoef output is there
+        bool bsc = false;
+        for (int w = 0; w < OPT_NSW; ++w) bsc = bsc || a.bscoef[w];
+        if (bsc)
+            hipLaunchKernelGGL(optics_bsc_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS),
+                               0, stream, a);
+        else
+            hipLaunchKernelGGL(optics_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                               stream, a);
+    }
     if (any_lw && precision == 1)
         hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
                            stream, a);
