@@ -110,13 +110,20 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
     const double en = (double)n;
     const double psi = (2. * en - 1.) * xinv * A.psi1 - A.psi0;
     const double chi = (2. * en - 1.) * xinv * A.chi1 - A.chi0;
-    const cplx xi = {psi, -chi}, xi1 = {A.psi1, -A.chi1};
+    // a_n = (t psi_n - psi_(n-1)) / (t xi_n - xi_(n-1)) with xi = psi - i chi: the denominator is the numerator minus
+    // i (t chi_n - chi_(n-1)) -- four operations instead of a complex product and a complex difference (fp64 only:
+    // in the packed-fp32 terms the same rearrangement cost accuracy -- the mixed path's heating-rate bound of
+    // tests/test_full_domain_gpu.py went from inside 5e-3 K/day to 8.5e-3 -- and was withdrawn there)
     cplx t = cmul(D, minv);
     t.re += en * xinv;
-    const cplx na = {t.re * psi - A.psi1, t.im * psi}, da = csub(cmul(t, xi), xi1);
+    const cplx na = {t.re * psi - A.psi1, t.im * psi};
+    const cplx ca = {t.re * chi - A.chi1, t.im * chi};
+    const cplx da = {na.re + ca.im, na.im - ca.re};
     t = cmul(m, D);
     t.re += en * xinv;
-    const cplx nb = {t.re * psi - A.psi1, t.im * psi}, db = csub(cmul(t, xi), xi1);
+    const cplx nb = {t.re * psi - A.psi1, t.im * psi};
+    const cplx cb = {t.re * chi - A.chi1, t.im * chi};
+    const cplx db = {nb.re + cb.im, nb.im - cb.re};
     // a_n = na/da, b_n = nb/db with one reciprocal: 1/|da|^2 = |db|^2 / (|da|^2 |db|^2)
     const double ma = da.re * da.re + da.im * da.im, mb = db.re * db.re + db.im * db.im;
     const double r = frcp1(ma * mb);
