@@ -359,6 +359,11 @@ def main():
     ap.add_argument("--cloudy-pass", type=int, default=1,
                     help="N = 1: after the timed region, one short pass of the same domain with the SURVEY 8d full-domain "
                          "atmosphere (clouds in 20 %% of the columns, 10 %% night columns) -> key `cloudy`; 0 = skip")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 on a box with fewer GPUs than ranks (development): ranks share the devices (local_rank modulo "
+                         "the device count) and the one all-reduce goes over gloo, since RCCL refuses two ranks on a device; "
+                         "exercises launch, slabs, kernels on slabs and the reduction -- the number it prints is not a "
+                         "scaling measurement")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only (no GPU, gloo): every rank computes its slab, rank 0 prints them as JSON")
     args = ap.parse_args()
@@ -389,9 +394,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # one launch per kernel for the whole domain: an explicit opt-in (the engine's default scratch caps are modest,
     # 32 / 16 GiB and at most a quarter of the free memory; larger tiles then run in column batches)
@@ -488,7 +499,12 @@ def main():
         wa.tiles.tile_sums_device(sw_out, SW12, d, sums[:16])          # native deterministic reduction
         if do_lw:
             wa.tiles.tile_sums_device(lw_out, LW12, d, sums[16:])
-        wa.tiles.allreduce_sums(sums)
+        if rehearse:                       # gloo reduces host tensors
+            h = sums.cpu()
+            wa.tiles.allreduce_sums(h)
+            sums.copy_(h)
+        else:
+            wa.tiles.allreduce_sums(sums)
 
     def opt_call(outs=None):
         if not empty:
@@ -534,7 +550,7 @@ def main():
     eng.sw_status()
     if do_lw:
         engl.lw_status()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -602,6 +618,8 @@ def main():
             "value": value, "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
+            **({"rehearsal": "ranks share one GPU, all-reduce over gloo: plumbing check, not a scaling measurement"}
+               if rehearse else {}),
             "vs_baseline": None, "dtype": "f64" if prec == "f64" or not do_opt else "f64 (optical averaging f32)",
             "data": "synthetic",
             "config": {"workload": workload, "columns": ncol_job, "columns_rank0": ncol, "layers": nk,
@@ -620,6 +638,12 @@ def main():
                          "valu": valu,
                          "note": "fp64-VALU-bound path (SURVEY 8d): see roofline.fp64 and DESIGN.md 4.4"},
         }
+        if world > 1:
+            # what the one collective delivered: the column count and the domain-mean TOA upward fluxes (tiles.domain_means)
+            hs_ = sums.cpu().numpy()
+            line["allreduce"] = {"columns_reduced": float(hs_[13]), "columns_expected": float(ncol_job),
+                                 "mean_swupt_Wm2": float(hs_[0] / hs_[13]) if hs_[13] > 0 else None,
+                                 "mean_lwupt_Wm2": float(hs_[16] / hs_[29]) if do_lw and hs_[29] > 0 else None}
         if world == 1 and not args.no_cpu:
             try:
                 fl = algorithmic_flops(wa, tab, tabl, st, ms, mode)

@@ -26,3 +26,25 @@ def test_tile_sums_device_matches_numpy(hip_lib, wa):
     wa.tiles.tile_sums_device(dev32, names, dims, out2)
     torch.cuda.synchronize()
     np.testing.assert_allclose(out2.cpu().numpy(), ref, rtol=1e-6)
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python3 bench.py --gpus 2` end to end on this one-GPU box: the parent starts the two ranks, each builds only
+    its j-slab of the domain and runs the three stages on it, the per-tile sums are all-reduced (over gloo here: RCCL
+    refuses two ranks on one device) and rank 0 prints one line whose reduced column count is the whole domain's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--config", "2",
+                        "--steps", "1", "--warmup", "1", "--night", "0.2"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["allreduce"]["columns_reduced"] == d["allreduce"]["columns_expected"] == 40000.0
+    assert 0 < d["config"]["columns_rank0"] < 40000
+    assert 50.0 < d["allreduce"]["mean_lwupt_Wm2"] < 600.0
