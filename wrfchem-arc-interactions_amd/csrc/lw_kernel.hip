@@ -1464,19 +1464,22 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
 // aerosol in the scratch slots the gas optics occupied (same bytes), and the way up is one relaxation per layer.
 // The spectral sums (LW:3366-3377) are taken four levels at a time.
 //
-// THREE columns per workgroup of eight waves.  A column's 140 g-points are five chunks of 28; a chunk sits on the
-// lower or the upper half of a wave (lanes 0..27 / 32..59), so 3 x 5 = 15 of the workgroup's 16 half-wave seats are
-// taken and 52.5 of 64 lanes work (a column alone on three waves: 47; two columns on five waves: 56, but a five-wave
-// workgroup puts two of its waves on one SIMD and only two such workgroups fit a CU -- measured 2.05 waves per SIMD).
-// Every spectral sum is taken per chunk, i.e. per half wave, and the five chunk sums of a column are added in chunk
-// order: a column's sums are formed the same way whichever seats it has (results do not depend on the tiling).
+// SEVEN columns per workgroup of sixteen waves.  A column's 140 g-points are nine chunks of 16 (the last one holds
+// 12); a chunk sits on one ROW of a wave (16 lanes, the unit of the DPP row operations), so 7 x 9 = 63 of the
+// workgroup's 64 rows are taken and 61.25 of 64 lanes work (a column alone on three waves: 47; three columns on eight
+// waves in half-wave chunks of 28: 52.5).  One such workgroup fills a CU (4 waves per SIMD, what 121 VGPRs allow); a
+// five-wave workgroup -- two columns, 56 lanes -- puts two of its waves on one SIMD and only two of them fit (measured
+// 2.05 waves per SIMD).  Every spectral sum is taken per chunk, i.e. inside a row, and the nine chunk sums of a column
+// are added in chunk order: a column's sums are formed the same way whichever rows it has (results do not depend on
+// the tiling of the domain).
 // What the upward sweep works from: the (A, S) pairs the downward sweep stored in the scratch slots of the gas optics
 // (true: no second evaluation of the layer optics, but 2 x 35 GB more HBM traffic per 250 000 columns x 63 layers -- the
 // kernel then runs at the memory system's pace: measured 33.8 ms), or the gas optics read a second time with the
 // layer optics evaluated again (false: 4.4 G more wave-instructions, 49 GB less traffic).
 constexpr bool RTF_STORE_UP = false;
-constexpr int RTF_COLS = 3, RTF_WAVES = 8, RTF_THREADS = RTF_WAVES * 64, RTF_CHUNK = 28, RTF_NCHUNK = 5;
-static_assert(RTF_CHUNK * RTF_NCHUNK == LW_NGPT, "chunks must tile the g-points");
+constexpr int RTF_COLS = 7, RTF_WAVES = 16, RTF_THREADS = RTF_WAVES * 64, RTF_CHUNK = 16, RTF_NCHUNK = 9;
+static_assert(RTF_CHUNK * RTF_NCHUNK >= LW_NGPT && RTF_CHUNK * (RTF_NCHUNK - 1) < LW_NGPT, "chunks must cover the g-points");
+static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4, "a row per chunk");
 
 // LDS per column: the in-cloud state of the column (McICA instantiations only) and the flux slots of its five chunks.
 // The per-band arrays of the column record (Planck functions, aerosol optical depth) are NOT staged: the lanes of a
@@ -1488,16 +1491,26 @@ __host__ __device__ inline size_t rtf_col_doubles(int nl, bool cloud)
     return (cloud ? rtf_cloud_doubles(nl) : 0) + (size_t)RTF_NCHUNK * (2 * (nl + 1) + 8);
 }
 
-// sums of four values over each HALF of the wave: afterwards lane 16 r (r = 0..3) of qa holds the sum of v[r & 1] over
-// half r >> 1 (lanes 0..31 / 32..63), and of qb that of v[2 + (r & 1)].  The two halves are reduced by the same tree.
-__device__ __forceinline__ void half_sum4(double v0, double v1, double v2, double v3, double &qa, double &qb)
+// Sums of four values over each ROW of the wave (16 lanes): afterwards every lane of quad q of a row holds the row's
+// sum of v[{0, 2, 1, 3}[q]].  The values are folded onto each other on the way (halves of the row keep v0 / v1 and
+// v2 / v3, then quads keep one each), so the four sums cost what one and a half would; all rows use the same tree.
+__device__ __forceinline__ double row_sum4(double v0, double v1, double v2, double v3, int lane)
 {
-    double x = fold16(v0, v1), y = fold16(v2, v3);   // rows: v0 low half, v1 low half, v0 high half, v1 high half
-    x = dpp_add<0x140>(x); y = dpp_add<0x140>(y);   // row_mirror
-    x = dpp_add<0x141>(x); y = dpp_add<0x141>(y);   // row_half_mirror
-    x = dpp_add<0x4E>(x); y = dpp_add<0x4E>(y);     // quad_perm [2,3,0,1]
-    x = dpp_add<0xB1>(x); y = dpp_add<0xB1>(y);     // quad_perm [1,0,3,2]
-    qa = x; qb = y;
+    const bool up = lane & 8, q1 = lane & 4;
+    // row_mirror pairs lane i with 15 - i (the other half of the row)
+    const double x01 = (up ? v1 : v0) + __hiloint2double(
+        __builtin_amdgcn_mov_dpp(__double2hiint(up ? v0 : v1), 0x140, 0xF, 0xF, true),
+        __builtin_amdgcn_mov_dpp(__double2loint(up ? v0 : v1), 0x140, 0xF, 0xF, true));
+    const double x23 = (up ? v3 : v2) + __hiloint2double(
+        __builtin_amdgcn_mov_dpp(__double2hiint(up ? v2 : v3), 0x140, 0xF, 0xF, true),
+        __builtin_amdgcn_mov_dpp(__double2loint(up ? v2 : v3), 0x140, 0xF, 0xF, true));
+    // row_half_mirror pairs lane i with 7 - i (the other quad of the half)
+    const double send = q1 ? x01 : x23;
+    double y = (q1 ? x23 : x01) + __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(send), 0x141, 0xF, 0xF, true),
+                                                   __builtin_amdgcn_mov_dpp(__double2loint(send), 0x141, 0xF, 0xF, true));
+    y = dpp_add<0x4E>(y);    // quad_perm [2,3,0,1]
+    y = dpp_add<0xB1>(y);    // quad_perm [1,0,3,2]
+    return y;
 }
 
 template <bool DEEP, bool CLOUD>   // CLOUD: McICA (icloud != 0); the cloud-free instantiation carries none of it
@@ -1522,13 +1535,14 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     __shared__ unsigned long long s_cmhi[RTF_THREADS];
     if (tid < 2 * RTF_COLS) s_lmask[tid >> 1][tid & 1] = 0ull;
 
-    // this lane's seat: half wave -> (column, chunk); lanes 28..31 of a half and the 16th seat are idle
-    const int seat = 2 * wave + (lane >> 5), l32 = lane & 31;
+    // this lane's seat: row -> (column, chunk); lanes 12..15 of a column's last chunk and the 64th row are idle
+    const int seat = 4 * wave + (lane >> 4), l16 = lane & 15;
     const int scol = seat / RTF_NCHUNK, chunk = seat - scol * RTF_NCHUNK;
-    const bool seat_on = scol < ncols;                        // uniform over the half wave
-    const bool live = seat_on && l32 < RTF_CHUNK;             // a lane with a g-point of an existing column
+    const bool seat_on = scol < ncols;                        // uniform over the row
+    const int graw = chunk * RTF_CHUNK + l16;
+    const bool live = seat_on && graw < LW_NGPT;              // a lane with a g-point of an existing column
     const int colsel = seat_on ? scol : 0;                    // idle seats shadow column 0 (no stores, nothing summed)
-    const int g = chunk * RTF_CHUNK + (l32 < RTF_CHUNK ? l32 : RTF_CHUNK - 1);
+    const int g = graw < LW_NGPT ? graw : LW_NGPT - 1;
     const int slot = RTF_COLS * grp + colsel;
     const int col = a.col0 + slot;
     const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: planklay planklev taua secdiff plankbnd pz
@@ -1591,9 +1605,9 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const uint64_t lmask_hi = cloud && deep ? (uint64_t)s_lmask[colsel][1] : 0;
     const bool col_cloudy = lmask != 0 || lmask_hi != 0;
     int bad = 0;
-    // the lanes 0 and 16 of a half wave hold the half's sums (half_sum4): of v[jw] in qa, of v[2 + jw] in qb
-    const bool writer = (lane & 15) == 0 && seat_on;
-    const int jw = (lane >> 4) & 1;
+    // the first lane of quad q of a row holds the row's sum of value jw = {0, 2, 1, 3}[q] (row_sum4)
+    const bool writer = (lane & 3) == 0 && seat_on;
+    const int jw = ((lane >> 1) & 2) | ((lane >> 3) & 1);
 
     // ---- downward sweep (top -> surface), LW:3207-3312, in blocks of four layers ----
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
@@ -1675,12 +1689,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             }
         }
         // downward flux at the bottom of the block's layers = levels 4b .. 4b+3
-        double qa, qb;
-        half_sum4(v[0], v[1], v[2], v[3], qa, qb);
-        if (writer) {
-            if (b * 4 + jw < nl) fl[b * 4 + jw] = qa;
-            if (b * 4 + 2 + jw < nl) fl[b * 4 + 2 + jw] = qb;
-        }
+        const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
+        if (writer && b * 4 + jw < nl) fl[b * 4 + jw] = qs;
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
     const double rad0 = frac0 * plankbnd;
@@ -1689,13 +1699,11 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     {
         const double radlu_c = __builtin_fma(reflect, radld_c, rad0), radclru = __builtin_fma(reflect, radclr, rad0);
         const double topc = __builtin_fma(trc, radlu_c, ec), topk = __builtin_fma(trk, radclru, ek);
-        double q0a, q0b, q1a, q1b;
-        half_sum4(wgt * radld_c, wgt * radlu_c, wgt * topc, wgt * radlu_t, q0a, q0b);
-        half_sum4(wgt * radclr, wgt * radclru, wgt * topk, 0., q1a, q1b);
+        const double q0 = row_sum4(wgt * radld_c, wgt * radlu_c, wgt * topc, wgt * radlu_t, lane);
+        const double q1 = row_sum4(wgt * radclr, wgt * radclru, wgt * topk, 0., lane);
         if (writer) {
-            fl[2 * nlev + jw] = q0a; fl[2 * nlev + 4 + jw] = q1a;       // surface down (jw 0) / surface up (jw 1)
-            if (jw == 0) { fl[2 * nlev + 2] = q0b; fl[2 * nlev + 6] = q1b; }   // top up
-            else fl[nlev] = q0b;                                        // upward flux of the call with aerosol at the surface
+            if (jw < 3) { fl[2 * nlev + jw] = q0; fl[2 * nlev + 4 + jw] = q1; }   // surface down, surface up, top up
+            else fl[nlev] = q0;                                        // upward flux of the call with aerosol at the surface
         }
     }
     // ---- upward sweep (surface -> top), LW:3331-3356: the call with aerosol ----
@@ -1717,12 +1725,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                 }
             }
             // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
-            double qa, qb;
-            half_sum4(v[0], v[1], v[2], v[3], qa, qb);
-            if (writer) {
-                if (b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qa;
-                if (b * 4 + 2 + jw < nl) fl[nlev + b * 4 + 3 + jw] = qb;
-            }
+            const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
+            if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
         }
     } else {
         // tnext / fnext / blnext / tanext hold layer 0 after the downward sweep, pvhi the level below it
@@ -1763,18 +1767,14 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                 }
             }
             // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
-            double qa, qb;
-            half_sum4(v[0], v[1], v[2], v[3], qa, qb);
-            if (writer) {
-                if (b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qa;
-                if (b * 4 + 2 + jw < nl) fl[nlev + b * 4 + 3 + jw] = qb;
-            }
+            const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
+            if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
         }
     }
     if (bad && live) atomicMax(a.status, (bad << 28) | (1 + col));
     __syncthreads();
 
-    // ======================= epilogue: lanes = levels; two waves per column =======================
+    // ======================= epilogue: lanes = levels; two waves per column (waves 14, 15 idle) =======================
     const int ec_col = wave >> 1;
     if (ec_col < ncols) {
         const int etid = tid & 127;
@@ -1787,8 +1787,13 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 1);
         const double *f0 = lds + ec_col * cold + recn;
         const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
-        // the five chunk sums in chunk order
-        auto tot = [&](size_t q) { return ((((f0[q] + f0[ws + q]) + f0[2 * ws + q]) + f0[3 * ws + q]) + f0[4 * ws + q]) * tb.fluxfac; };
+        // the chunk sums in chunk order
+        auto tot = [&](size_t q) {
+            double t = f0[q];
+#pragma unroll
+            for (int c9 = 1; c9 < RTF_NCHUNK; ++c9) t = t + f0[c9 * ws + q];
+            return t * tb.fluxfac;
+        };
         auto dnl = [&](int lev) { return tot(lev); };
         auto upl = [&](int lev) { return tot(nlev + lev); };
         auto sm = [&](int q) { return tot(2 * nlev + q); };
