@@ -636,6 +636,13 @@ def main():
                          "optics_lw_kernel_ms": opt_part_ms.get("lw", 0.0), "optics_algorithmic_bytes_per_column": obpc,
                          "step_algorithmic_GBs": ncol * (bpc + obpc) / ((sw_ms + lw_ms + opt_ms) * 1e-3) / 1e9,
                          "valu": valu,
+                         # every kernel of the step (the three largest are within a few per cent of each other, so which
+                         # one is "dominant" changes from run to run): duration, algorithmic GB/s, fraction of the HBM peak
+                         "kernels": [
+                             {"kernel": nm, "ms": ms_, "algorithmic_bytes_per_column": b_,
+                              "achieved": ncol * b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
+                              "frac": ncol * b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None}
+                             for nm, ms_, b_ in (cand + ([("lw_gas_kernel + lw_rt_fast_kernel", lw_ms, bpc_lw)] if do_lw else []))],
                          "note": "fp64-VALU-bound path (SURVEY 8d): see roofline.fp64 and DESIGN.md 4.4"},
         }
         if world > 1:
