@@ -26,6 +26,7 @@ struct LwKernelArgs {
     double *taug, *frac, *rec;
     int col0;                           // first tile column of this batch
     int nbatch;                         // columns of this batch
+    int stage_cont;                     // gas kernel: continuum rows of a segment's band through LDS (lw_launch decides)
     // clouds (icloud != 0), as in SwKernelArgs
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
     int f_ice_phy, fer_hires;            // "MP option 5" split of snow; Ferrier-Aligo (qi3d = all frozen water)
@@ -49,7 +50,7 @@ __host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_base_do
 // scratch doubles one column needs (taug + frac + record)
 inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_rec_doubles(nl); }
 
-size_t lw_gas_lds_bytes(int nlayers);
+size_t lw_gas_lds_bytes(int nlayers, bool stage_continua = false);
 size_t lw_rt_lds_bytes(int nlayers, bool cloud = true);
 size_t lw_rt_fast_lds_bytes(int nlayers, bool cloud = true);   // the two-column kernel of calls without flux profiles
 hipError_t lw_upload_constants(const double *preflog, const double *tref);

@@ -42,6 +42,11 @@ constexpr int LW_CHUNK = 47;
 //   species' tables; of the Planck-fraction table
 constexpr int PP_LAYERS = 16, PP_NDBL = 18, PP_NINT = 6;
 constexpr int PP_DOUBLES = PP_NDBL * PP_LAYERS + PP_NINT * PP_LAYERS / 2;
+// The water-vapour continuum rows of a segment's band (selfref: 10 rows, forref: 4 rows of <= 16 g-points), staged by
+// the wave that works on the segment: 4 of an item's gathers become LDS reads -- the gas kernel is bound by the bytes
+// its gathers pull through the vector cache (64 B per cycle and CU), the LDS has twice that rate and is idle.
+constexpr int CONT_SELF_ROWS = 10, CONT_FOR_ROWS = 4, CONT_STRIDE = 16;
+constexpr int CONT_DOUBLES = (CONT_SELF_ROWS + CONT_FOR_ROWS) * CONT_STRIDE;
 
 
 __constant__ double c_lw_preflog[59];
@@ -198,6 +203,7 @@ struct LCol {   // LDS image of the column
     double *tz;        // [nl+1] level temperatures
     double *tav;       // [nl] t3d of the layer (the layers kte-1.. take the level mean instead)
     double *pp;        // [3 waves][PP_DOUBLES] per-layer results of the binary-species pre-pass (gas kernel)
+    double *cont;      // [3 waves][CONT_DOUBLES] staged continuum rows of the wave's segment, or nullptr
     double *flux;      // [3 waves][4][nl+1]: down clean, down total, up clean, up total
     int *rb0, *rb1, *inds, *indf, *indm;
     int nl;
@@ -205,7 +211,7 @@ struct LCol {   // LDS image of the column
 
 // gas kernel: the layer state lives in LDS; the per-band Planck / aerosol arrays are written straight
 // into the column's global record (lw_rec_doubles), which lw_rt_kernel stages into its own LDS
-__device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
+__device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl, bool stage_cont)
 {
     LCol c;
     c.nl = nl;
@@ -220,6 +226,7 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl)
     c.tz = p; p += nl + 1;
     c.tav = p; p += nl;
     c.pp = p; p += 3 * PP_DOUBLES;
+    c.cont = stage_cont ? p : nullptr; p += stage_cont ? 3 * CONT_DOUBLES : 0;
     int *q = reinterpret_cast<int *>(p);
     c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
     double *r = rec;
@@ -289,7 +296,7 @@ __device__ __forceinline__ double2 mad2(double w, double2 v, double2 a) { return
 // depend on temperature only), and two key species (gas_prepass + gas_item_binary below).
 __device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
                                                 const int off_self, const int off_for, const LaneG &G, const int k,
-                                                double2 &taug, double2 &frac)
+                                                const double *cont, double2 &taug, double2 &frac)
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ig = G.ig;
@@ -310,11 +317,20 @@ __device__ __forceinline__ void gas_item_single(const LwDeviceTables &tb, const 
     }
     double2 s0 = zero, s1 = zero, f0 = zero, f1 = zero;
     if (cf & (LC_SELF | LC_FOR)) {
-        const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
-        f0 = ld2(Ff); f1 = ld2(Ff + ng);
-        if (cf & LC_SELF) {
-            const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
-            s0 = ld2(Sf); s1 = ld2(Sf + ng);
+        if (cont) {   // staged by this wave for the segment (lw_gas_kernel)
+            const double *Ff = cont + (CONT_SELF_ROWS + c.indf[k]) * CONT_STRIDE + ig;
+            f0 = ld2(Ff); f1 = ld2(Ff + CONT_STRIDE);
+            if (cf & LC_SELF) {
+                const double *Sf = cont + c.inds[k] * CONT_STRIDE + ig;
+                s0 = ld2(Sf); s1 = ld2(Sf + CONT_STRIDE);
+            }
+        } else {
+            const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
+            f0 = ld2(Ff); f1 = ld2(Ff + ng);
+            if (cf & LC_SELF) {
+                const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
+                s0 = ld2(Sf); s1 = ld2(Sf + ng);
+            }
         }
     }
     double2 ma[3], mb[3];
@@ -432,7 +448,7 @@ __device__ __forceinline__ void gas_prepass(const LwDeviceTables &tb, const LCol
 __device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const LCol &c, const LwRegime &R, const int ng,
                                                 const int off_self, const int off_for, const LaneG &G,
                                                 const double *ppd, const int *ppi, const int k, const int l,
-                                                double2 &taug, double2 &frac)
+                                                const double *cont, double2 &taug, double2 &frac)
 {
     const uint32_t cf = R.cfg;
     const int nl = c.nl, ig = G.ig;
@@ -452,11 +468,20 @@ __device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const 
     }
     double2 s0 = zero, s1 = zero, f0 = zero, f1 = zero;
     if (cf & (LC_SELF | LC_FOR)) {
-        const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
-        f0 = ld2(Ff); f1 = ld2(Ff + ng);
-        if (cf & LC_SELF) {
-            const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
-            s0 = ld2(Sf); s1 = ld2(Sf + ng);
+        if (cont) {   // staged by this wave for the segment (lw_gas_kernel)
+            const double *Ff = cont + (CONT_SELF_ROWS + c.indf[k]) * CONT_STRIDE + ig;
+            f0 = ld2(Ff); f1 = ld2(Ff + CONT_STRIDE);
+            if (cf & LC_SELF) {
+                const double *Sf = cont + c.inds[k] * CONT_STRIDE + ig;
+                s0 = ld2(Sf); s1 = ld2(Sf + CONT_STRIDE);
+            }
+        } else {
+            const double *Ff = tb.K + off_for + ig + (size_t)c.indf[k] * ng;
+            f0 = ld2(Ff); f1 = ld2(Ff + ng);
+            if (cf & LC_SELF) {
+                const double *Sf = tb.K + off_self + ig + (size_t)c.inds[k] * ng;
+                s0 = ld2(Sf); s1 = ld2(Sf + ng);
+            }
         }
     }
     double2 ma0[3], ma1[3], mb0[3], mb1[3];
@@ -716,7 +741,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     const int slot = batch_slot();
     const int col = a.col0 + slot;
     double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
-    LCol c = carve_gas(lds, rec, nl);
+    LCol c = carve_gas(lds, rec, nl, a.stage_cont != 0);
 
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
@@ -1167,6 +1192,22 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         // contiguous run
         double *tgb = tg + (size_t)nl * g0 + G.ig, *frb = fr + (size_t)nl * g0 + G.ig;
         const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
+        // continuum rows of this band into the wave's LDS area: lanes = (row, g-pair), 16-byte loads
+        const double *cont = nullptr;
+        if (c.cont && (R.cfg & (LC_SELF | LC_FOR))) {
+            double *cw = c.cont + (size_t)wave * CONT_DOUBLES;
+            __builtin_amdgcn_wave_barrier();   // the previous segment's items have read their rows
+            for (int it = lane; it < (CONT_SELF_ROWS + CONT_FOR_ROWS) * np; it += 64) {
+                const int row = it / np, pr = it - row * np;
+                const bool self = row < CONT_SELF_ROWS;
+                if (self && !(R.cfg & LC_SELF)) continue;
+                const double *src = tb.K + (self ? B.off_self + row * B.stride : B.off_for + (row - CONT_SELF_ROWS) * B.stride) + 2 * pr;
+                *reinterpret_cast<double2 *>(cw + row * CONT_STRIDE + 2 * pr) = ld2(src);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cont = cw;
+        }
         if (type == 2) {
             // binary-species regime: per-layer pre-pass into this wave's LDS area, then the items of the same layers
             double *ppd = c.pp + (size_t)wave * PP_DOUBLES;
@@ -1183,7 +1224,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                     const int l = act ? kb + dk : nin - 1;
                     const int k = kc + l;
                     double2 taug, plfrac;
-                    gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, taug, plfrac);
+                    gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, cont, taug, plfrac);
                     if (act) {
                         *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
                         *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
@@ -1198,7 +1239,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             const bool act = lane_on && kb + dk < kend;
             const int k = act ? kb + dk : kend - 1;
             double2 taug, plfrac;
-            gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, taug, plfrac);
+            gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, cont, taug, plfrac);
             if (act) {
                 *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
                 *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
@@ -1837,9 +1878,10 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
 lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
 
 // ---------------------------------------------------------------------------
-size_t lw_gas_lds_bytes(int nl)
+size_t lw_gas_lds_bytes(int nl, bool stage_cont)
 {
-    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1) + 2 * (nl + 1) + 3 * PP_DOUBLES;
+    size_t nd = (size_t)nl * (10 + LS_COUNT + LR_COUNT * 2 + 2 + 1) + 2 * (nl + 1) + 3 * PP_DOUBLES +
+                (stage_cont ? 3 * CONT_DOUBLES : 0);
     size_t ni = (size_t)nl * 5;
     return nd * sizeof(double) + ((ni * sizeof(int) + 7) & ~size_t(7));
 }
@@ -1940,7 +1982,9 @@ hipError_t lw_upload_retab()
 hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hipStream_t stream)
 {
     const int nl = a.nlayers;
-    const size_t lds_gas = lw_gas_lds_bytes(nl), lds_rt = lw_rt_lds_bytes(nl, a.icloud != 0);
+    // the continuum rows go through LDS when that still leaves four workgroups per CU
+    a.stage_cont = lw_gas_lds_bytes(nl, true) + 64 <= 160 * 1024 / 4 ? 1 : 0;
+    const size_t lds_gas = lw_gas_lds_bytes(nl, a.stage_cont != 0), lds_rt = lw_rt_lds_bytes(nl, a.icloud != 0);
     const size_t lds_fast = lw_rt_fast_lds_bytes(nl, a.icloud != 0);
     static size_t attr_gas = 0, attr_rt = 0, attr_fast = 0;
     if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
