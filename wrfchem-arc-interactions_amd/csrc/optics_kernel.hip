@@ -36,6 +36,16 @@ __constant__ OpticsTables c_opt;
 // c_gw[n] = {(2n+1)/(n(n+1)), (n-1)(n+1)/n}: the weights of the asymmetry sums of term n (the term number is
 // wave-uniform, so these are scalar loads; 8 entries of slack for the loop that fetches a block of terms ahead)
 __constant__ double2 c_gw[OPT_NMIE + 10];
+// everything of term n that depends on n alone, one 64-byte record per term: the term number is wave-uniform, so the
+// record is one scalar load and its fields are scalar operands of the lanes' arithmetic (formed per lane they cost
+// three conversions and as many multiply-adds per term)
+struct MieN { double en, tnm1, w2, gx, gy, pad_[3]; };   // n, 2n - 1, 2n + 1, the two asymmetry weights
+__constant__ MieN c_mn[OPT_NMIE + 10];
+__device__ __forceinline__ MieN mie_n(int n, double2 gw)   // the same from n (folds where n is a compile-time constant)
+{
+    const double en = (double)n;
+    return MieN{en, 2. * en - 1., 2. * en + 1., gw.x, gw.y, {0., 0., 0.}};
+}
 // per wavelength slot: pi / lambda (size parameter per um of diameter) and its cube root
 __constant__ double c_pil[2][OPT_NWAVE];
 
@@ -97,54 +107,75 @@ constexpr int OPT_MB = 16, OPT_RB = 8;   // checkpoint spacing, register block
 constexpr int OPT_NCK = 12;   // default of the template parameter
 
 
+// The values a term hands to the next one live in two slots by the PARITY of their index (psi_k, chi_k, a_k, b_k in
+// slot k & 1): term n overwrites slot n & 1, which held the values of n - 2, in place.  The loops that take the terms are
+// unrolled by an even count, so the parity is a compile-time constant and nothing is ever moved -- with "previous" and
+// "one before" variables every term ended in six register moves (under the per-lane predicate n <= nstop a rename is
+// not possible: lanes past their series keep their values).
 struct MieAcc {
-    double psi0, psi1, chi0, chi1, qs, qe, gs, sgn;
-    cplx an1, bn1, xb;
+    double psi[2], chi[2], qs, qe, gs, sgn;
+    cplx an[2], bn[2], xb;
 };
+__device__ __forceinline__ void mie_acc_start(MieAcc &A, double sinx, double cosx)
+{
+    A.psi[0] = sinx; A.psi[1] = cosx;      // psi_0 = sin x, psi_(-1) = cos x
+    A.chi[0] = cosx; A.chi[1] = -sinx;     // chi_0 = cos x, chi_(-1) = -sin x
+    A.qs = 0.; A.qe = 0.; A.gs = 0.; A.sgn = -1.;
+    A.an[0] = {0., 0.}; A.an[1] = {0., 0.}; A.bn[0] = {0., 0.}; A.bn[1] = {0., 0.}; A.xb = {0., 0.};
+}
 
 // FULL = false: only the extinction and scattering sums (longwave bands use absorption alone); BSC = false: no
 // backscatter sum (the radiation calls take tau, omega and g; bscoef is a diagnostic that is evaluated when asked for)
 template <bool FULL, bool BSC = FULL>
-__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv, double2 gw)
+__device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv, const MieN &K)
 {
-    const double en = (double)n;
-    const double psi = (2. * en - 1.) * xinv * A.psi1 - A.psi0;
-    const double chi = (2. * en - 1.) * xinv * A.chi1 - A.chi0;
+    const int par = n & 1;   // a constant after unrolling
+    const double nx = K.en * xinv, tx = K.tnm1 * xinv;
+    const double psi1 = A.psi[par ^ 1], chi1 = A.chi[par ^ 1];
+    const double psi = tx * psi1 - A.psi[par];
+    const double chi = tx * chi1 - A.chi[par];
+    A.psi[par] = psi; A.chi[par] = chi;
     // a_n = (t psi_n - psi_(n-1)) / (t xi_n - xi_(n-1)) with xi = psi - i chi: the denominator is the numerator minus
     // i (t chi_n - chi_(n-1)) -- four operations instead of a complex product and a complex difference (fp64 only:
     // in the packed-fp32 terms the same rearrangement cost accuracy -- the mixed path's heating-rate bound of
     // tests/test_full_domain_gpu.py went from inside 5e-3 K/day to 8.5e-3 -- and was withdrawn there)
     cplx t = cmul(D, minv);
-    t.re += en * xinv;
-    const cplx na = {t.re * psi - A.psi1, t.im * psi};
-    const cplx ca = {t.re * chi - A.chi1, t.im * chi};
+    t.re += nx;
+    const cplx na = {t.re * psi - psi1, t.im * psi};
+    const cplx ca = {t.re * chi - chi1, t.im * chi};
     const cplx da = {na.re + ca.im, na.im - ca.re};
     t = cmul(m, D);
-    t.re += en * xinv;
-    const cplx nb = {t.re * psi - A.psi1, t.im * psi};
-    const cplx cb = {t.re * chi - A.chi1, t.im * chi};
+    t.re += nx;
+    const cplx nb = {t.re * psi - psi1, t.im * psi};
+    const cplx cb = {t.re * chi - chi1, t.im * chi};
     const cplx db = {nb.re + cb.im, nb.im - cb.re};
     // a_n = na/da, b_n = nb/db with one reciprocal: 1/|da|^2 = |db|^2 / (|da|^2 |db|^2)
     const double ma = da.re * da.re + da.im * da.im, mb = db.re * db.re + db.im * db.im;
     const double r = frcp1(ma * mb);
     const double ra = r * mb, rb = r * ma;
-    const cplx an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
-    const cplx bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
-    const double w2 = 2. * en + 1.;
-    A.qs += w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
-    A.qe += w2 * (an.re + bn.re);
-    if (FULL) {
-        A.gs += gw.x * (an.re * bn.re + an.im * bn.im);
-        if (n > 1)
-            A.gs += gw.y * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+    if (!FULL) {
+        // extinction and scattering only: Re a_n and |a_n|^2 = |na|^2 / |da|^2 without forming a_n
+        const double are = (na.re * da.re + na.im * da.im) * ra, bre = (nb.re * db.re + nb.im * db.im) * rb;
+        const double a2 = (na.re * na.re + na.im * na.im) * ra, b2 = (nb.re * nb.re + nb.im * nb.im) * rb;
+        A.qs += K.w2 * (a2 + b2);
+        A.qe += K.w2 * (are + bre);
+    } else {
+        const cplx an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+        const cplx bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
+        A.qs += K.w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im);
+        A.qe += K.w2 * (an.re + bn.re);
+        A.gs += K.gx * (an.re * bn.re + an.im * bn.im);
+        if (n > 1) {
+            const cplx an1 = A.an[par ^ 1], bn1 = A.bn[par ^ 1];
+            A.gs += K.gy * (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
+        }
         if (BSC) {
-            A.xb.re += A.sgn * w2 * (an.re - bn.re);
-            A.xb.im += A.sgn * w2 * (an.im - bn.im);
+            A.xb.re += A.sgn * K.w2 * (an.re - bn.re);
+            A.xb.im += A.sgn * K.w2 * (an.im - bn.im);
             A.sgn = -A.sgn;
         }
-        A.an1 = an; A.bn1 = bn;
+        A.an[par] = an; A.bn[par] = bn;
     }
-    A.psi0 = A.psi1; A.psi1 = psi; A.chi0 = A.chi1; A.chi1 = chi;
 }
 
 // Where the logarithmic derivative may be carried UPWARD with the series (Wiscombe's MIEV0 does the same under a
@@ -184,7 +215,7 @@ __device__ __forceinline__ cplx ccot(cplx y)
 template <bool FULL, bool BSC = FULL>
 __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx minv, double xinv)
 {
-    mie_term<FULL, BSC>(A, n, D, m, minv, xinv, FULL ? c_gw[n] : make_double2(0., 0.));
+    mie_term<FULL, BSC>(A, n, D, m, minv, xinv, mie_n(n, FULL ? c_gw[n] : make_double2(0., 0.)));
 }
 
 template <bool FULL, bool BSC = FULL>
@@ -194,33 +225,33 @@ __device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, do
     const int nstop = (int)(x + 4. * cbrt(x) + 2.);
     const cplx yinv = crecip(y);
     MieAcc A;
-    sincos(x, &A.psi1, &A.psi0);
-    A.chi0 = -A.psi1; A.chi1 = A.psi0;
-    A.qs = 0.; A.qe = 0.; A.gs = 0.; A.sgn = -1.;
-    A.an1 = {0., 0.}; A.bn1 = {0., 0.}; A.xb = {0., 0.};
+    {
+        double sn, cs;
+        sincos(x, &sn, &cs);
+        mie_acc_start(A, sn, cs);
+    }
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
     cplx d = ccot(y);
-    // the asymmetry weights of the NEXT four terms are fetched while these four are evaluated: read where they are
-    // used, each of the two scalar loads of a term stood in front of a wait
-    double2 gw[4], gwn[4];
+    // the per-term records of the NEXT four terms are fetched while these four are evaluated: read where they are
+    // used, each scalar load of a term stood in front of a wait
+    MieN kn[4], knn[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gw[i] = FULL ? c_gw[i + 1] : make_double2(0., 0.);
+    for (int i = 0; i < 4; ++i) kn[i] = c_mn[i + 1];
     for (int n0 = 0; n0 < nstop; n0 += 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gwn[i] = FULL ? c_gw[n0 + 5 + i] : make_double2(0., 0.);
+        for (int i = 0; i < 4; ++i) knn[i] = c_mn[n0 + 5 + i];
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
             const int n = n0 + i;
             if (n <= nstop) {
-                const double en = (double)n;
-                const cplx ny = {en * yinv.re, en * yinv.im};
+                const cplx ny = {kn[i - 1].en * yinv.re, kn[i - 1].en * yinv.im};
                 d = csub(crecip(csub(ny, d)), ny);
-                mie_term<FULL, BSC>(A, n, d, m, minv, xinv, gw[i - 1]);
+                mie_term<FULL, BSC>(A, n, d, m, minv, xinv, kn[i - 1]);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gw[i] = gwn[i];
+        for (int i = 0; i < 4; ++i) kn[i] = knn[i];
     }
     const double x2inv = xinv * xinv;
     qsca = 2. * x2inv * A.qs;
@@ -246,10 +277,11 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
     const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
     const cplx yinv = crecip(y);
     MieAcc A;
-    sincos(x, &A.psi1, &A.psi0);
-    A.chi0 = -A.psi1; A.chi1 = A.psi0;
-    A.qs = 0.; A.qe = 0.; A.gs = 0.; A.sgn = -1.;
-    A.an1 = {0., 0.}; A.bn1 = {0., 0.}; A.xb = {0., 0.};
+    {
+        double sn, cs;
+        sincos(x, &sn, &cs);
+        mie_acc_start(A, sn, cs);
+    }
     const double xinv = frcp(x);
     const cplx minv = crecip(m);
     for (int seg = 0; seg < nck; seg += NCK) {   // once, unless the series is longer than NCK * OPT_MB terms
@@ -424,6 +456,7 @@ __device__ __forceinline__ void mie_pair_su(double x1, cplx m1, double x2, cplx 
     cplx dd1[OPT_MB2], dd2[OPT_MB2];
     cplx d1 = {0., 0.}, d2 = {0., 0.};
     MieAcc A1, A2;
+    double sn1, cs1, sn2, cs2;
     if (small) {
         const int nstart = s1.nstart > s2.nstart ? s1.nstart : s2.nstart;
         for (int n = nstart; n > OPT_MB2 + 1; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), down to D_9
@@ -440,18 +473,18 @@ __device__ __forceinline__ void mie_pair_su(double x1, cplx m1, double x2, cplx 
             d2 = csub(ny2, crecip(cadd(d2, ny2)));
             dd1[i] = d1; dd2[i] = d2;
         }
-        sincos_small(x1, A1.psi1, A1.psi0);
-        sincos_small(x2, A2.psi1, A2.psi0);
+        sincos_small(x1, sn1, cs1);
+        sincos_small(x2, sn2, cs2);
     } else {
 #pragma unroll
         for (int i = 0; i < OPT_MB2; ++i) { dd1[i] = {0., 0.}; dd2[i] = {0., 0.}; }
         d1 = ccot({x1 * m1.re, x1 * m1.im});
         d2 = ccot({x2 * m2.re, x2 * m2.im});
-        sincos(x1, &A1.psi1, &A1.psi0);
-        sincos(x2, &A2.psi1, &A2.psi0);
+        sincos(x1, &sn1, &cs1);
+        sincos(x2, &sn2, &cs2);
     }
-    A1.chi0 = -A1.psi1; A1.chi1 = A1.psi0; A1.qs = 0.; A1.qe = 0.;
-    A2.chi0 = -A2.psi1; A2.chi1 = A2.psi0; A2.qs = 0.; A2.qe = 0.;
+    mie_acc_start(A1, sn1, cs1);
+    mie_acc_start(A2, sn2, cs2);
 #pragma unroll
     for (int i = 0; i < OPT_MB2; ++i) {
         const int n = i + 1;
@@ -1166,6 +1199,13 @@ hipError_t optics_upload_tables(const OpticsTables &t)
         gw[n].y = (en - 1.) * (en + 1.) / en;
     }
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_gw), gw, sizeof gw);
+    if (e != hipSuccess) return e;
+    static MieN mn[OPT_NMIE + 10];
+    for (int n = 0; n < OPT_NMIE + 10; ++n) {
+        const double en = (double)n;
+        mn[n] = MieN{en, 2. * en - 1., 2. * en + 1., gw[n].x, gw[n].y, {0., 0., 0.}};
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_mn), mn, sizeof mn);
     if (e != hipSuccess) return e;
     double pil[2][OPT_NWAVE];
     for (int w = 0; w < OPT_NWAVE; ++w) {
