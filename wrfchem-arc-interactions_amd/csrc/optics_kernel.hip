@@ -562,20 +562,23 @@ __device__ __forceinline__ MieSetup32 mie_setup32(float x1, float m1re, float m1
     s.xinv = rcp2(s.x);
     return s;
 }
-struct MieAcc32 { v2f p, pm, c, cm, qs, qe; };   // psi_{n-1}, psi_{n-2}, chi_{n-1}, chi_{n-2}, sums
+struct MieAcc32 { v2f p[2], c[2], qs, qe; };   // psi_k, chi_k in slot k & 1 (as MieAcc: no moves between terms), sums
 __device__ __forceinline__ void mie_term32(MieAcc32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
 {
     const float en = (float)n;
     const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
-    const v2f psi = sel2(en > s.x.x, en > s.x.y, A.p * rcp2(nx + An), up * A.p - A.pm);
-    const v2f chi = up * A.c - A.cm;
-    const cplx2 xi = {psi, -chi}, xi1 = {A.p, -A.c};
+    const int par = n & 1;   // a constant after unrolling
+    const v2f p1 = A.p[par ^ 1], c1 = A.c[par ^ 1];
+    const v2f psi = sel2(en > s.x.x, en > s.x.y, p1 * rcp2(nx + An), up * p1 - A.p[par]);
+    const v2f chi = up * c1 - A.c[par];
+    A.p[par] = psi; A.c[par] = chi;
+    const cplx2 xi = {psi, -chi}, xi1 = {p1, -c1};
     cplx2 t = cmul2(D, s.minv);
     t.re += nx;
-    const cplx2 na = {t.re * psi - A.p, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
+    const cplx2 na = {t.re * psi - p1, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
     t = cmul2(s.m, D);
     t.re += nx;
-    const cplx2 nb = {t.re * psi - A.p, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
+    const cplx2 nb = {t.re * psi - p1, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
     const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
     const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
     const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
@@ -584,7 +587,6 @@ __device__ __forceinline__ void mie_term32(MieAcc32 &A, int n, cplx2 D, v2f An, 
     // an evaluation whose series has ended adds nothing
     A.qs += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
     A.qe += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re + bn.re), zero);
-    A.pm = A.p; A.p = psi; A.cm = A.c; A.c = chi;
 }
 // register blocks of OPT_MB2 terms; checkpoints of D_n (both evaluations) in slots 0..NCK2-1 and of A_n (both, two
 // checkpoints per slot) in slots NCK2..NCK2+NCK2/2-1 of the thread's column: OPT_NCK32 slots of 16 bytes
@@ -613,7 +615,7 @@ __device__ __forceinline__ void mie_pair32(const MieSetup32 &s, double2 *ck, flo
     float sn1, cs1, sn2, cs2;
     sincosf(s.x.x, &sn1, &cs1);
     sincosf(s.x.y, &sn2, &cs2);
-    A.p = v2f{sn1, sn2}; A.pm = v2f{cs1, cs2}; A.c = A.pm; A.cm = -A.p;
+    A.p[0] = v2f{sn1, sn2}; A.p[1] = v2f{cs1, cs2}; A.c[0] = A.p[1]; A.c[1] = -A.p[0];   // psi_0, psi_(-1), chi_0, chi_(-1)
     A.qs = v2f{0.f, 0.f}; A.qe = v2f{0.f, 0.f};
     for (int j = 0; j < nck; ++j) {
         cplx2 dd[OPT_MB2];
@@ -897,20 +899,23 @@ __device__ __forceinline__ cf32 mix_index32(const float *vol, float vwet, int mi
 // checkpoint above it: the chain is walked 2.5 times on average -- ~12 packed instructions per step against ~70 per
 // term of the series.  Asymmetry and backscatter sums as in mie_term<true>.
 constexpr int OPT_SB = 32;     // terms between checkpoints
-struct MieAccF32 { v2f p, pm, c, cm, qs, qe, gs; cplx2 an1, bn1, xb; float sgn; };
+struct MieAccF32 { v2f p[2], c[2], qs, qe, gs; cplx2 an[2], bn[2], xb; float sgn; };   // slots by index parity
 __device__ __forceinline__ void mie_term32_full(MieAccF32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
 {
     const float en = (float)n;
     const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
-    const v2f psi = sel2(en > s.x.x, en > s.x.y, A.p * rcp2(nx + An), up * A.p - A.pm);
-    const v2f chi = up * A.c - A.cm;
-    const cplx2 xi = {psi, -chi}, xi1 = {A.p, -A.c};
+    const int par = n & 1;   // a constant after unrolling
+    const v2f p1 = A.p[par ^ 1], c1 = A.c[par ^ 1];
+    const v2f psi = sel2(en > s.x.x, en > s.x.y, p1 * rcp2(nx + An), up * p1 - A.p[par]);
+    const v2f chi = up * c1 - A.c[par];
+    A.p[par] = psi; A.c[par] = chi;
+    const cplx2 xi = {psi, -chi}, xi1 = {p1, -c1};
     cplx2 t = cmul2(D, s.minv);
     t.re += nx;
-    const cplx2 na = {t.re * psi - A.p, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
+    const cplx2 na = {t.re * psi - p1, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
     t = cmul2(s.m, D);
     t.re += nx;
-    const cplx2 nb = {t.re * psi - A.p, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
+    const cplx2 nb = {t.re * psi - p1, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
     const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
     const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
     const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
@@ -920,13 +925,15 @@ __device__ __forceinline__ void mie_term32_full(MieAccF32 &A, int n, cplx2 D, v2
     A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
     A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
     v2f dg = (float)c_gw[n].x * (an.re * bn.re + an.im * bn.im);
-    if (n > 1) dg += (float)c_gw[n].y * (A.an1.re * an.re + A.an1.im * an.im + A.bn1.re * bn.re + A.bn1.im * bn.im);
+    if (n > 1) {
+        const cplx2 an1 = A.an[par ^ 1], bn1 = A.bn[par ^ 1];
+        dg += (float)c_gw[n].y * (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
+    }
     A.gs += sel2(on1, on2, dg, zero);
     A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
     A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
     A.sgn = -A.sgn;
-    A.an1 = an; A.bn1 = bn;
-    A.pm = A.p; A.p = psi; A.cm = A.c; A.c = chi;
+    A.an[par] = an; A.bn[par] = bn;
 }
 __device__ __forceinline__ void mie_pair32_full(const MieSetup32 &s, double2 *ck, v2f &qext, v2f &qsca, v2f &gasy, v2f &qback)
 {
@@ -960,9 +967,9 @@ __device__ __forceinline__ void mie_pair32_full(const MieSetup32 &s, double2 *ck
     sincosf(s.x.x, &sn1, &cs1);
     sincosf(s.x.y, &sn2, &cs2);
     const v2f zero = v2f{0.f, 0.f};
-    A.p = v2f{sn1, sn2}; A.pm = v2f{cs1, cs2}; A.c = A.pm; A.cm = -A.p;
+    A.p[0] = v2f{sn1, sn2}; A.p[1] = v2f{cs1, cs2}; A.c[0] = A.p[1]; A.c[1] = -A.p[0];
     A.qs = zero; A.qe = zero; A.gs = zero; A.sgn = -1.f;
-    A.an1 = {zero, zero}; A.bn1 = {zero, zero}; A.xb = {zero, zero};
+    A.an[0] = {zero, zero}; A.an[1] = {zero, zero}; A.bn[0] = {zero, zero}; A.bn[1] = {zero, zero}; A.xb = {zero, zero};
     for (int j = 0; j < nck; ++j) {
         const float4 cd = *reinterpret_cast<const float4 *>(&ck[(size_t)j * OPT_THREADS]);
         const float2 ca = reinterpret_cast<const float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1];
