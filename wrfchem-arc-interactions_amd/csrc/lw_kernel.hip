@@ -110,6 +110,16 @@ __device__ __forceinline__ double fdiv(double a, double b)
     double rem = __builtin_fma(-b, q, a);
     return __builtin_fma(rem, r, q);
 }
+// One Horner step p*r + c with the coefficient c kept in a register that SURVIVES the step.  Written as C the compiler
+// picks the two-address v_fmac_f64 (dst += a*b) and copies the coefficient into a fresh destination first -- a
+// v_mov_b64 per step: the 13 steps of exp_neg were 26 instructions, 130 of the 1 166 of the transfer kernel's
+// downward loop (four layers).  The three-address v_fma_f64 needs no copy.
+__device__ __forceinline__ double horner(double p, double r, double c)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "v"(c));
+    return o;
+}
 // exp(-x) for 0 <= x <~ 700 in fp64: n = rint(-x/ln2), two-term Cody-Waite reduction, degree-13 Taylor
 // on |r| <= ln2/2 (truncation 6e-18 relative), v_ldexp_f64.  Within ~2 ulp of a correctly rounded exp.
 __device__ __forceinline__ double exp_neg(double x)
@@ -118,20 +128,20 @@ __device__ __forceinline__ double exp_neg(double x)
     const double n = rint(t * 1.4426950408889634074);
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, t);
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;               // 1/13!
-    p = __builtin_fma(p, r, 2.0876756987868098979e-09); // 1/12!
-    p = __builtin_fma(p, r, 2.5052108385441718775e-08); // 1/11!
-    p = __builtin_fma(p, r, 2.7557319223985890653e-07); // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985892511e-06); // 1/9!
-    p = __builtin_fma(p, r, 2.4801587301587301566e-05); // 1/8!
-    p = __builtin_fma(p, r, 1.9841269841269841253e-04); // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889419e-03); // 1/6!
-    p = __builtin_fma(p, r, 8.3333333333333332177e-03); // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664354e-02); // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666665741e-01); // 1/3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
+    double p = 1.6059043836821614599e-10;      // 1/13!
+    p = horner(p, r, 2.0876756987868098979e-09); // 1/12!
+    p = horner(p, r, 2.5052108385441718775e-08); // 1/11!
+    p = horner(p, r, 2.7557319223985890653e-07); // 1/10!
+    p = horner(p, r, 2.7557319223985892511e-06); // 1/9!
+    p = horner(p, r, 2.4801587301587301566e-05); // 1/8!
+    p = horner(p, r, 1.9841269841269841253e-04); // 1/7!
+    p = horner(p, r, 1.3888888888888889419e-03); // 1/6!
+    p = horner(p, r, 8.3333333333333332177e-03); // 1/5!
+    p = horner(p, r, 4.1666666666666664354e-02); // 1/4!
+    p = horner(p, r, 1.6666666666666665741e-01); // 1/3!
+    p = horner(p, r, 0.5);
+    p = horner(p, r, 1.0);
+    p = horner(p, r, 1.0);
     return ldexp(p, (int)n);
 }
 
