@@ -20,7 +20,8 @@ struct LwKernelArgs {
     void *lwupb, *lwupbc, *lwupbcln, *lwdnb, *lwdnbc, *lwdnbcln;
     void *lwupflx, *lwupflxc, *lwupflxcln, *lwdnflx, *lwdnflxc, *lwdnflxcln;
     int *status;
-    // scratch between the gas-optics kernel and the transfer kernel, per column slot of the batch:
+    // scratch between the gas-optics kernel and the transfer kernel, per column slot of the batch (frac is written and
+    // read only where the regime interpolates it -- elsewhere it is a constant of the g-point, LwRegime::fracconst):
     // taug / frac [slot][band][layer][ig] (band-major: the band's block starts at nlayers * g0(band), a layer's row
     // of the band's ng g-points is contiguous, consecutive layers follow each other); rec [slot][lw_rec_doubles(nlayers)]
     double *taug, *frac, *rec;
@@ -42,10 +43,10 @@ void lw_cloud_tables(double *out /*[2][LW_NBND][58]*/);
 hipError_t lw_upload_retab();
 
 // per-column record handed from lw_gas_kernel to lw_rt_kernel:
-// planklay[16][nl] planklev[16][nl+1] taua[16][nl] secdiff[16] plankbnd[16] pz[nl+1]
+// planklay[16][nl] planklev[16][nl+1] taua[16][nl] secdiff[16] plankbnd[16] pz[nl+1] laytrop
 // followed by the in-cloud state of the column (written when icloud != 0):
 // cldf clwp ciwp cswp fliq fice fsno [nl] each, iliq iice isno [nl] each (integers stored as doubles), seeds[4]
-__host__ __device__ inline size_t lw_rec_base_doubles(int nl) { return (size_t)49 * nl + 49; }
+__host__ __device__ inline size_t lw_rec_base_doubles(int nl) { return (size_t)49 * nl + 50; }
 __host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_base_doubles(nl) + (size_t)10 * nl + 4; }
 // scratch doubles one column needs (taug + frac + record)
 inline size_t lw_scratch_doubles(int nl) { return (size_t)2 * LW_NGPT * nl + lw_rec_doubles(nl); }

@@ -732,6 +732,27 @@ __device__ __forceinline__ double adjcol(double col, double coldry, double chire
 
 }  // namespace
 
+// Where a lane of the transfer kernels finds the Planck fraction of its g-point in layer k: in the scratch if the
+// layer's regime (lower / upper atmosphere, decided by the column's laytrop) interpolates it, else the descriptor's
+// constant (the gas kernel does not store those).
+struct FracSrc {
+    bool lo2, up2;
+    double fclo, fcup;
+    int ltrop;
+};
+__device__ __forceinline__ FracSrc frac_src(const LwGDesc *gd, double laytrop)
+{
+    const int mlo = (gd->lo.cfg >> LC_FRAC_SHIFT) & 3, mup = (gd->up.cfg >> LC_FRAC_SHIFT) & 3;
+    return FracSrc{mlo == 2, mup == 2, mlo == 1 ? gd->lo.fracconst : 0., mup == 1 ? gd->up.fracconst : 0., (int)laytrop};
+}
+__device__ __forceinline__ double frac_at(const FracSrc &F, const double *fr, int k, int ng)
+{
+    const bool lower = k < F.ltrop;
+    double f = lower ? F.fclo : F.fcup;
+    if (lower ? F.lo2 : F.up2) f = fr[(size_t)k * ng];
+    return f;
+}
+
 // column slot of this workgroup within the batch: consecutive slots stay on one XCD (its own L2)
 __device__ __forceinline__ int batch_slot()
 {
@@ -1164,7 +1185,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
-    for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 1) + l] = c.pz[l];
+    for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 2) + l] = c.pz[l];
+    if (tid == 0) rec[lw_rec_base_doubles(nl) - 1] = (double)ltrop;   // the transfer kernel needs the regime of a layer
 
     LW_STAMP(5);
     // ======================= gas optics: (band, regime) segments; lanes = (layer, g-point) =======================
@@ -1202,6 +1224,9 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         // contiguous run
         double *tgb = tg + (size_t)nl * g0 + G.ig, *frb = fr + (size_t)nl * g0 + G.ig;
         const int type = (R.cfg >> LC_TYPE_SHIFT) & 3;
+        // the Planck fraction travels through the scratch only where it is interpolated; elsewhere the transfer kernel
+        // takes the g-point's constant from the descriptor (48 % of the (layer, g-point) pairs: 17 GB less to read)
+        const bool frac_stored = ((R.cfg >> LC_FRAC_SHIFT) & 3) == 2;
         // continuum rows of this band into the wave's LDS area: lanes = (row, g-pair), 16-byte loads
         const double *cont = nullptr;
         if (c.cont && (R.cfg & (LC_SELF | LC_FOR))) {
@@ -1237,7 +1262,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                     gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, cont, taug, plfrac);
                     if (act) {
                         *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
-                        *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
+                        if (frac_stored) *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1252,7 +1277,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, cont, taug, plfrac);
             if (act) {
                 *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
-                *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
+                if (frac_stored) *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
             }
         }
     }
@@ -1310,6 +1335,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
     const double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
+    const FracSrc FS = frac_src(gd, c.pz[nl + 1]);   // laytrop follows pz in the record
     const double secdiff = c.secdiff[band];
     double *fl = c.flux + (size_t)wave * nslot * nlev;   // down clean, down total, up clean, up total, down clear, up clear
     const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
@@ -1360,10 +1386,10 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
     bool iclddn = false;
     if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; if (nslot == 6) fl[4 * nlev + nl] = 0.; }
-    double tnext = tg[(size_t)(nl - 1) * ng], fnext = fr[(size_t)(nl - 1) * ng];
+    double tnext = tg[(size_t)(nl - 1) * ng], fnext = frac_at(FS, fr, nl - 1, ng);
     for (int k = nl - 1; k >= 0; --k) {
         const double taug = tnext, plfrac = fnext;
-        if (k > 0) { tnext = tg[(size_t)(k - 1) * ng]; fnext = fr[(size_t)(k - 1) * ng]; }
+        if (k > 0) { tnext = tg[(size_t)(k - 1) * ng]; fnext = frac_at(FS, fr, k - 1, ng); }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
@@ -1422,7 +1448,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     // ---- upward sweep (surface -> top), LW:3331-3356 ----
     for (int k = 0; k < nl; ++k) {   // tnext / fnext hold layer 0 after the downward sweep
         const double taug = tnext, plfrac = fnext;
-        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * ng]; fnext = fr[(size_t)(k + 1) * ng]; }
+        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * ng]; fnext = frac_at(FS, fr, k + 1, ng); }
         const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
@@ -1616,6 +1642,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
     double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
+    const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1]);
     // per chunk: downward and upward flux of the call with aerosol at every level, then the small sums
     // [0..2] clean sky: surface down, surface up, top up; [4..6] clear sky alike
     const size_t ws = 2 * nlev + 8;
@@ -1669,7 +1696,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     // the layer's inputs are fetched one layer ahead: gas optics from the scratch, Planck functions and aerosol
     // optical depth of the lane's band from the column record
     // (one layer ahead; two layers ahead, in either issue order, was measured slower: 30.2 against 28.0 ms)
-    double tnext = tg[(size_t)(nl - 1) * ng], fnext = fr[(size_t)(nl - 1) * ng];
+    double tnext = tg[(size_t)(nl - 1) * ng], fnext = frac_at(FS, fr, nl - 1, ng);
     double blnext = pl[nl - 1], pvnext = pv[nl - 1], tanext = ta[nl - 1], pvhi = pv[nl];
     for (int b = nblk - 1; b >= 0; --b) {
         double v[4] = {0., 0., 0., 0.};
@@ -1679,7 +1706,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             if (k < nl) {
                 const double taug = tnext, plfrac = fnext, blay = blnext, pvlo = pvnext, tak = tanext;
                 if (k > 0) {
-                    tnext = tg[(size_t)(k - 1) * ng]; fnext = fr[(size_t)(k - 1) * ng];
+                    tnext = tg[(size_t)(k - 1) * ng]; fnext = frac_at(FS, fr, k - 1, ng);
                     blnext = pl[k - 1]; pvnext = pv[k - 1]; tanext = ta[k - 1];
                 }
                 const double dplankup = pvhi - blay, dplankdn = pvlo - blay;
@@ -1791,7 +1818,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                 if (k < nl) {
                     const double taug = tnext, plfrac = fnext, blay = blnext, tak = tanext, pvup = pvnext;
                     if (k + 1 < nl) {
-                        tnext = tg[(size_t)(k + 1) * ng]; fnext = fr[(size_t)(k + 1) * ng];
+                        tnext = tg[(size_t)(k + 1) * ng]; fnext = frac_at(FS, fr, k + 1, ng);
                         blnext = pl[k + 1]; pvnext = pv[k + 2]; tanext = ta[k + 1];
                     }
                     const double dplankup = pvup - blay, dplankdn = pvlo - blay;
@@ -1835,7 +1862,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         const size_t ei2 = ej0 * a.ni_m + ei0;
         const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
         const size_t base3 = ej0 * sj + k0 * sk + ei0;
-        const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 1);
+        const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 2);
         const double *f0 = lds + ec_col * cold + recn;
         const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
         // the chunk sums in chunk order
