@@ -188,12 +188,44 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
 constexpr double OPT_UP_XMIN = 0.3, OPT_UP_ABSMAX = 10.0;
 __device__ __forceinline__ bool mie_upward_ok(double x, cplx m) { return x >= OPT_UP_XMIN && m.im * x < OPT_UP_ABSMAX; }
 
+// sin and cos of 0 <= x < 1e5 (size parameters reach 225, |m| x 600): the library's sincos carries the reduction of
+// arbitrary arguments -- two of them per evaluation were a tenth of the shortwave kernel's instructions.  Here: n =
+// rint(x 2/pi), three-part Cody-Waite reduction with 33-bit pieces of pi/2 (n pi/2_1 and n pi/2_2 are exact products),
+// the kernel polynomials of fdlibm on |r| <= pi/4, quadrant by selects.  Absolute error about 1e-16 (1 + x 1e-16),
+// far inside the stage's tolerance.
+__device__ __forceinline__ void sincos_mid(double x, double &sn, double &cs)
+{
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-fn, 6.07710050630396597660e-11, r);
+    r = __builtin_fma(-fn, 2.02226624871116645580e-21, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(ps * z, r, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    const double cr = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
+    const int q = (int)fn & 3;
+    const double s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // cot(a + ib) = (sin 2a - i sinh 2b) / (cosh 2b - cos 2a) = (sa ca - i sh ch) / (sa^2 + sh^2), b >= 0: one sincos, one
 // sinh (its own series below 0.25, where (e^b - e^-b)/2 would cancel), cosh from sinh
 __device__ __forceinline__ cplx ccot(cplx y)
 {
     double sa, ca;
-    sincos(y.re, &sa, &ca);
+    sincos_mid(y.re, sa, ca);
     const double b = y.im, b2 = b * b;
     double sh;
     if (b < 0.25) {
@@ -218,16 +250,18 @@ __device__ __forceinline__ void mie_term(MieAcc &A, int n, cplx D, cplx m, cplx 
     mie_term<FULL, BSC>(A, n, D, m, minv, xinv, mie_n(n, FULL ? c_gw[n] : make_double2(0., 0.)));
 }
 
+// cbx: cube root of x (the caller has it from the particle's diameter: one cube root per section, not per wavelength)
 template <bool FULL, bool BSC = FULL>
-__device__ __forceinline__ void mie_sphere_up(double x, cplx m, double &qext, double &qsca, double &gasy, double &qback)
+__device__ __forceinline__ void mie_sphere_up(double x, cplx m, double cbx, double &qext, double &qsca, double &gasy,
+                                              double &qback)
 {
     const cplx y = {x * m.re, x * m.im};
-    const int nstop = (int)(x + 4. * cbrt(x) + 2.);
+    const int nstop = (int)(x + 4. * cbx + 2.);
     const cplx yinv = crecip(y);
     MieAcc A;
     {
         double sn, cs;
-        sincos(x, &sn, &cs);
+        sincos_mid(x, sn, cs);
         mie_acc_start(A, sn, cs);
     }
     const double xinv = frcp(x);
@@ -279,7 +313,7 @@ __device__ __forceinline__ void mie_sphere_down(double x, cplx m, double2 *ck /*
     MieAcc A;
     {
         double sn, cs;
-        sincos(x, &sn, &cs);
+        sincos_mid(x, sn, cs);
         mie_acc_start(A, sn, cs);
     }
     const double xinv = frcp(x);
@@ -360,10 +394,10 @@ __device__ __noinline__ MieQ2 mie_sphere_down_call(double x, cplx m, double2 *ck
 }
 
 template <bool FULL, int NCK = OPT_NCK, bool BSC = FULL>
-__device__ __forceinline__ void mie_sphere(double x, cplx m, double2 *ck, double &qext, double &qsca, double &gasy,
-                                           double &qback)
+__device__ __forceinline__ void mie_sphere(double x, cplx m, double cbx, double2 *ck, double &qext, double &qsca,
+                                           double &gasy, double &qback)
 {
-    if (mie_upward_ok(x, m)) mie_sphere_up<FULL, BSC>(x, m, qext, qsca, gasy, qback);   // the particle's own choice: no vote
+    if (mie_upward_ok(x, m)) mie_sphere_up<FULL, BSC>(x, m, cbx, qext, qsca, gasy, qback);   // the particle's own choice: no vote
     else mie_sphere_down<FULL, NCK, BSC>(x, m, ck, qext, qsca, gasy, qback);
 }
 
@@ -480,8 +514,8 @@ __device__ __forceinline__ void mie_pair_su(double x1, cplx m1, double x2, cplx 
         for (int i = 0; i < OPT_MB2; ++i) { dd1[i] = {0., 0.}; dd2[i] = {0., 0.}; }
         d1 = ccot({x1 * m1.re, x1 * m1.im});
         d2 = ccot({x2 * m2.re, x2 * m2.im});
-        sincos(x1, &sn1, &cs1);
-        sincos(x2, &sn2, &cs2);
+        sincos_mid(x1, sn1, cs1);
+        sincos_mid(x2, sn2, cs2);
     }
     mie_acc_start(A1, sn1, cs1);
     mie_acc_start(A2, sn2, cs2);
@@ -735,6 +769,7 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
             num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
         }
         const double dwet = ddry * cbrt(vwet * frcp(vdry));
+        const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for the four wavelengths
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
 #pragma unroll 1
@@ -742,9 +777,11 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
             if (!((want >> w) & 1)) continue;
             const cplx m = mix_index(vol, vwet, a.mix, w);
             double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
-            x = x > OPT_XMAX ? OPT_XMAX : x;
+            const bool capped = x > OPT_XMAX;
+            x = capped ? OPT_XMAX : x;
+            const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
             double qe, qs, g = 0., qb = 0.;
-            mie_sphere<true, OPT_NCK_SWC, BSC>(x, m, ck, qe, qs, g, qb);
+            mie_sphere<true, OPT_NCK_SWC, BSC>(x, m, cbx, ck, qe, qs, g, qb);
             double *s = acc + (size_t)(4 * w) * OPT_THREADS;
             s[0] += cross * qe;
             s[OPT_THREADS] += cross * qs;
