@@ -70,6 +70,21 @@ def test_cloudy_lwrad_without_profiles_matches_oracle(hip_lib, wa, lw_table_file
     assert (got["lwcf"][~cloudy] == 0).all()
 
 
+@pytest.mark.parametrize("fraction", [0.0, 1.0])
+def test_lw_cloud_lists_with_one_list_empty(hip_lib, wa, lw_table_file, lw_oracle, fraction):
+    """icloud /= 0 sends cloud-free and cloudy columns to their own launches (csrc/cloud_lists.h): a tile where every
+    column is cloud-free, and one where every column holds cloud, leave one of the two lists empty."""
+    eng, nlay = _init(wa, lw_table_file, 40)
+    st = wa.synth.make_wrf_state(7, 5, 40, seed=20260540)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260541, cloudy_fraction=fraction)
+    cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
+    assert cloudy.all() if fraction else not cloudy.any()
+    for device in (True, False):
+        got = run_hip_lwrad(eng, st, cloud=cloud, device=device)
+        ref = run_oracle_lwrad(lw_oracle, st, nlay, cloud=cloud)
+        assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+
+
 def test_cloudy_lw_tile_subset_host_mode_and_no_clean(hip_lib, wa, lw_table_file, lw_oracle):
     eng, nlay = _init(wa, lw_table_file, 40)
     st = wa.synth.make_wrf_state(9, 7, 40, seed=20260520)

@@ -52,6 +52,21 @@ def test_cloudy_swrad_without_profiles_matches_oracle(hip_lib, wa, sw_table_file
     assert worst < 1e-8
 
 
+@pytest.mark.parametrize("fraction", [0.0, 1.0])
+def test_cloud_lists_with_one_list_empty(hip_lib, wa, sw_table_file, sw_oracle, fraction):
+    """icloud /= 0 sends cloud-free and cloudy columns to their own launches (csrc/cloud_lists.h): a tile where every
+    column is cloud-free, and one where every column holds cloud, leave one of the two lists empty."""
+    eng = _init(wa, sw_table_file)
+    st = wa.synth.make_wrf_state(7, 5, 40, seed=20260440, night_fraction=0.1)
+    cloud = wa.synth_clouds.add_clouds(st, seed=20260441, cloudy_fraction=fraction)
+    cloudy = st.a3["cldfra3d"].sum(axis=1) > 0
+    assert cloudy.all() if fraction else not cloudy.any()
+    for device in (True, False):
+        got = run_hip_swrad(eng, st, cloud=cloud, device=device)
+        ref = run_oracle_swrad(sw_oracle, st, cloud=cloud)
+        assert compare_sw(got, ref, RTOL, ATOL) < 1e-8
+
+
 def test_cloudy_tile_subset_host_mode_and_no_clean(hip_lib, wa, sw_table_file, sw_oracle):
     eng = _init(wa, sw_table_file)
     st = wa.synth.make_wrf_state(9, 7, 40, seed=20260420)

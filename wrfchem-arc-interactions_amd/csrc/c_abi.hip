@@ -15,6 +15,7 @@
 #include "rrtmg_state.h"
 #include "sw_kernel.h"
 #include "tile_staging.h"
+#include "cloud_lists.h"
 #include "lw_state.h"
 
 namespace rrtmg {
@@ -362,6 +363,17 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             }
             k.scratch = w.p;
             k.scratch_stride = percol;
+            // cloud-free and cloudy columns to their own kernel instantiations (cloud_lists.h): two device lists per
+            // launch unit, grow-only like the scratch
+            const bool lists_on = k.icloud != 0 && cloud_lists_enabled();
+            if (lists_on && w.lists_ints < 2 * (size_t)ncol_all + 8) {
+                if (w.lists) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.lists)); w.lists = nullptr; w.lists_ints = 0; }
+                void *p = nullptr;
+                HIPCHK(hipMalloc(&p, (2 * (size_t)ncol_all + 8) * sizeof(int)));
+                w.lists = static_cast<int *>(p);
+                w.lists_ints = 2 * (size_t)ncol_all + 8;
+            }
+            int *const lists = w.lists;
             // mem = 1: launched under the lock -- another host thread on the caller's stream may not resize the buffer
             // in between.  mem = 0: the stream and its scratch belong to this thread alone; the lock is dropped so
             // that concurrent tiles pack and enqueue side by side.
@@ -375,6 +387,22 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
                     k.status = stg.status_word(c);
                     ncol_c = ni_t * k.nj_t;
                 }
+                if (lists_on) {
+                    int *const counts = lists + 2 * (size_t)ncol_all;
+                    HIPCHK(cloud_lists_launch(k.cldfra3d, k.real4, k.ni_m, k.nk_m, k.its - k.ims, k.jts - k.jms, k.kts - k.kms,
+                                              k.ni_t, k.nj_t, k.nk, lists, counts, stream));
+                    for (int pass = 0; pass < 2; ++pass) {   // 0: the cloud-free columns without McICA, 1: the cloudy ones
+                        SwKernelArgs kp = k;
+                        if (pass == 0) kp.icloud = 0;
+                        kp.colmap = lists + (size_t)pass * ncol_c;
+                        kp.colcount = counts + pass;
+                        for (int c0 = 0; c0 < ncol_c; c0 += cap_cols) {
+                            kp.col0 = c0;
+                            kp.ncol = ncol_c - c0 < cap_cols ? ncol_c - c0 : cap_cols;
+                            HIPCHK(sw_launch(kp, stream));
+                        }
+                    }
+                } else
                 for (int c0 = 0; c0 < ncol_c; c0 += cap_cols) {
                     k.col0 = c0;
                     k.ncol = ncol_c - c0 < cap_cols ? ncol_c - c0 : cap_cols;
@@ -426,7 +454,10 @@ extern "C" int rrtmg_hip_finalize(void)
     if (st.dCld) (void)hipFree(st.dCld);
     for (auto &kv : st.dJump) if (kv.second) (void)hipFree(kv.second);
     st.dJump.clear();
-    for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : st.scratch) {
+        if (kv.second.p) (void)hipFree(kv.second.p);
+        if (kv.second.lists) (void)hipFree(kv.second.lists);
+    }
     st.scratch.clear();
     st.dK = st.dExp = st.dG = st.dStatus = st.dCld = nullptr;
     st.ready = false;

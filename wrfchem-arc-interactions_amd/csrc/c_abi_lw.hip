@@ -14,6 +14,7 @@
 #include "lw_common.h"
 #include "lw_kernel.h"
 #include "tile_staging.h"
+#include "cloud_lists.h"
 #include "sw_kernel.h"   // kiss_jump_table
 #include "lw_ref_tables.h"
 #include "lw_state.h"
@@ -333,6 +334,16 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
             w.doubles = percol * (size_t)cap_cols;
         }
         scratch = w.p;
+        // cloud-free and cloudy columns to their own kernel instantiations (cloud_lists.h)
+        const bool lists_on = k.icloud != 0 && cloud_lists_enabled();
+        if (lists_on && w.lists_ints < 2 * (size_t)ncol + 8) {
+            if (w.lists) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.lists)); w.lists = nullptr; w.lists_ints = 0; }
+            void *p = nullptr;
+            HIPCHK(hipMalloc(&p, (2 * (size_t)ncol + 8) * sizeof(int)));
+            w.lists = static_cast<int *>(p);
+            w.lists_ints = 2 * (size_t)ncol + 8;
+        }
+        int *const lists = w.lists;
         // the gas and transfer kernels of one call hand their batch over through this buffer.  mem = 1: host threads
         // that share the caller's stream enqueue their kernel sequences one call at a time, under the lock.  mem = 0:
         // stream and scratch belong to this thread alone; the lock is dropped so that concurrent tiles pack and
@@ -347,6 +358,18 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
                 k.status = stg.status_word(c);
                 ncol_c = ni_t * k.nj_t;
             }
+            if (lists_on) {
+                int *const counts = lists + 2 * (size_t)ncol;
+                HIPCHK(cloud_lists_launch(k.cldfra3d, k.real4, k.ni_m, k.nk_m, k.its - k.ims, k.jts - k.jms, k.kts - k.kms,
+                                          k.ni_t, k.nj_t, k.nk, lists, counts, stream));
+                for (int pass = 0; pass < 2; ++pass) {   // 0: the cloud-free columns without McICA, 1: the cloudy ones
+                    LwKernelArgs kp = k;
+                    if (pass == 0) kp.icloud = 0;
+                    kp.colmap = lists + (size_t)pass * ncol_c;
+                    kp.colcount = counts + pass;
+                    HIPCHK(lw_launch(kp, ncol_c, scratch, cap_cols, stream));
+                }
+            } else
             HIPCHK(lw_launch(k, ncol_c, scratch, cap_cols, stream));
             if (a->mem != 1) HIPCHK(stg.fetch(c));
         }
@@ -392,7 +415,10 @@ extern "C" int rrtmg_hip_lw_finalize(void)
     for (void **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }
     {
         std::lock_guard<std::mutex> lock(st.scratch_mutex);
-        for (auto &kv : st.scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+        for (auto &kv : st.scratch) {
+            if (kv.second.p) (void)hipFree(kv.second.p);
+            if (kv.second.lists) (void)hipFree(kv.second.lists);
+        }
         st.scratch.clear();
     }
     st.ready = false;

@@ -28,6 +28,7 @@ struct LwKernelArgs {
     int col0;                           // first tile column of this batch
     int nbatch;                         // columns of this batch
     int stage_cont;                     // gas kernel: continuum rows of a segment's band through LDS (lw_launch decides)
+    const int *colmap, *colcount;       // column list of this call (cloud_lists.h) or null: columns col0 .. col0+nbatch-1
     // clouds (icloud != 0), as in SwKernelArgs
     int icloud, has_reqc, has_reqi, has_reqs, warm_rain, progn;
     int f_ice_phy, fer_hires;            // "MP option 5" split of snow; Ferrier-Aligo (qi3d = all frozen water)

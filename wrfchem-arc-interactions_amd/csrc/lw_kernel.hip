@@ -754,11 +754,24 @@ __device__ __forceinline__ double frac_at(const FracSrc &F, const double *fr, in
 }
 
 // column slot of this workgroup within the batch: consecutive slots stay on one XCD (its own L2)
-__device__ __forceinline__ int batch_slot()
+// nwg: the workgroups of the launch that have work (all of them, or what the call's column list holds, cloud_lists.h);
+// -1 for the others
+__device__ __forceinline__ int batch_slot(const int nwg)
 {
-    const int b = blockIdx.x, nwg = gridDim.x;
+    const int b = blockIdx.x;
+    if (b >= nwg) return -1;
     const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+// columns of this launch: the batch's own count, or what the call's column list holds beyond col0
+__device__ __forceinline__ int batch_columns(const LwKernelArgs &a)
+{
+    int n = a.nbatch;
+    if (a.colmap) {
+        const int left = *a.colcount - a.col0;
+        n = left < n ? left : n;
+    }
+    return n;
 }
 
 // Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
@@ -769,8 +782,10 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
-    const int slot = batch_slot();
-    const int col = a.col0 + slot;
+    const int slot = batch_slot(batch_columns(a));
+    if (slot < 0) return;   // (uniform over the workgroup, in front of its first barrier)
+    int col = a.col0 + slot;
+    if (a.colmap) col = a.colmap[col];   // entry of the call's column list (cloud_lists.h)
     double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
     LCol c = carve_gas(lds, rec, nl, a.stage_cont != 0);
 
@@ -1299,8 +1314,10 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
-    const int slot = batch_slot();
-    const int col = a.col0 + slot;
+    const int slot = batch_slot(batch_columns(a));
+    if (slot < 0) return;   // (uniform over the workgroup, in front of its first barrier)
+    int col = a.col0 + slot;
+    if (a.colmap) col = a.colmap[col];   // entry of the call's column list (cloud_lists.h)
     LCol c = carve_rt(lds, nl, a.icloud != 0);
     const int nslot = a.icloud != 0 ? 6 : 4;   // flux slots per wave: + clear-sky down / up with clouds
     {
@@ -1597,9 +1614,11 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
-    const int grp = batch_slot();
     constexpr bool cloud = CLOUD;
-    const int ncols = a.nbatch - RTF_COLS * grp < RTF_COLS ? a.nbatch - RTF_COLS * grp : RTF_COLS;   // 1..3
+    const int nbatch = batch_columns(a);
+    const int grp = batch_slot((nbatch + RTF_COLS - 1) / RTF_COLS);
+    if (grp < 0) return;   // (uniform over the workgroup, in front of its first barrier)
+    const int ncols = nbatch - RTF_COLS * grp < RTF_COLS ? nbatch - RTF_COLS * grp : RTF_COLS;   // 1..7
     const size_t recn = cloud ? rtf_cloud_doubles(nl) : 0;   // staged part of the record
     const size_t cold = rtf_col_doubles(nl, cloud);
     if (cloud)
@@ -1621,7 +1640,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int colsel = seat_on ? scol : 0;                    // idle seats shadow column 0 (no stores, nothing summed)
     const int g = graw < LW_NGPT ? graw : LW_NGPT - 1;
     const int slot = RTF_COLS * grp + colsel;
-    const int col = a.col0 + slot;
+    int col = a.col0 + slot;
+    if (a.colmap) col = a.colmap[col];   // (an existing entry: slot is clamped to the group's columns)
     const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: planklay planklev taua secdiff plankbnd pz
     const double *cb = lds + colsel * cold;
     const int r4 = a.real4;
@@ -1856,7 +1876,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int ec_col = wave >> 1;
     if (ec_col < ncols) {
         const int etid = tid & 127;
-        const int ecol = a.col0 + RTF_COLS * grp + ec_col;
+        int ecol = a.col0 + RTF_COLS * grp + ec_col;
+        if (a.colmap) ecol = a.colmap[ecol];
         const int eit = ecol % a.ni_t, ejt = ecol / a.ni_t;
         const size_t ei0 = (size_t)(a.its - a.ims + eit), ej0 = (size_t)(a.jts - a.jms + ejt), k0 = (size_t)(a.kts - a.kms);
         const size_t ei2 = ej0 * a.ni_m + ei0;

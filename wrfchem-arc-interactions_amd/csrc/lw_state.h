@@ -32,7 +32,10 @@ struct LwState {
     // Scratch between the two kernels (taug, frac, column record), one grow-only buffer per stream: calls
     // on one stream run in order and may share it, calls on different streams (the OpenMP tile loop of
     // DRV:975-982) must not.
-    struct Scratch { double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */ };
+    struct Scratch {
+        double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */
+        int *lists = nullptr; size_t lists_ints = 0;   // column lists of the cloud-free / cloudy dispatch (cloud_lists.h)
+    };
     std::map<void *, Scratch> scratch;
     std::mutex scratch_mutex;
 };

@@ -13,7 +13,10 @@
 //    when the seed is < 10^9, which the seeding rule guarantees.)
 // 2. Cloud optics coefficient tables in the layout the kernel reads.
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+
+#include "cloud_lists.h"
 
 #include "sw_kernel.h"
 #include "sw_cld_tables.h"
@@ -109,6 +112,62 @@ void lw_cloud_tables(double *out)
         for (int i = 0; i < 58; ++i) out[(0 * LW_NBND + b) * 58 + i] = LWCLD_ABSLIQ1[b][i];
         for (int i = 0; i < 46; ++i) out[(1 * LW_NBND + b) * 58 + i] = LWCLD_ABSICE3[b][i];
     }
+}
+
+
+// ---- cloud lists (cloud_lists.h) ----
+namespace {
+__global__ void cloud_lists_kernel(const void *cldfra3d, int real4, int ni_m, int nk_m, int i0, int j0, int k0, int ni_t,
+                                   int ncol, int nk, int *lists, int *counts)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = col < ncol;
+    bool cloudy = false;
+    if (valid) {
+        const int it = col % ni_t, jt = col / ni_t;
+        const size_t base = ((size_t)(j0 + jt) * nk_m + k0) * ni_m + (size_t)(i0 + it);
+        for (int k = 0; k < nk; ++k) {
+            const size_t q = base + (size_t)k * ni_m;
+            const double cf = real4 ? (double)static_cast<const float *>(cldfra3d)[q] : static_cast<const double *>(cldfra3d)[q];
+            cloudy = cloudy || !(cf < 1.0e-20);   // the kernels' own threshold for "no cloud in this layer"
+        }
+    }
+    // one atomic per wave and list; the wave's columns stay together and in order
+    const unsigned long long mc = __ballot(valid && cloudy), mf = __ballot(valid && !cloudy);
+    const int lane = threadIdx.x & 63;
+    int basec = 0, basef = 0;
+    if (lane == 0) {
+        if (mc) basec = atomicAdd(&counts[1], __popcll(mc));
+        if (mf) basef = atomicAdd(&counts[0], __popcll(mf));
+    }
+    basec = __shfl(basec, 0, 64);
+    basef = __shfl(basef, 0, 64);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (valid) {
+        if (cloudy) lists[ncol + basec + __popcll(mc & below)] = col;
+        else lists[basef + __popcll(mf & below)] = col;
+    }
+}
+}  // namespace
+
+hipError_t cloud_lists_launch(const void *cldfra3d, int real4, int ni_m, int nk_m, int i0, int j0, int k0, int ni_t, int nj_t,
+                              int nk, int *lists, int *counts, hipStream_t stream)
+{
+    const int ncol = ni_t * nj_t;
+    hipError_t e = hipMemsetAsync(counts, 0, 2 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cloud_lists_kernel, dim3((ncol + 255) / 256), dim3(256), 0, stream, cldfra3d, real4, ni_m, nk_m, i0, j0,
+                       k0, ni_t, ncol, nk, lists, counts);
+    return hipGetLastError();
+}
+
+bool cloud_lists_enabled()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RRTMG_HIP_CLOUD_LISTS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
 }
 
 }  // namespace rrtmg

@@ -29,7 +29,10 @@ struct SwState {
     std::map<int, void *> dJump;           // KISS jump tables by layer count
     std::mutex jump_mutex;
     // layer scratch of the column kernel, one grow-only buffer per stream (guarded by jump_mutex)
-    struct Scratch { double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */ };
+    struct Scratch {
+        double *p = nullptr; size_t doubles = 0; size_t limit = 0; /* doubles that fitted after an OOM */
+        int *lists = nullptr; size_t lists_ints = 0;   // column lists of the cloud-free / cloudy dispatch (cloud_lists.h)
+    };
     std::map<void *, Scratch> scratch;
 };
 

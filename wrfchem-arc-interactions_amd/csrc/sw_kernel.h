@@ -38,6 +38,9 @@ struct SwKernelArgs {
     double *scratch;                     // ncol x scratch_stride doubles
     size_t scratch_stride;               // sw_scratch_doubles_per_column(nk)
     int col0, ncol;                      // this launch covers columns col0 .. col0+ncol-1 of the tile
+    // ... or, with a column list (cloud_lists.h: the cloud-free and the cloudy columns of a tile go to their own kernel
+    // instantiations), the list entries col0 .. col0+ncol-1 that exist: workgroups beyond *colcount leave at once
+    const int *colmap, *colcount;
     SwDeviceTables tab;
 };
 

@@ -718,9 +718,16 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     // ---- column of this workgroup (XCD-aware: b, b+8, b+16.. are neighbours in i) ----
     int col;
     {
-        const int b = vb, nwg = a.ncol;   // columns of this launch (a chunk of the tile)
+        const int b = vb;
+        int nwg = a.ncol;   // columns of this launch (a chunk of the tile), or what the call's column list holds of them
+        if (a.colmap) {
+            const int left = *a.colcount - a.col0;
+            nwg = left < nwg ? left : nwg;
+        }
+        if (b >= nwg) return;   // (uniform over the workgroup, in front of its first barrier)
         const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         col = a.col0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        if (a.colmap) col = a.colmap[col];   // (cloud_lists.h)
     }
     const int it = col % a.ni_t, jt = col / a.ni_t;            // position inside the tile
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt);
