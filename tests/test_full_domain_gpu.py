@@ -180,9 +180,10 @@ def test_config3_500x500x50_8bin(hip_lib, wa, sw_table_file, lw_table_file, monk
 
 
 def test_config4_share_1000x125x60_mixed(hip_lib, wa, sw_table_file, lw_table_file):
-    """One rank's slab of BASELINE configs[4] (rows 0..124 of the 1000x1000x60 domain), optical averaging in packed
-    fp32.  Properties as above; the first row against the fp64 oracle at the mixed path's tolerance (the optics differ
-    by up to 2e-4 in optical depth, 1e-4 in omega and g: tests/test_optics_gpu.py)."""
+    """One rank's slab of BASELINE configs[4] (rows 0..124 of the 1000x1000x60 domain), optical averaging in mixed
+    precision.  Properties as above; the first row against the fp64 oracle at the mixed path's tolerance (the optics
+    differ by up to 2e-5 in shortwave optical depth, 1e-5 in omega and g, 1e-4 in longwave absorption:
+    tests/test_optics_gpu.py)."""
     st, ms = wa.synth_mosaic.make_mosaic_rows(1000, 1000, 60, 0, 125, nbin=4, seed=20260005, wrf_seed=20260002)
     ch = Chain(wa, sw_table_file, lw_table_file, st, ms, precision="mixed")
     try:
@@ -191,11 +192,11 @@ def test_config4_share_1000x125x60_mixed(hip_lib, wa, sw_table_file, lw_table_fi
         wa.engine_optics.optics_precision("f64")
     _properties(st, out)
     ref = _oracle_first_row(wa, sw_table_file, lw_table_file, st, ms)
-    _compare_row(out, ref, st, 2e-4, 5e-2)
+    _compare_row(out, ref, st, 2e-5, 5e-3)
 
 
 def test_mixed_optics_flux_and_forcing_error_is_bounded(hip_lib, wa, sw_table_file, lw_table_file):
-    """What the packed-fp32 Mie series costs downstream: TOA / surface fluxes, heating rates and the clean-minus-aerosol
+    """What the packed-fp32 terms of the Mie series cost downstream: TOA / surface fluxes, heating rates and the clean-minus-aerosol
     forcing of the mixed path against the fp64 path on the same 8-bin state."""
     st, ms = wa.synth_mosaic.make_mosaic_rows(64, 32, 40, 0, 32, nbin=8, seed=20260015, wrf_seed=20260012)
     ch = Chain(wa, sw_table_file, lw_table_file, st, ms)
@@ -208,10 +209,10 @@ def test_mixed_optics_flux_and_forcing_error_is_bounded(hip_lib, wa, sw_table_fi
     worst = {}
     for n in ("swupt", "swdnb", "swupb", "lwupt", "lwdnb"):
         worst[n] = np.abs(a[n] - b[n]).max()
-        assert worst[n] < 0.05, (n, worst[n])                       # W m-2 (fluxes are O(100-1000))
+        assert worst[n] < 0.005, (n, worst[n])                      # W m-2 (fluxes are O(100-1000))
     f_sw = np.abs((a["swuptcln"] - a["swupt"]) - (b["swuptcln"] - b["swupt"])).max()
     f_lw = np.abs((a["lwuptcln"] - a["lwupt"]) - (b["lwuptcln"] - b["lwupt"])).max()
-    assert f_sw < 0.05 and f_lw < 0.01, (f_sw, f_lw)                # forcing is O(1-50) W m-2
-    assert 86400.0 * np.abs(a["rthratensw"] - b["rthratensw"])[:, :40].max() < 5e-3    # K/day
-    assert 86400.0 * np.abs(a["rthratenlw"] - b["rthratenlw"])[:, :40].max() < 5e-3
+    assert f_sw < 0.005 and f_lw < 0.001, (f_sw, f_lw)              # forcing is O(1-50) W m-2
+    assert 86400.0 * np.abs(a["rthratensw"] - b["rthratensw"])[:, :40].max() < 2e-3    # K/day
+    assert 86400.0 * np.abs(a["rthratenlw"] - b["rthratenlw"])[:, :40].max() < 2e-3
     assert max(worst.values()) > 0.0                                # the two paths are different arithmetic

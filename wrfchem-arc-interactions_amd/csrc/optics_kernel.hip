@@ -19,6 +19,7 @@
 // (cell, wavelength pair / band pair).  Compute-bound (fp64 VALU): ~10^5 flop per cell against
 // 0.6 KB of tracer data.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cmath>
 
@@ -39,12 +40,12 @@ __constant__ double2 c_gw[OPT_NMIE + 10];
 // everything of term n that depends on n alone, one 64-byte record per term: the term number is wave-uniform, so the
 // record is one scalar load and its fields are scalar operands of the lanes' arithmetic (formed per lane they cost
 // three conversions and as many multiply-adds per term)
-struct MieN { double en, tnm1, w2, gx, gy, pad_[3]; };   // n, 2n - 1, 2n + 1, the two asymmetry weights
+struct MieN { double en, tnm1, w2, gx, gy; float fen, ftn, fw2, fgx, fgy, pad_; };   // n, 2n - 1, 2n + 1, the two asymmetry weights; the same in fp32 (mixed path)
 __constant__ MieN c_mn[OPT_NMIE + 10];
 __device__ __forceinline__ MieN mie_n(int n, double2 gw)   // the same from n (folds where n is a compile-time constant)
 {
     const double en = (double)n;
-    return MieN{en, 2. * en - 1., 2. * en + 1., gw.x, gw.y, {0., 0., 0.}};
+    return MieN{en, 2. * en - 1., 2. * en + 1., gw.x, gw.y, (float)en, (float)(2. * en - 1.), (float)(2. * en + 1.), (float)gw.x, (float)gw.y, 0.f};
 }
 // per wavelength slot: pi / lambda (size parameter per um of diameter) and its cube root
 __constant__ double c_pil[2][OPT_NWAVE];
@@ -405,9 +406,7 @@ __device__ __forceinline__ void mie_sphere(double x, cplx m, double cbx, double2
 // kernels pack them into one register pair): the recurrences of D_n are serial chains of ~10 dependent fp64 operations
 // per step and the longwave series are short, so a single evaluation leaves the SIMD waiting on its own results; two
 // independent chains in one instruction stream fill those gaps.  Register blocks of OPT_MB2 terms.
-constexpr int OPT_MB2 = 8, OPT_NCK2 = 8;   // the fp32 kernels keep 8 + 4 checkpoint slots per thread
-constexpr double OPT_XMAX32 = 47.0;   // x + 4 x^(1/3) + 2 < 64 = OPT_MB2 * OPT_NCK2
-constexpr int OPT_NCK32 = OPT_NCK2 + OPT_NCK2 / 2;   // LDS slots per thread of the fp32 pair
+constexpr int OPT_MB2 = 8;   // terms of the register-only ladder
 
 // ---- one particle in two neighbouring longwave bands, small size parameters (|mx| <= 4, at most OPT_MB2 terms) ----
 // Most longwave evaluations are of this kind (x = pi d / lambda with d <= 10 um and lambda >= 3 um).  The whole
@@ -551,13 +550,12 @@ __device__ __forceinline__ void mie_pair_su(double x1, cplx m1, double x2, cplx 
     qsca2 = f2 * A2.qs; qext2 = f2 * A2.qe;
 }
 
-// ---- single-precision pair (the "mixed" optics path: longwave bands in fp32, everything else fp64) ----
-// Same series, two changes that fp32 needs.  (1) psi_n(x) is carried upward by its recurrence only while n <= x
-// (the oscillatory range, where errors do not grow); beyond, psi_n = psi_{n-1} / (n/x + A_n(x)) with the logarithmic
-// derivative A_n of the real argument obtained by the same downward recurrence as D_n -- the plain recurrence
-// cancels catastrophically there (psi_1 = sin x / x - cos x is off by 5 % at x = 0.002 in fp32).  (2) a_n and b_n
-// take one reciprocal each (the product of their denominators overflows fp32).  Reciprocals are v_rcp_f32 (1 ulp).
-// Measured against the fp64 oracle over x = 0.0016 .. 40: absorption efficiency within 6e-5, median 2e-7.
+// ---- packed fp32 helpers of the mixed optics path (precision 1) ----
+// The first mixed kernels (rounds 1-2) ran the whole series in fp32: psi_n by its recurrence only while n <= x and as
+// psi_{n-1} / (n/x + A_n(x)) beyond (the plain recurrence cancels catastrophically: psi_1 = sin x / x - cos x is off by
+// 5 % at x = 0.002 in fp32), D_n and A_n downward through checkpoints and rebuilds.  Once the fp64 kernels carried D_n
+// upward they had caught up with that; the mixed path below keeps the two recurrences in fp64 instead.  a_n and b_n
+// take one reciprocal each (the product of their denominators overflows fp32); reciprocals are v_rcp_f32 (1 ulp).
 __device__ __forceinline__ float rcpf(float b) { return __builtin_amdgcn_rcpf(b); }
 // The two evaluations of a pair travel as the two components of packed fp32 values (v_pk_fma_f32 and friends
 // process both per instruction); complex numbers are (re, im) of such pairs.
@@ -573,39 +571,41 @@ __device__ __forceinline__ cplx2 crecip2(cplx2 a)
     const v2f r = rcp2(a.re * a.re + a.im * a.im);
     return {a.re * r, -a.im * r};
 }
-struct MieSetup32 {      // both evaluations of the pair
-    cplx2 m, yinv, minv;
-    v2f x, xinv;
-    int nstop1, nstop2, nmx;
-};
-__device__ __forceinline__ MieSetup32 mie_setup32(float x1, float m1re, float m1im, float x2, float m2re, float m2im)
+// ---- mixed path, round 3: psi_n -- and D_n where it is carried upward -- in fp64; chi_n, a_n, b_n and the sums as
+// packed fp32 pairs ----
+// The packed-fp32 series above pays for what fp32 cannot do: psi_n needs a second downward recurrence (A_n) beyond
+// n = x, and D_n goes downward from far above the series through checkpoints and rebuilds (the upward recurrence in
+// fp32 is off by up to 1e-3 for weakly absorbing particles, whose cot y runs close to its poles:
+// tools/probes/mie_mixed32.py).  Both recurrences are cheap in fp64 -- psi_n two operations per term, D_n upward
+// eleven -- while the forty-odd operations of a_n, b_n and the sums are where the packed arithmetic pays.  So the
+// recurrences that need the precision keep it and hand their values over by conversion; the small-argument ladder
+// D_1..D_8 (contracting downward recurrence) runs in packed fp32 from a start order that leaves 1e-8 of the start error.
+struct MiePsi2 { double a[2], b[2]; };   // psi_k of evaluation 1 / 2 in slot k & 1
+struct MieAccM { v2f pf[2], c[2], qs, qe, gs; cplx2 an[2], bn[2], xb; float sgn; };   // as MieAccF32; pf: psi_k rounded
+struct MiePairC { cplx2 m, minv; v2f xinv; double xinv1, xinv2; int nstop1, nstop2; };
+__device__ __forceinline__ cplx2 pack2(cplx a, cplx b) { return {v2f{(float)a.re, (float)b.re}, v2f{(float)a.im, (float)b.im}}; }
+__device__ __forceinline__ void mie_accM_start(MieAccM &A, MiePsi2 &P, double sn1, double cs1, double sn2, double cs2)
 {
-    MieSetup32 s;
-    s.x = v2f{x1, x2};
-    s.m = {v2f{m1re, m2re}, v2f{m1im, m2im}};
-    const cplx2 y = {s.x * s.m.re, s.x * s.m.im};
-    const v2f ymod2 = y.re * y.re + y.im * y.im;
-    const float ym1 = sqrtf(ymod2.x), ym2 = sqrtf(ymod2.y);
-    const float xs1 = s.x.x + 4.f * cbrtf(s.x.x) + 2.f, xs2 = s.x.y + 4.f * cbrtf(s.x.y) + 2.f;
-    s.nstop1 = (int)xs1; s.nstop2 = (int)xs2;
-    const float b1 = fmaxf(xs1, ym1), b2 = fmaxf(xs2, ym2);
-    const int n1 = (int)(b1 + (b1 > 8.f ? 8.f * cbrtf(b1) : 0.f)) + 16, n2 = (int)(b2 + (b2 > 8.f ? 8.f * cbrtf(b2) : 0.f)) + 16;
-    s.nmx = n1 > n2 ? n1 : n2;      // a higher start is only more accurate
-    s.yinv = crecip2(y);
-    s.minv = crecip2(s.m);
-    s.xinv = rcp2(s.x);
-    return s;
+    P.a[0] = sn1; P.a[1] = cs1; P.b[0] = sn2; P.b[1] = cs2;
+    const v2f zero = v2f{0.f, 0.f};
+    A.pf[0] = v2f{(float)sn1, (float)sn2}; A.pf[1] = v2f{(float)cs1, (float)cs2};
+    A.c[0] = A.pf[1]; A.c[1] = -A.pf[0];
+    A.qs = zero; A.qe = zero; A.gs = zero; A.sgn = -1.f;
+    A.an[0] = {zero, zero}; A.an[1] = {zero, zero}; A.bn[0] = {zero, zero}; A.bn[1] = {zero, zero}; A.xb = {zero, zero};
 }
-struct MieAcc32 { v2f p[2], c[2], qs, qe; };   // psi_k, chi_k in slot k & 1 (as MieAcc: no moves between terms), sums
-__device__ __forceinline__ void mie_term32(MieAcc32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
+template <bool FULL, bool BSC>
+__device__ __forceinline__ void mie_termM(MieAccM &A, MiePsi2 &P, const int n, const cplx2 D, const MiePairC &s, const MieN &K)
 {
-    const float en = (float)n;
-    const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
     const int par = n & 1;   // a constant after unrolling
-    const v2f p1 = A.p[par ^ 1], c1 = A.c[par ^ 1];
-    const v2f psi = sel2(en > s.x.x, en > s.x.y, p1 * rcp2(nx + An), up * p1 - A.p[par]);
+    const float en = K.fen;
+    const double ps1 = __builtin_fma(K.tnm1 * s.xinv1, P.a[par ^ 1], -P.a[par]);
+    const double ps2 = __builtin_fma(K.tnm1 * s.xinv2, P.b[par ^ 1], -P.b[par]);
+    P.a[par] = ps1; P.b[par] = ps2;
+    const v2f psi = v2f{(float)ps1, (float)ps2};
+    const v2f p1 = A.pf[par ^ 1], c1 = A.c[par ^ 1];
+    const v2f nx = en * s.xinv, up = K.ftn * s.xinv;
     const v2f chi = up * c1 - A.c[par];
-    A.p[par] = psi; A.c[par] = chi;
+    A.pf[par] = psi; A.c[par] = chi;
     const cplx2 xi = {psi, -chi}, xi1 = {p1, -c1};
     cplx2 t = cmul2(D, s.minv);
     t.re += nx;
@@ -614,68 +614,166 @@ __device__ __forceinline__ void mie_term32(MieAcc32 &A, int n, cplx2 D, v2f An, 
     t.re += nx;
     const cplx2 nb = {t.re * psi - p1, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
     const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
-    const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
-    const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
-    const float w2 = 2.f * en + 1.f;
+    const float w2 = K.fw2;
     const v2f zero = v2f{0.f, 0.f};
-    // an evaluation whose series has ended adds nothing
-    A.qs += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
-    A.qe += sel2(n <= s.nstop1, n <= s.nstop2, w2 * (an.re + bn.re), zero);
+    const bool on1 = n <= s.nstop1, on2 = n <= s.nstop2;   // an evaluation whose series has ended adds nothing
+    if (!FULL) {
+        const v2f are = (na.re * da.re + na.im * da.im) * ra, bre = (nb.re * db.re + nb.im * db.im) * rb;
+        const v2f a2 = (na.re * na.re + na.im * na.im) * ra, b2 = (nb.re * nb.re + nb.im * nb.im) * rb;
+        A.qs += sel2(on1, on2, w2 * (a2 + b2), zero);
+        A.qe += sel2(on1, on2, w2 * (are + bre), zero);
+    } else {
+        const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+        const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
+        A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
+        A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
+        v2f dg = K.fgx * (an.re * bn.re + an.im * bn.im);
+        if (n > 1) {
+            const cplx2 an1 = A.an[par ^ 1], bn1 = A.bn[par ^ 1];
+            dg += K.fgy * (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
+        }
+        A.gs += sel2(on1, on2, dg, zero);
+        if (BSC) {
+            A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
+            A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
+            A.sgn = -A.sgn;
+        }
+        A.an[par] = an; A.bn[par] = bn;
+    }
 }
-// register blocks of OPT_MB2 terms; checkpoints of D_n (both evaluations) in slots 0..NCK2-1 and of A_n (both, two
-// checkpoints per slot) in slots NCK2..NCK2+NCK2/2-1 of the thread's column: OPT_NCK32 slots of 16 bytes
-__device__ __forceinline__ void mie_pair32(const MieSetup32 &s, double2 *ck, float &qext1, float &qsca1,
-                                           float &qext2, float &qsca2)
+
+// Two shortwave wavelengths of a particle, both inside the window of the upward recurrence (mie_upward_ok): D_n of
+// both evaluations upward in fp64 from D_0 = cot y, handed to the packed-fp32 terms by conversion.  The series run to
+// the longer of the two; an evaluation past its own end adds nothing (mie_termM).
+template <bool BSC>
+__device__ __forceinline__ void mie_pairM_up(double x1, cplx m1, double cbx1, double x2, cplx m2, double cbx2,
+                                             double (&qext)[2], double (&qsca)[2], double (&gasy)[2], double (&qback)[2])
 {
-    const int nstopm = s.nstop1 > s.nstop2 ? s.nstop1 : s.nstop2;
-    const int nck = (nstopm + OPT_MB2 - 1) / OPT_MB2, ntop = nck * OPT_MB2;
-    cplx2 d = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-    v2f a = v2f{0.f, 0.f};
-    for (int n = s.nmx; n >= 2; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), A_{n-1} = n/x - 1/(A_n + n/x)
-        const float en = (float)n;
-        const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
-        d = csub2(ny, crecip2(cadd2(d, ny)));
-        const v2f nx = en * s.xinv;
-        a = nx - rcp2(a + nx);
-        const int n1 = n - 1;
-        if (n1 <= ntop && (n1 & (OPT_MB2 - 1)) == 0) {
-            const int j = n1 / OPT_MB2 - 1;
-            *reinterpret_cast<float4 *>(&ck[(size_t)j * OPT_THREADS]) = make_float4(d.re.x, d.re.y, d.im.x, d.im.y);
-            reinterpret_cast<float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1] = make_float2(a.x, a.y);
-        }
-        if (n1 <= OPT_MB2) break;
+    const cplx y1 = {x1 * m1.re, x1 * m1.im}, y2 = {x2 * m2.re, x2 * m2.im};
+    const cplx yinv1 = crecip(y1), yinv2 = crecip(y2);
+    MiePairC c;
+    c.nstop1 = (int)(x1 + 4. * cbx1 + 2.); c.nstop2 = (int)(x2 + 4. * cbx2 + 2.);
+    c.xinv1 = frcp(x1); c.xinv2 = frcp(x2);
+    c.xinv = v2f{(float)c.xinv1, (float)c.xinv2};
+    c.m = pack2(m1, m2); c.minv = pack2(crecip(m1), crecip(m2));
+    MieAccM A;
+    MiePsi2 P;
+    {
+        double sn1, cs1, sn2, cs2;
+        sincos_mid(x1, sn1, cs1);
+        sincos_mid(x2, sn2, cs2);
+        mie_accM_start(A, P, sn1, cs1, sn2, cs2);
     }
-    MieAcc32 A;
-    float sn1, cs1, sn2, cs2;
-    sincosf(s.x.x, &sn1, &cs1);
-    sincosf(s.x.y, &sn2, &cs2);
-    A.p[0] = v2f{sn1, sn2}; A.p[1] = v2f{cs1, cs2}; A.c[0] = A.p[1]; A.c[1] = -A.p[0];   // psi_0, psi_(-1), chi_0, chi_(-1)
-    A.qs = v2f{0.f, 0.f}; A.qe = v2f{0.f, 0.f};
-    for (int j = 0; j < nck; ++j) {
-        cplx2 dd[OPT_MB2];
-        v2f aa[OPT_MB2];
-        const float4 cd = *reinterpret_cast<const float4 *>(&ck[(size_t)j * OPT_THREADS]);
-        const float2 ca = reinterpret_cast<const float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1];
-        dd[OPT_MB2 - 1] = {v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};
-        aa[OPT_MB2 - 1] = v2f{ca.x, ca.y};
+    cplx d1 = ccot(y1), d2 = ccot(y2);
+    const int nstopm = c.nstop1 > c.nstop2 ? c.nstop1 : c.nstop2;
+    MieN kn[4], knn[4];
 #pragma unroll
-        for (int i = OPT_MB2 - 1; i >= 1; --i) {
-            const float en = (float)(j * OPT_MB2 + i + 1);
-            const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
-            dd[i - 1] = csub2(ny, crecip2(cadd2(dd[i], ny)));
-            const v2f nx = en * s.xinv;
-            aa[i - 1] = nx - rcp2(aa[i] + nx);
+    for (int i = 0; i < 4; ++i) kn[i] = c_mn[i + 1];
+    for (int n0 = 0; n0 < nstopm; n0 += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) knn[i] = c_mn[n0 + 5 + i];
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) {
+            const int n = n0 + i;
+            if (n <= nstopm) {
+                const double en = kn[i - 1].en;
+                const cplx ny1 = {en * yinv1.re, en * yinv1.im}, ny2 = {en * yinv2.re, en * yinv2.im};
+                d1 = csub(crecip(csub(ny1, d1)), ny1);
+                d2 = csub(crecip(csub(ny2, d2)), ny2);
+                mie_termM<true, BSC>(A, P, n, pack2(d1, d2), c, kn[i - 1]);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < OPT_MB2; ++i) {
-            const int n = j * OPT_MB2 + i + 1;
-            if (n <= nstopm) mie_term32(A, n, dd[i], aa[i], s);
+        for (int i = 0; i < 4; ++i) kn[i] = knn[i];
+    }
+    const double f1 = c.xinv1 * c.xinv1, f2 = c.xinv2 * c.xinv2;
+    qsca[0] = 2. * f1 * (double)A.qs.x; qsca[1] = 2. * f2 * (double)A.qs.y;
+    qext[0] = 2. * f1 * (double)A.qe.x; qext[1] = 2. * f2 * (double)A.qe.y;
+    gasy[0] = A.qs.x > 0.f ? (double)(2.f * A.gs.x * rcpf(A.qs.x)) : 0.;
+    gasy[1] = A.qs.y > 0.f ? (double)(2.f * A.gs.y * rcpf(A.qs.y)) : 0.;
+    const v2f xb2 = A.xb.re * A.xb.re + A.xb.im * A.xb.im;
+    qback[0] = BSC ? f1 * (double)xb2.x : 0.; qback[1] = BSC ? f2 * (double)xb2.y : 0.;
+}
+
+// The longwave pair of mie_pair_su in this arithmetic: every lane prepares its own source of D_n -- the packed-fp32
+// ladder (small) or D_0 = cot y carried upward in fp64 -- and the terms are taken in one pass.
+__device__ __forceinline__ void mie_pairM_su(double x1, cplx m1, double x2, cplx m2, const MieSetupS &s1,
+                                             const MieSetupS &s2, const bool small, double &qext1, double &qsca1,
+                                             double &qext2, double &qsca2)
+{
+    MiePairC c;
+    c.m = pack2(m1, m2); c.minv = pack2(s1.minv, s2.minv);
+    c.xinv = v2f{(float)s1.xinv, (float)s2.xinv}; c.xinv1 = s1.xinv; c.xinv2 = s2.xinv;
+    c.nstop1 = s1.nstop; c.nstop2 = s2.nstop;
+    const v2f zero = v2f{0.f, 0.f};
+    cplx2 dd[OPT_MB2];
+    cplx d1 = {0., 0.}, d2 = {0., 0.};
+    double sn1, cs1, sn2, cs2;
+    if (small) {
+        const cplx2 yinv = pack2(s1.yinv, s2.yinv);
+        // steps until the start error has contracted by 1e-8 (fp32): each contributes at least 2 ln((2 nstop + 3) / |y|)
+        const v2f ay = v2f{(float)(2 * s1.nstop + 3), (float)(2 * s2.nstop + 3)} *
+                       v2f{__builtin_amdgcn_sqrtf(yinv.re.x * yinv.re.x + yinv.im.x * yinv.im.x),
+                           __builtin_amdgcn_sqrtf(yinv.re.y * yinv.re.y + yinv.im.y * yinv.im.y)};
+        const int na = s1.nstop + (int)(9.25f * __builtin_amdgcn_rcpf(__logf(ay.x))) + 2;
+        const int nb = s2.nstop + (int)(9.25f * __builtin_amdgcn_rcpf(__logf(ay.y))) + 2;
+        const int nab = na > nb ? na : nb;
+        const int nstart = nab < OPT_MB2 + 1 ? OPT_MB2 + 1 : nab;
+        cplx2 d = {zero, zero};
+        for (int n = nstart; n > OPT_MB2 + 1; --n) {   // D_{n-1} = n/y - 1/(D_n + n/y), down to D_9
+            const float en = (float)n;
+            const cplx2 ny = {en * yinv.re, en * yinv.im};
+            d = csub2(ny, crecip2(cadd2(d, ny)));
+        }
+#pragma unroll
+        for (int i = OPT_MB2 - 1; i >= 0; --i) {       // dd[i] = D_{i+1}
+            const float en = (float)(i + 2);
+            const cplx2 ny = {en * yinv.re, en * yinv.im};
+            d = csub2(ny, crecip2(cadd2(d, ny)));
+            dd[i] = d;
+        }
+        sincos_small(x1, sn1, cs1);
+        sincos_small(x2, sn2, cs2);
+    } else {
+#pragma unroll
+        for (int i = 0; i < OPT_MB2; ++i) dd[i] = {zero, zero};
+        d1 = ccot({x1 * m1.re, x1 * m1.im});
+        d2 = ccot({x2 * m2.re, x2 * m2.im});
+        sincos_mid(x1, sn1, cs1);
+        sincos_mid(x2, sn2, cs2);
+    }
+    MieAccM A;
+    MiePsi2 P;
+    mie_accM_start(A, P, sn1, cs1, sn2, cs2);
+    const int nstopm = s1.nstop > s2.nstop ? s1.nstop : s2.nstop;
+#pragma unroll
+    for (int i = 0; i < OPT_MB2; ++i) {
+        const int n = i + 1;
+        cplx2 D = dd[i];
+        if (!small) {
+            const double en = (double)n;
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(crecip(csub(ny1, d1)), ny1);
+            d2 = csub(crecip(csub(ny2, d2)), ny2);
+            D = pack2(d1, d2);
+        }
+        if (n <= nstopm) mie_termM<false, false>(A, P, n, D, c, mie_n(n, make_double2(0., 0.)));
+    }
+    // beyond eight terms only upward lanes are left
+    for (int n0 = OPT_MB2; n0 < nstopm; n0 += 4) {
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) {
+            const int n = n0 + i;
+            const double en = (double)n;
+            const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
+            d1 = csub(crecip(csub(ny1, d1)), ny1);
+            d2 = csub(crecip(csub(ny2, d2)), ny2);
+            if (n <= nstopm) mie_termM<false, false>(A, P, n, pack2(d1, d2), c, c_mn[n]);
         }
     }
-    const v2f f = 2.f * s.xinv * s.xinv;
-    const v2f qs = f * A.qs, qe = f * A.qe;
-    qsca1 = qs.x; qext1 = qe.x;
-    qsca2 = qs.y; qext2 = qe.y;
+    const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
+    qsca1 = f1 * (double)A.qs.x; qext1 = f1 * (double)A.qe.x;
+    qsca2 = f2 * (double)A.qs.y; qext2 = f2 * (double)A.qe.y;
 }
 
 // refractive index of the internal mixture at wavelength slot w (volume average, or Maxwell-Garnett with BC inclusions)
@@ -723,7 +821,7 @@ __device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mi
 // badly: 1.7 of 3 waves per SIMD resident; wavelength-major order fixed that, 5.38 -> 4.19 ms per 1.6 M cells; per
 // cell: 3.94 ms.)  The downward fallback keeps 4 checkpoints per thread (segments of 64 terms).
 constexpr int OPT_NCK_SWC = 4;
-template <bool BSC>   // BSC: a backscatter output (bscoef) is requested
+template <bool BSC, bool MIXED = false>   // BSC: a backscatter output (bscoef) is requested; MIXED: wavelength pairs in mixed arithmetic (precision 1)
 __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
 {
     const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
@@ -772,21 +870,48 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
         const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for the four wavelengths
         const double dcm = dwet * 1.e-4;
         const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
-#pragma unroll 1
-        for (int w = 0; w < OPT_NSW; ++w) {
-            if (!((want >> w) & 1)) continue;
-            const cplx m = mix_index(vol, vwet, a.mix, w);
-            double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
-            const bool capped = x > OPT_XMAX;
-            x = capped ? OPT_XMAX : x;
-            const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
-            double qe, qs, g = 0., qb = 0.;
-            mie_sphere<true, OPT_NCK_SWC, BSC>(x, m, cbx, ck, qe, qs, g, qb);
+        auto add = [&](int w, double qe, double qs, double g, double qb) {
             double *s = acc + (size_t)(4 * w) * OPT_THREADS;
             s[0] += cross * qe;
             s[OPT_THREADS] += cross * qs;
             s[2 * OPT_THREADS] += cross * qs * g;
             s[3 * OPT_THREADS] += cross * qb * (0.25 / pi);
+        };
+        auto size_of = [&](int w, double &x, double &cbx) {
+            x = pi * dwet * frcp(c_opt.wavelength_um[w]);
+            const bool capped = x > OPT_XMAX;
+            x = capped ? OPT_XMAX : x;
+            cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
+        };
+        if (MIXED) {
+#pragma unroll 1
+            for (int w = 0; w < OPT_NSW; w += 2) {   // the output groups are complete or absent: a pair is wanted or not
+                if (!((want >> w) & 1)) continue;
+                const cplx m1 = mix_index(vol, vwet, a.mix, w), m2 = mix_index(vol, vwet, a.mix, w + 1);
+                double x1, cbx1, x2, cbx2;
+                size_of(w, x1, cbx1);
+                size_of(w + 1, x2, cbx2);
+                double qe[2], qs[2], g[2] = {0., 0.}, qb[2] = {0., 0.};
+                if (mie_upward_ok(x1, m1) && mie_upward_ok(x2, m2)) {
+                    mie_pairM_up<BSC>(x1, m1, cbx1, x2, m2, cbx2, qe, qs, g, qb);
+                } else {   // very small or strongly absorbing: the fp64 evaluation, one wavelength after the other
+                    mie_sphere<true, OPT_NCK_SWC, BSC>(x1, m1, cbx1, ck, qe[0], qs[0], g[0], qb[0]);
+                    mie_sphere<true, OPT_NCK_SWC, BSC>(x2, m2, cbx2, ck, qe[1], qs[1], g[1], qb[1]);
+                }
+                add(w, qe[0], qs[0], g[0], qb[0]);
+                add(w + 1, qe[1], qs[1], g[1], qb[1]);
+            }
+        } else {
+#pragma unroll 1
+            for (int w = 0; w < OPT_NSW; ++w) {
+                if (!((want >> w) & 1)) continue;
+                const cplx m = mix_index(vol, vwet, a.mix, w);
+                double x, cbx;
+                size_of(w, x, cbx);
+                double qe, qs, g = 0., qb = 0.;
+                mie_sphere<true, OPT_NCK_SWC, BSC>(x, m, cbx, ck, qe, qs, g, qb);
+                add(w, qe, qs, g, qb);
+            }
         }
     }
 #pragma unroll 1
@@ -807,93 +932,6 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
 // cube roots, the clipping rule) is formed once instead of once per band pair; the pairs follow in a loop, and the 32
 // running sums of the cell (extinction and scattering per band) live in the thread's LDS column, which a loop may
 // index -- in registers they cost an occupancy step (round 2's first per-cell kernel: 256 VGPRs + 100 AGPRs).
-__device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
-{
-    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
-    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
-    if (cell >= ncell) return;
-    unsigned want = 0;   // pairs with an output requested
-#pragma unroll
-    for (int p = 0; p < OPT_NLW / 2; ++p)
-        if (a.tauaerlw[2 * p] || a.extaerlw[2 * p] || a.tauaerlw[2 * p + 1] || a.extaerlw[2 * p + 1]) want |= 1u << p;
-    if (!want) return;
-    double2 *ck = s_ck + threadIdx.x;
-    double *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
-#pragma unroll
-    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = 0.;
-    const int it = (int)(cell % a.ni_t);
-    const long r = cell / a.ni_t;
-    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
-    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
-    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
-    const int r4 = a.real4;
-    const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
-    const double pi = 3.14159265358979323846;
-    for (int ib = 0; ib < a.nbin; ++ib) {
-        double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
-        double vdry = 0.;
-#pragma unroll
-        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
-            const int id = a.idx[ib][sp];
-            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
-            vol[sp] = mass * c_opt.rdens[sp];
-            if (sp != OS_WATER) vdry += vol[sp];
-        }
-        const int idn = a.idx[ib][OS_NUM];
-        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
-        if (!(vdry > 1.e-25)) continue;
-        const double vwet = vdry + vol[OS_WATER];
-        // dry diameter (um) from dry volume and number; clipped to the section, number follows (volume is kept)
-        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));   // cm3 per particle
-        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
-        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
-        if (ddry < dlo || ddry > dhi) {
-            ddry = ddry < dlo ? dlo : dhi;
-            const double dcm = ddry * 1.e-4;
-            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
-        }
-        const double dwet = ddry * cbrt(vwet * frcp(vdry));
-        const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for all bands
-        const double dcm = dwet * 1.e-4;
-        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
-#pragma unroll 1
-        for (int p = 0; p < OPT_NLW / 2; ++p) {
-            if (!((want >> p) & 1)) continue;
-            const int w = OPT_NSW + 2 * p, w2 = w + 1;
-            const cplx m = mix_index(vol, vwet, a.mix, w), mb = mix_index(vol, vwet, a.mix, w2);
-            double x = pi * dwet * frcp(c_opt.wavelength_um[w]), xb = pi * dwet * frcp(c_opt.wavelength_um[w2]);
-            x = x > OPT_XMAX ? OPT_XMAX : x;
-            xb = xb > OPT_XMAX ? OPT_XMAX : xb;
-            double qe, qs, qe2, qs2;
-            // the register-only small-size ladder or the upward recurrence, the particle's own choice (a wave with
-            // both kinds takes the terms in one pass, mie_pair_su): a cell's result does not depend on which cells
-            // share its wave, i.e. on the tiling of the domain
-            const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
-            const bool small = t1.small && t2.small;
-            if (small || (mie_upward_ok(x, m) && mie_upward_ok(xb, mb))) {
-                mie_pair_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
-            } else {   // strongly absorbing beyond any aerosol at these wavelengths: downward, one band after the other
-                const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
-                qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
-            }
-            double *s = acc + (size_t)(4 * p) * OPT_THREADS;
-            s[0] += cross * qe;
-            s[OPT_THREADS] += cross * qs;
-            s[2 * OPT_THREADS] += cross * qe2;
-            s[3 * OPT_THREADS] += cross * qs2;
-        }
-    }
-#pragma unroll 1
-    for (int ib = 0; ib < OPT_NLW; ++ib) {
-        const double ext = acc[(size_t)(2 * ib) * OPT_THREADS], sca = acc[(size_t)(2 * ib + 1) * OPT_THREADS];
-        const double ab = fmax(ext - sca, 0.);
-        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
-        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
-    }
-}
-
-// Mixed path, longwave band pair: the whole cell evaluation in fp32 (particle geometry, refractive index of the
-// mixture, Mie series); tracers are read and optical depths written in the arrays' own type.
 struct cf32 { float re, im; };
 __device__ __forceinline__ cf32 mix_index32(const float *vol, float vwet, int mix, int w)
 {
@@ -930,269 +968,103 @@ __device__ __forceinline__ cf32 mix_index32(const float *vol, float vwet, int mi
     return {re, e.im < 0.f ? -im : im};
 }
 
-// ---- mixed path, shortwave: two wavelengths of a particle as a packed fp32 pair, series up to nstop = 256 ----
-// 256 terms of D_n and A_n for two evaluations do not fit registers or LDS at 12 waves per CU, so only every 32nd
-// term is kept in LDS (OPT_NCK32 slots, as for the longwave pair) and each block of 8 terms is rebuilt from the
-// checkpoint above it: the chain is walked 2.5 times on average -- ~12 packed instructions per step against ~70 per
-// term of the series.  Asymmetry and backscatter sums as in mie_term<true>.
-constexpr int OPT_SB = 32;     // terms between checkpoints
-struct MieAccF32 { v2f p[2], c[2], qs, qe, gs; cplx2 an[2], bn[2], xb; float sgn; };   // slots by index parity
-__device__ __forceinline__ void mie_term32_full(MieAccF32 &A, int n, cplx2 D, v2f An, const MieSetup32 &s)
-{
-    const float en = (float)n;
-    const v2f nx = en * s.xinv, up = (2.f * en - 1.f) * s.xinv;
-    const int par = n & 1;   // a constant after unrolling
-    const v2f p1 = A.p[par ^ 1], c1 = A.c[par ^ 1];
-    const v2f psi = sel2(en > s.x.x, en > s.x.y, p1 * rcp2(nx + An), up * p1 - A.p[par]);
-    const v2f chi = up * c1 - A.c[par];
-    A.p[par] = psi; A.c[par] = chi;
-    const cplx2 xi = {psi, -chi}, xi1 = {p1, -c1};
-    cplx2 t = cmul2(D, s.minv);
-    t.re += nx;
-    const cplx2 na = {t.re * psi - p1, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
-    t = cmul2(s.m, D);
-    t.re += nx;
-    const cplx2 nb = {t.re * psi - p1, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
-    const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
-    const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
-    const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
-    const float w2 = 2.f * en + 1.f;
-    const v2f zero = v2f{0.f, 0.f};
-    const bool on1 = n <= s.nstop1, on2 = n <= s.nstop2;   // an evaluation whose series has ended adds nothing
-    A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
-    A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
-    v2f dg = (float)c_gw[n].x * (an.re * bn.re + an.im * bn.im);
-    if (n > 1) {
-        const cplx2 an1 = A.an[par ^ 1], bn1 = A.bn[par ^ 1];
-        dg += (float)c_gw[n].y * (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
-    }
-    A.gs += sel2(on1, on2, dg, zero);
-    A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
-    A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
-    A.sgn = -A.sgn;
-    A.an[par] = an; A.bn[par] = bn;
-}
-__device__ __forceinline__ void mie_pair32_full(const MieSetup32 &s, double2 *ck, v2f &qext, v2f &qsca, v2f &gasy, v2f &qback)
-{
-    const int nstopm = s.nstop1 > s.nstop2 ? s.nstop1 : s.nstop2;
-    const int nck = (nstopm + OPT_SB - 1) / OPT_SB, ntop = nck * OPT_SB;
-    auto step = [&](cplx2 &d, v2f &a, int n) {   // D_{n-1}, A_{n-1} from D_n, A_n
-        const float en = (float)n;
-        const cplx2 ny = {en * s.yinv.re, en * s.yinv.im};
-        d = csub2(ny, crecip2(cadd2(d, ny)));
-        const v2f nx = en * s.xinv;
-        a = nx - rcp2(a + nx);
-    };
-    {
-        cplx2 d = {v2f{0.f, 0.f}, v2f{0.f, 0.f}};
-        v2f a = v2f{0.f, 0.f};
-        // the start must lie above the highest checkpoint (a higher start is only more accurate)
-        const int nstart = s.nmx > ntop + 1 ? s.nmx : ntop + 1;
-        for (int n = nstart; n >= 2; --n) {
-            step(d, a, n);
-            const int n1 = n - 1;
-            if (n1 <= ntop && (n1 & (OPT_SB - 1)) == 0) {
-                const int j = n1 / OPT_SB - 1;
-                *reinterpret_cast<float4 *>(&ck[(size_t)j * OPT_THREADS]) = make_float4(d.re.x, d.re.y, d.im.x, d.im.y);
-                reinterpret_cast<float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1] = make_float2(a.x, a.y);
-            }
-            if (n1 <= OPT_SB) break;
-        }
-    }
-    MieAccF32 A;
-    float sn1, cs1, sn2, cs2;
-    sincosf(s.x.x, &sn1, &cs1);
-    sincosf(s.x.y, &sn2, &cs2);
-    const v2f zero = v2f{0.f, 0.f};
-    A.p[0] = v2f{sn1, sn2}; A.p[1] = v2f{cs1, cs2}; A.c[0] = A.p[1]; A.c[1] = -A.p[0];
-    A.qs = zero; A.qe = zero; A.gs = zero; A.sgn = -1.f;
-    A.an[0] = {zero, zero}; A.an[1] = {zero, zero}; A.bn[0] = {zero, zero}; A.bn[1] = {zero, zero}; A.xb = {zero, zero};
-    for (int j = 0; j < nck; ++j) {
-        const float4 cd = *reinterpret_cast<const float4 *>(&ck[(size_t)j * OPT_THREADS]);
-        const float2 ca = reinterpret_cast<const float2 *>(&ck[(size_t)(OPT_NCK2 + (j >> 1)) * OPT_THREADS])[j & 1];
-        for (int sub = 0; sub < OPT_SB / OPT_MB2; ++sub) {
-            const int nlo = j * OPT_SB + sub * OPT_MB2 + 1;      // first term of this block of OPT_MB2
-            if (nlo > nstopm) break;
-            cplx2 d = {v2f{cd.x, cd.y}, v2f{cd.z, cd.w}};        // D_{SB (j+1)}
-            v2f a = v2f{ca.x, ca.y};
-            for (int n = (j + 1) * OPT_SB; n > nlo + OPT_MB2 - 1; --n) step(d, a, n);   // walk down to the block's top
-            cplx2 dd[OPT_MB2];
-            v2f aa[OPT_MB2];
-            dd[OPT_MB2 - 1] = d; aa[OPT_MB2 - 1] = a;
-#pragma unroll
-            for (int i = OPT_MB2 - 1; i >= 1; --i) {
-                dd[i - 1] = dd[i]; aa[i - 1] = aa[i];
-                step(dd[i - 1], aa[i - 1], nlo + i);
-            }
-#pragma unroll
-            for (int i = 0; i < OPT_MB2; ++i)
-                if (nlo + i <= nstopm) mie_term32_full(A, nlo + i, dd[i], aa[i], s);
-        }
-    }
-    const v2f x2inv = s.xinv * s.xinv;
-    qsca = 2.f * x2inv * A.qs;
-    qext = 2.f * x2inv * A.qe;
-    gasy = v2f{A.qs.x > 0.f ? 2.f * A.gs.x * rcpf(A.qs.x) : 0.f, A.qs.y > 0.f ? 2.f * A.gs.y * rcpf(A.qs.y) : 0.f};
-    qback = x2inv * (A.xb.re * A.xb.re + A.xb.im * A.xb.im);
-}
-
-// particle geometry of one section in fp32; false: the section is empty
-__device__ __forceinline__ bool bin_geometry32(const OpticsKernelArgs &a, int ib, size_t q, size_t sspec, int r4,
-                                               float *vol, float &vwet, float &dwet, float &num)
-{
-    const float pi = 3.14159265358979323846f;
-    float vdry = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
-        const int id = a.idx[ib][sp];
-        const float mass = id >= 0 ? fmaxf((float)ldr(a.chem, (size_t)id * sspec + q, r4), 0.f) : 0.f;
-        vol[sp] = mass * rcpf((float)c_opt.dens[sp]);
-        if (sp != OS_WATER) vdry += vol[sp];
-    }
-    const int idn = a.idx[ib][OS_NUM];
-    num = idn >= 0 ? fmaxf((float)ldr(a.chem, (size_t)idn * sspec + q, r4), 0.f) : 0.f;
-    if (!(vdry > 1.e-25f)) return false;
-    vwet = vdry + vol[OS_WATER];
-    const float vpart = vdry * 1.e-6f * rcpf(fmaxf(num, 1.e-30f));   // cm3 per particle
-    float ddry = 1.e4f * cbrtf(vpart * (6.f / pi));
-    const float dlo = (float)c_opt.dlo_um[ib], dhi = (float)c_opt.dhi_um[ib];
-    if (ddry < dlo || ddry > dhi) {
-        ddry = ddry < dlo ? dlo : dhi;
-        const float dcm = ddry * 1.e-4f;
-        num = vdry * 1.e-6f * rcpf((pi / 6.f) * dcm * dcm * dcm);
-    }
-    dwet = ddry * cbrtf(vwet * rcpf(vdry));
-    return true;
-}
-
-__device__ __forceinline__ void optics_body_sw32(const OpticsKernelArgs &a, double2 *s_ck)
-{
-    constexpr int NW = OPT_NSW / 2;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, s = b >> 3;
-    // pair-major, as the fp64 kernel is wavelength-major: workgroups of equal duration next to each other
-    const int ng8 = (int)(gridDim.x >> 3) / NW;
-    const int slot = s / ng8, gl = s - slot * ng8;
-    const int w = 2 * slot, w2 = w + 1;
-    double2 *ck = s_ck + threadIdx.x;
-    const long cell = ((long)gl * 8 + xcd) * OPT_THREADS + threadIdx.x;
-    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
-    if (cell >= ncell) return;
-    if (!(a.tauaer[w] || a.extaer[w] || a.bscoef[w])) return;   // the groups are complete or absent
-    const int it = (int)(cell % a.ni_t);
-    const long r = cell / a.ni_t;
-    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
-    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
-    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
-    const int r4 = a.real4;
-    const float alt = (float)ldr(a.alt, q, r4), dz = (float)ldr(a.dz8w, q, r4);
-    const float pi = 3.14159265358979323846f;
-    const v2f rlam = v2f{rcpf((float)c_opt.wavelength_um[w]), rcpf((float)c_opt.wavelength_um[w2])};
-    const float ralt = rcpf(alt);
-    const v2f zero = v2f{0.f, 0.f};
-    v2f ext = zero, sca = zero, gsca = zero, bsc = zero;   // 1/cm (bsc: 1/(cm sr))
-    for (int ib = 0; ib < a.nbin; ++ib) {
-        float vol[OPT_NSPEC], vwet, dwet, num;
-        if (!bin_geometry32(a, ib, q, sspec, r4, vol, vwet, dwet, num)) continue;
-        const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
-        const float x1 = fminf(pi * dwet * rlam.x, (float)OPT_XMAX), x2 = fminf(pi * dwet * rlam.y, (float)OPT_XMAX);
-        const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
-        v2f qe, qs, g, qb;
-        mie_pair32_full(t12, ck, qe, qs, g, qb);
-        const float dcm = dwet * 1.e-4f;
-        const float cross = (num * ralt * 1.e-6f) * (0.25f * pi * dcm * dcm);   // #/cm3 * cm2
-        ext += cross * qe;
-        sca += cross * qs;
-        gsca += cross * qs * g;
-        bsc += (cross * (0.25f / pi)) * qb;
-    }
-    const float e2[2] = {ext.x, ext.y}, s2[2] = {sca.x, sca.y}, g2[2] = {gsca.x, gsca.y}, b2[2] = {bsc.x, bsc.y};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int ww = w + u;
-        if (a.tauaer[ww]) {
-            str(a.tauaer[ww], q, r4, (double)(e2[u] * 100.f * dz));
-            str(a.waer[ww], q, r4, (double)(e2[u] > 0.f ? s2[u] * rcpf(e2[u]) : 0.f));
-            str(a.gaer[ww], q, r4, (double)(s2[u] > 0.f ? g2[u] * rcpf(s2[u]) : 0.f));
-        }
-        if (a.extaer[ww]) str(a.extaer[ww], q, r4, (double)(e2[u] * 1.e5f));
-        if (a.bscoef[ww]) str(a.bscoef[ww], q, r4, (double)(b2[u] * 1.e5f));
-    }
-}
-
-// one thread = one cell, the eight band pairs in a loop, the cell's 32 running sums (fp32) in the thread's LDS column
-__device__ __forceinline__ void optics_body_lw32(const OpticsKernelArgs &a, double2 *s_ck, float *s_acc)
+template <bool MIXED>   // MIXED: the pair in the mixed arithmetic of mie_pairM_su (precision 1)
+__device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double2 *s_ck,
+                                               typename std::conditional<MIXED, float, double>::type *s_acc)
 {
     const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (cell >= ncell) return;
-    unsigned want = 0;
+    unsigned want = 0;   // pairs with an output requested
 #pragma unroll
     for (int p = 0; p < OPT_NLW / 2; ++p)
         if (a.tauaerlw[2 * p] || a.extaerlw[2 * p] || a.tauaerlw[2 * p + 1] || a.extaerlw[2 * p + 1]) want |= 1u << p;
     if (!want) return;
     double2 *ck = s_ck + threadIdx.x;
-    float *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
+    typedef typename std::conditional<MIXED, float, double>::type acc_t;   // the mixed path keeps its sums in fp32
+    acc_t *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
 #pragma unroll
-    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = 0.f;
+    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = (acc_t)0;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
     const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
     const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
     const int r4 = a.real4;
-    const float alt = (float)ldr(a.alt, q, r4), dz = (float)ldr(a.dz8w, q, r4);
-    const float pi = 3.14159265358979323846f;
-    const float ralt = rcpf(alt);
+    const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
+    const double pi = 3.14159265358979323846;
     for (int ib = 0; ib < a.nbin; ++ib) {
-        float vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
-        float vdry = 0.f;
+        double vol[OPT_NSPEC];   // 1e-6 cm3 per kg of dry air
+        double vdry = 0.;
 #pragma unroll
         for (int sp = 0; sp < OPT_NSPEC; ++sp) {
             const int id = a.idx[ib][sp];
-            const float mass = id >= 0 ? fmaxf((float)ldr(a.chem, (size_t)id * sspec + q, r4), 0.f) : 0.f;
-            vol[sp] = mass * rcpf((float)c_opt.dens[sp]);
+            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
+            vol[sp] = mass * c_opt.rdens[sp];
             if (sp != OS_WATER) vdry += vol[sp];
         }
         const int idn = a.idx[ib][OS_NUM];
-        float num = idn >= 0 ? fmaxf((float)ldr(a.chem, (size_t)idn * sspec + q, r4), 0.f) : 0.f;
-        if (!(vdry > 1.e-25f)) continue;
-        const float vwet = vdry + vol[OS_WATER];
-        const float vpart = vdry * 1.e-6f * rcpf(fmaxf(num, 1.e-30f));   // cm3 per particle
-        float ddry = 1.e4f * cbrtf(vpart * (6.f / pi));
-        const float dlo = (float)c_opt.dlo_um[ib], dhi = (float)c_opt.dhi_um[ib];
+        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
+        if (!(vdry > 1.e-25)) continue;
+        const double vwet = vdry + vol[OS_WATER];
+        // dry diameter (um) from dry volume and number; clipped to the section, number follows (volume is kept)
+        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));   // cm3 per particle
+        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
         if (ddry < dlo || ddry > dhi) {
             ddry = ddry < dlo ? dlo : dhi;
-            const float dcm = ddry * 1.e-4f;
-            num = vdry * 1.e-6f * rcpf((pi / 6.f) * dcm * dcm * dcm);
+            const double dcm = ddry * 1.e-4;
+            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
         }
-        const float dwet = ddry * cbrtf(vwet * rcpf(vdry));
-        const float dcm = dwet * 1.e-4f;
-        const float cross = (num * ralt * 1.e-6f) * (0.25f * pi * dcm * dcm);   // #/cm3 * cm2
+        const double dwet = ddry * cbrt(vwet * frcp(vdry));
+        const double cbd = cbrt(dwet);   // x^(1/3) = dwet^(1/3) (pi / lambda)^(1/3): one cube root for all bands
+        float volf[OPT_NSPEC];
+        if (MIXED) {
+#pragma unroll
+            for (int sp = 0; sp < OPT_NSPEC; ++sp) volf[sp] = (float)vol[sp];
+        }
+        const double dcm = dwet * 1.e-4;
+        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);   // #/cm3 * cm2
 #pragma unroll 1
         for (int p = 0; p < OPT_NLW / 2; ++p) {
             if (!((want >> p) & 1)) continue;
             const int w = OPT_NSW + 2 * p, w2 = w + 1;
-            const float rlam = rcpf((float)c_opt.wavelength_um[w]), rlam2 = rcpf((float)c_opt.wavelength_um[w2]);
-            const cf32 m1 = mix_index32(vol, vwet, a.mix, w), m2 = mix_index32(vol, vwet, a.mix, w2);
-            // size parameters capped so that the series fits the register blocks (nstop <= 64); no aerosol reaches
-            // x = 47 at wavelengths >= 3.3 um (diameter 50 um)
-            const float x1 = fminf(pi * dwet * rlam, (float)OPT_XMAX32), x2 = fminf(pi * dwet * rlam2, (float)OPT_XMAX32);
-            const MieSetup32 t12 = mie_setup32(x1, m1.re, m1.im, x2, m2.re, m2.im);
-            float qe, qs, qe2, qs2;
-            mie_pair32(t12, ck, qe, qs, qe2, qs2);
-            float *s = acc + (size_t)(4 * p) * OPT_THREADS;
-            s[0] += cross * qe;
-            s[OPT_THREADS] += cross * qs;
-            s[2 * OPT_THREADS] += cross * qe2;
-            s[3 * OPT_THREADS] += cross * qs2;
+            cplx m, mb;
+            if (MIXED) {   // the mixture's index from fp32 volumes: nine registers instead of eighteen across the band loop
+                const cf32 f1 = mix_index32(volf, (float)vwet, a.mix, w), f2 = mix_index32(volf, (float)vwet, a.mix, w2);
+                m = {(double)f1.re, (double)f1.im}; mb = {(double)f2.re, (double)f2.im};
+            } else {
+                m = mix_index(vol, vwet, a.mix, w); mb = mix_index(vol, vwet, a.mix, w2);
+            }
+            double x = pi * dwet * frcp(c_opt.wavelength_um[w]), xb = pi * dwet * frcp(c_opt.wavelength_um[w2]);
+            x = x > OPT_XMAX ? OPT_XMAX : x;
+            xb = xb > OPT_XMAX ? OPT_XMAX : xb;
+            double qe, qs, qe2, qs2;
+            // the register-only small-size ladder or the upward recurrence, the particle's own choice (a wave with
+            // both kinds takes the terms in one pass, mie_pair_su): a cell's result does not depend on which cells
+            // share its wave, i.e. on the tiling of the domain
+            const MieSetupS t1 = mie_setup_small(x, m, cbd * c_pil[1][w]), t2 = mie_setup_small(xb, mb, cbd * c_pil[1][w2]);
+            const bool small = t1.small && t2.small;
+            if (small || (mie_upward_ok(x, m) && mie_upward_ok(xb, mb))) {
+                if (MIXED) mie_pairM_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
+                else mie_pair_su(x, m, xb, mb, t1, t2, small, qe, qs, qe2, qs2);
+            } else {   // strongly absorbing beyond any aerosol at these wavelengths: downward, one band after the other
+                const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
+                qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
+            }
+            acc_t *s = acc + (size_t)(4 * p) * OPT_THREADS;
+            s[0] += (acc_t)(cross * qe);
+            s[OPT_THREADS] += (acc_t)(cross * qs);
+            s[2 * OPT_THREADS] += (acc_t)(cross * qe2);
+            s[3 * OPT_THREADS] += (acc_t)(cross * qs2);
         }
     }
 #pragma unroll 1
     for (int ib = 0; ib < OPT_NLW; ++ib) {
-        const float ab = fmaxf(acc[(size_t)(2 * ib) * OPT_THREADS] - acc[(size_t)(2 * ib + 1) * OPT_THREADS], 0.f);
-        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, (double)(ab * 100.f * dz));
-        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, (double)(ab * 1.e5f));
+        const double ext = (double)acc[(size_t)(2 * ib) * OPT_THREADS], sca = (double)acc[(size_t)(2 * ib + 1) * OPT_THREADS];
+        const double ab = fmax(ext - sca, 0.);
+        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
+        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
     }
 }
 
@@ -1215,21 +1087,28 @@ optics_lw_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK_LW * OPT_THREADS];
     __shared__ double s_acc[2 * OPT_NLW * OPT_THREADS];
-    optics_lw_cell(a, s_ck, s_acc);
+    optics_lw_cell<false>(a, s_ck, s_acc);
 }
-
-// the mixed-precision path: shortwave wavelength pairs and longwave band pairs in fp32
-__global__ void __launch_bounds__(OPT_THREADS) optics_sw32_kernel(const OpticsKernelArgs a)
+// mixed path: the shortwave cell loop over wavelength pairs in mixed arithmetic (with / without the backscatter sums)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_mix_kernel(const OpticsKernelArgs a)
 {
-    __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
-    optics_body_sw32(a, s_ck);
+    __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
+    __shared__ double s_acc[4 * OPT_NSW * OPT_THREADS];
+    optics_sw_cell<false, true>(a, s_ck, s_acc);
 }
-
-__global__ void __launch_bounds__(OPT_THREADS) optics_lw32_kernel(const OpticsKernelArgs a)
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_mix_bsc_kernel(const OpticsKernelArgs a)
 {
-    __shared__ double2 s_ck[OPT_NCK32 * OPT_THREADS];
+    __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
+    __shared__ double s_acc[4 * OPT_NSW * OPT_THREADS];
+    optics_sw_cell<true, true>(a, s_ck, s_acc);
+}
+// mixed path: the same cell loop with the pair in mixed arithmetic
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+optics_lw_mix_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double2 s_ck[OPT_NCK_LW * OPT_THREADS];
     __shared__ float s_acc[2 * OPT_NLW * OPT_THREADS];
-    optics_body_lw32(a, s_ck, s_acc);
+    optics_lw_cell<true>(a, s_ck, s_acc);
 }
 
 }  // namespace
@@ -1247,7 +1126,8 @@ hipError_t optics_upload_tables(const OpticsTables &t)
     static MieN mn[OPT_NMIE + 10];
     for (int n = 0; n < OPT_NMIE + 10; ++n) {
         const double en = (double)n;
-        mn[n] = MieN{en, 2. * en - 1., 2. * en + 1., gw[n].x, gw[n].y, {0., 0., 0.}};
+        mn[n] = MieN{en, 2. * en - 1., 2. * en + 1., gw[n].x, gw[n].y, (float)en, (float)(2. * en - 1.), (float)(2. * en + 1.),
+                     (float)gw[n].x, (float)gw[n].y, 0.f};
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_mn), mn, sizeof mn);
     if (e != hipSuccess) return e;
@@ -1265,28 +1145,22 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
 {
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
     if (ncell <= 0) return hipSuccess;
-    const long groups = (ncell + OPT_THREADS - 1) / OPT_THREADS;
-    const long groups8 = (groups + 7) / 8;
-    const long blocks = groups8 * 8 * OPT_NSW;   // the fp32 shortwave kernel: one workgroup per (cell group, wavelength pair)
-    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    if ((ncell + OPT_THREADS - 1) / OPT_THREADS > 0x7fffffffL) return hipErrorInvalidValue;
     // skip a kernel none of whose outputs were asked for
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
-    if (any_sw && precision == 1)
-        hipLaunchKernelGGL(optics_sw32_kernel, dim3((unsigned)(blocks / 2)), dim3(OPT_THREADS), 0, stream, a);
-    else if (any_sw) {   // one thread per cell; the backscatter sums only when a bscoef output is there
+    if (any_sw) {   // one thread per cell; the backscatter sums only when a bscoef output is there
         bool bsc = false;
         for (int w = 0; w < OPT_NSW; ++w) bsc = bsc || a.bscoef[w];
-        if (bsc)
-            hipLaunchKernelGGL(optics_bsc_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS),
-                               0, stream, a);
-        else
-            hipLaunchKernelGGL(optics_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
-                               stream, a);
+        const dim3 grid((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), wg(OPT_THREADS);
+        if (precision == 1 && bsc) hipLaunchKernelGGL(optics_mix_bsc_kernel, grid, wg, 0, stream, a);
+        else if (precision == 1) hipLaunchKernelGGL(optics_mix_kernel, grid, wg, 0, stream, a);
+        else if (bsc) hipLaunchKernelGGL(optics_bsc_kernel, grid, wg, 0, stream, a);
+        else hipLaunchKernelGGL(optics_kernel, grid, wg, 0, stream, a);
     }
     if (any_lw && precision == 1)
-        hipLaunchKernelGGL(optics_lw32_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+        hipLaunchKernelGGL(optics_lw_mix_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
                            stream, a);
     else if (any_lw)   // one thread per cell
         hipLaunchKernelGGL(optics_lw_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
