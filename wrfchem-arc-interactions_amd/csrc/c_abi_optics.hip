@@ -17,7 +17,7 @@ namespace {
 struct OpticsState {
     bool ready = false;
     int device = 0;
-    int precision = 0;       // 0 fp64, 1 longwave bands in fp32 (rrtmg_hip_optics_precision)
+    int precision = 0;       // 0 fp64, 1 mixed (rrtmg_hip_optics_precision)
     OpticsTables tab{};
 };
 OpticsState g_opt;
@@ -202,7 +202,7 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
 
 extern "C" int rrtmg_hip_optics_precision(int mode, char *err)
 {
-    if (mode != 0 && mode != 1) return failo(err, "rrtmg_hip_optics_precision: mode must be 0 (fp64) or 1 (longwave bands in fp32)");
+    if (mode != 0 && mode != 1) return failo(err, "rrtmg_hip_optics_precision: mode must be 0 (fp64) or 1 (mixed)");
     std::lock_guard<std::mutex> lock(g_opt_mutex);
     g_opt.precision = mode;
     return 0;

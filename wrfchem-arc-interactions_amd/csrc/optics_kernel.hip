@@ -42,6 +42,10 @@ __constant__ double2 c_gw[OPT_NMIE + 10];
 // three conversions and as many multiply-adds per term)
 struct MieN { double en, tnm1, w2, gx, gy; float fen, ftn, fw2, fgx, fgy, pad_; };   // n, 2n - 1, 2n + 1, the two asymmetry weights; the same in fp32 (mixed path)
 __constant__ MieN c_mn[OPT_NMIE + 10];
+// the same for the term pair (2q + 1, 2q + 2): the fp32 values as the two halves of packed operands
+struct MieN2 { double en0, en1, tn0, tn1; float fen[2], ftn[2], fw2[2], fgx[2], fgy[2], pad_[2]; };
+constexpr int OPT_NPAIR = (OPT_NMIE + 10) / 2;
+__constant__ MieN2 c_mp[OPT_NPAIR];
 __device__ __forceinline__ MieN mie_n(int n, double2 gw)   // the same from n (folds where n is a compile-time constant)
 {
     const double en = (double)n;
@@ -581,7 +585,7 @@ __device__ __forceinline__ cplx2 crecip2(cplx2 a)
 // recurrences that need the precision keep it and hand their values over by conversion; the small-argument ladder
 // D_1..D_8 (contracting downward recurrence) runs in packed fp32 from a start order that leaves 1e-8 of the start error.
 struct MiePsi2 { double a[2], b[2]; };   // psi_k of evaluation 1 / 2 in slot k & 1
-struct MieAccM { v2f pf[2], c[2], qs, qe, gs; cplx2 an[2], bn[2], xb; float sgn; };   // as MieAccF32; pf: psi_k rounded
+struct MieAccM { v2f pf[2], c[2], qs, qe; };   // pf: psi_k rounded, c: chi_k (slot k & 1); extinction and scattering sums
 struct MiePairC { cplx2 m, minv; v2f xinv; double xinv1, xinv2; int nstop1, nstop2; };
 __device__ __forceinline__ cplx2 pack2(cplx a, cplx b) { return {v2f{(float)a.re, (float)b.re}, v2f{(float)a.im, (float)b.im}}; }
 __device__ __forceinline__ void mie_accM_start(MieAccM &A, MiePsi2 &P, double sn1, double cs1, double sn2, double cs2)
@@ -590,10 +594,9 @@ __device__ __forceinline__ void mie_accM_start(MieAccM &A, MiePsi2 &P, double sn
     const v2f zero = v2f{0.f, 0.f};
     A.pf[0] = v2f{(float)sn1, (float)sn2}; A.pf[1] = v2f{(float)cs1, (float)cs2};
     A.c[0] = A.pf[1]; A.c[1] = -A.pf[0];
-    A.qs = zero; A.qe = zero; A.gs = zero; A.sgn = -1.f;
-    A.an[0] = {zero, zero}; A.an[1] = {zero, zero}; A.bn[0] = {zero, zero}; A.bn[1] = {zero, zero}; A.xb = {zero, zero};
+    A.qs = zero; A.qe = zero;
 }
-template <bool FULL, bool BSC>
+// extinction and scattering sums only (the longwave bands use absorption alone)
 __device__ __forceinline__ void mie_termM(MieAccM &A, MiePsi2 &P, const int n, const cplx2 D, const MiePairC &s, const MieN &K)
 {
     const int par = n & 1;   // a constant after unrolling
@@ -617,82 +620,114 @@ __device__ __forceinline__ void mie_termM(MieAccM &A, MiePsi2 &P, const int n, c
     const float w2 = K.fw2;
     const v2f zero = v2f{0.f, 0.f};
     const bool on1 = n <= s.nstop1, on2 = n <= s.nstop2;   // an evaluation whose series has ended adds nothing
-    if (!FULL) {
-        const v2f are = (na.re * da.re + na.im * da.im) * ra, bre = (nb.re * db.re + nb.im * db.im) * rb;
-        const v2f a2 = (na.re * na.re + na.im * na.im) * ra, b2 = (nb.re * nb.re + nb.im * nb.im) * rb;
-        A.qs += sel2(on1, on2, w2 * (a2 + b2), zero);
-        A.qe += sel2(on1, on2, w2 * (are + bre), zero);
-    } else {
-        const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
-        const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
-        A.qs += sel2(on1, on2, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
-        A.qe += sel2(on1, on2, w2 * (an.re + bn.re), zero);
-        v2f dg = K.fgx * (an.re * bn.re + an.im * bn.im);
-        if (n > 1) {
-            const cplx2 an1 = A.an[par ^ 1], bn1 = A.bn[par ^ 1];
-            dg += K.fgy * (an1.re * an.re + an1.im * an.im + bn1.re * bn.re + bn1.im * bn.im);
-        }
-        A.gs += sel2(on1, on2, dg, zero);
-        if (BSC) {
-            A.xb.re += sel2(on1, on2, (A.sgn * w2) * (an.re - bn.re), zero);
-            A.xb.im += sel2(on1, on2, (A.sgn * w2) * (an.im - bn.im), zero);
-            A.sgn = -A.sgn;
-        }
-        A.an[par] = an; A.bn[par] = bn;
-    }
+    // Re a_n and |a_n|^2 = |na|^2 / |da|^2 without forming a_n
+    const v2f are = (na.re * da.re + na.im * da.im) * ra, bre = (nb.re * db.re + nb.im * db.im) * rb;
+    const v2f a2 = (na.re * na.re + na.im * na.im) * ra, b2 = (nb.re * nb.re + nb.im * nb.im) * rb;
+    A.qs += sel2(on1, on2, w2 * (a2 + b2), zero);
+    A.qe += sel2(on1, on2, w2 * (are + bre), zero);
 }
 
-// Two shortwave wavelengths of a particle, both inside the window of the upward recurrence (mie_upward_ok): D_n of
-// both evaluations upward in fp64 from D_0 = cot y, handed to the packed-fp32 terms by conversion.  The series run to
-// the longer of the two; an evaluation past its own end adds nothing (mie_termM).
+// One evaluation with its terms taken TWO AT A TIME: terms n and n + 1 (n odd) are the two halves of the packed values.
+// Two wavelengths of a particle as the halves (built first: 13.1 ms against this function's 12.2 at one rank's share of
+// configs[4]) run to the longer of two series whose lengths differ by a third to two thirds -- a sixth of the packed
+// work is spent on an evaluation that has ended; two consecutive terms of ONE series waste at most half a step, and a
+// single evaluation's state needs fewer registers.  The recurrences (psi_n
+// and D_n in fp64, chi_n in fp32) advance two steps per packed step; the sums of the two halves are added at the end.
+struct MieAccT {
+    double p0, p1;      // psi_(n-2), psi_(n-1) on entry of a step
+    float c0, c1, pf;   // chi_(n-2), chi_(n-1); psi_(n-1) rounded
+    v2f qs, qe, gs;
+    cplx2 xb;
+    float anr, ani, bnr, bni;   // a_(n-1), b_(n-1)
+};
 template <bool BSC>
-__device__ __forceinline__ void mie_pairM_up(double x1, cplx m1, double cbx1, double x2, cplx m2, double cbx2,
-                                             double (&qext)[2], double (&qsca)[2], double (&gasy)[2], double (&qback)[2])
+__device__ __forceinline__ void mie_term2(MieAccT &A, cplx &d, const cplx yinv, const double xinv, const float xinvf,
+                                          const cplx2 m, const cplx2 minv, const int n, const int nstop, const MieN2 &K)
 {
-    const cplx y1 = {x1 * m1.re, x1 * m1.im}, y2 = {x2 * m2.re, x2 * m2.im};
-    const cplx yinv1 = crecip(y1), yinv2 = crecip(y2);
-    MiePairC c;
-    c.nstop1 = (int)(x1 + 4. * cbx1 + 2.); c.nstop2 = (int)(x2 + 4. * cbx2 + 2.);
-    c.xinv1 = frcp(x1); c.xinv2 = frcp(x2);
-    c.xinv = v2f{(float)c.xinv1, (float)c.xinv2};
-    c.m = pack2(m1, m2); c.minv = pack2(crecip(m1), crecip(m2));
-    MieAccM A;
-    MiePsi2 P;
+    // two steps of each recurrence
+    cplx ny = {K.en0 * yinv.re, K.en0 * yinv.im};
+    d = csub(crecip(csub(ny, d)), ny);
+    const cplx D0 = d;
+    ny = {K.en1 * yinv.re, K.en1 * yinv.im};
+    d = csub(crecip(csub(ny, d)), ny);
+    const double ps0 = __builtin_fma(K.tn0 * xinv, A.p1, -A.p0);
+    const double ps1 = __builtin_fma(K.tn1 * xinv, ps0, -A.p1);
+    A.p0 = ps0; A.p1 = ps1;
+    const v2f up = v2f{K.ftn[0], K.ftn[1]} * xinvf, nx = v2f{K.fen[0], K.fen[1]} * xinvf;
+    const float ch0 = up.x * A.c1 - A.c0;
+    const float ch1 = up.y * ch0 - A.c1;
+    const v2f psi = v2f{(float)ps0, (float)ps1}, p1 = v2f{A.pf, psi.x};
+    const v2f chi = v2f{ch0, ch1}, c1 = v2f{A.c1, ch0};
+    A.c0 = ch0; A.c1 = ch1; A.pf = psi.y;
+    const cplx2 D = pack2(D0, d);
+    const cplx2 xi = {psi, -chi}, xi1 = {p1, -c1};
+    cplx2 t = cmul2(D, minv);
+    t.re += nx;
+    const cplx2 na = {t.re * psi - p1, t.im * psi}, da = csub2(cmul2(t, xi), xi1);
+    t = cmul2(m, D);
+    t.re += nx;
+    const cplx2 nb = {t.re * psi - p1, t.im * psi}, db = csub2(cmul2(t, xi), xi1);
+    const v2f ra = rcp2(da.re * da.re + da.im * da.im), rb = rcp2(db.re * db.re + db.im * db.im);
+    const cplx2 an = {(na.re * da.re + na.im * da.im) * ra, (na.im * da.re - na.re * da.im) * ra};
+    const cplx2 bn = {(nb.re * db.re + nb.im * db.im) * rb, (nb.im * db.re - nb.re * db.im) * rb};
+    const v2f w2 = v2f{K.fw2[0], K.fw2[1]}, zero = v2f{0.f, 0.f};
+    const bool on1 = n + 1 <= nstop;   // (the caller has n <= nstop)
+    A.qs += sel2(true, on1, w2 * (an.re * an.re + an.im * an.im + bn.re * bn.re + bn.im * bn.im), zero);
+    A.qe += sel2(true, on1, w2 * (an.re + bn.re), zero);
+    // a_(n-1), b_(n-1) of the two halves: the previous step's upper half and this step's lower half
+    const cplx2 anp = {v2f{A.anr, an.re.x}, v2f{A.ani, an.im.x}}, bnp = {v2f{A.bnr, bn.re.x}, v2f{A.bni, bn.im.x}};
+    const v2f dg = v2f{K.fgx[0], K.fgx[1]} * (an.re * bn.re + an.im * bn.im) +
+                   v2f{K.fgy[0], K.fgy[1]} * (anp.re * an.re + anp.im * an.im + bnp.re * bn.re + bnp.im * bn.im);
+    A.gs += sel2(true, on1, dg, zero);
+    if (BSC) {   // (-1)^n (2n + 1) (a_n - b_n): n is odd
+        const v2f sw = v2f{-K.fw2[0], K.fw2[1]};
+        A.xb.re += sel2(true, on1, sw * (an.re - bn.re), zero);
+        A.xb.im += sel2(true, on1, sw * (an.im - bn.im), zero);
+    }
+    A.anr = an.re.y; A.ani = an.im.y; A.bnr = bn.re.y; A.bni = bn.im.y;
+}
+template <bool BSC>
+__device__ __forceinline__ void mie_sphereM_up(double x, cplx m, double cbx, double &qext, double &qsca, double &gasy,
+                                               double &qback)
+{
+    const cplx y = {x * m.re, x * m.im};
+    const int nstop = (int)(x + 4. * cbx + 2.);
+    const cplx yinv = crecip(y);
+    const double xinv = frcp(x);
+    const float xinvf = (float)xinv;
+    const cplx mi = crecip(m);
+    const cplx2 m2 = pack2(m, m), minv2 = pack2(mi, mi);
+    MieAccT A;
     {
-        double sn1, cs1, sn2, cs2;
-        sincos_mid(x1, sn1, cs1);
-        sincos_mid(x2, sn2, cs2);
-        mie_accM_start(A, P, sn1, cs1, sn2, cs2);
+        double sn, cs;
+        sincos_mid(x, sn, cs);
+        A.p0 = cs; A.p1 = sn;                        // psi_(-1), psi_0
+        A.c0 = -(float)sn; A.c1 = (float)cs;         // chi_(-1), chi_0
+        A.pf = (float)sn;
     }
-    cplx d1 = ccot(y1), d2 = ccot(y2);
-    const int nstopm = c.nstop1 > c.nstop2 ? c.nstop1 : c.nstop2;
-    MieN kn[4], knn[4];
+    const v2f zero = v2f{0.f, 0.f};
+    A.qs = zero; A.qe = zero; A.gs = zero; A.xb = {zero, zero};
+    A.anr = 0.f; A.ani = 0.f; A.bnr = 0.f; A.bni = 0.f;
+    cplx d = ccot(y);
+    // the records of the NEXT two steps are fetched while these two are evaluated
+    MieN2 kn[2], knn[2];
+    kn[0] = c_mp[0]; kn[1] = c_mp[1];
+    for (int n0 = 0; n0 < nstop; n0 += 4) {
+        knn[0] = c_mp[(n0 >> 1) + 2]; knn[1] = c_mp[(n0 >> 1) + 3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kn[i] = c_mn[i + 1];
-    for (int n0 = 0; n0 < nstopm; n0 += 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) knn[i] = c_mn[n0 + 5 + i];
-#pragma unroll
-        for (int i = 1; i <= 4; ++i) {
-            const int n = n0 + i;
-            if (n <= nstopm) {
-                const double en = kn[i - 1].en;
-                const cplx ny1 = {en * yinv1.re, en * yinv1.im}, ny2 = {en * yinv2.re, en * yinv2.im};
-                d1 = csub(crecip(csub(ny1, d1)), ny1);
-                d2 = csub(crecip(csub(ny2, d2)), ny2);
-                mie_termM<true, BSC>(A, P, n, pack2(d1, d2), c, kn[i - 1]);
-            }
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + 2 * i + 1;
+            if (n <= nstop) mie_term2<BSC>(A, d, yinv, xinv, xinvf, m2, minv2, n, nstop, kn[i]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kn[i] = knn[i];
+        kn[0] = knn[0]; kn[1] = knn[1];
     }
-    const double f1 = c.xinv1 * c.xinv1, f2 = c.xinv2 * c.xinv2;
-    qsca[0] = 2. * f1 * (double)A.qs.x; qsca[1] = 2. * f2 * (double)A.qs.y;
-    qext[0] = 2. * f1 * (double)A.qe.x; qext[1] = 2. * f2 * (double)A.qe.y;
-    gasy[0] = A.qs.x > 0.f ? (double)(2.f * A.gs.x * rcpf(A.qs.x)) : 0.;
-    gasy[1] = A.qs.y > 0.f ? (double)(2.f * A.gs.y * rcpf(A.qs.y)) : 0.;
-    const v2f xb2 = A.xb.re * A.xb.re + A.xb.im * A.xb.im;
-    qback[0] = BSC ? f1 * (double)xb2.x : 0.; qback[1] = BSC ? f2 * (double)xb2.y : 0.;
+    const double x2inv = xinv * xinv;
+    const float qs = A.qs.x + A.qs.y, qe = A.qe.x + A.qe.y, gs = A.gs.x + A.gs.y;
+    qsca = 2. * x2inv * (double)qs;
+    qext = 2. * x2inv * (double)qe;
+    gasy = qs > 0.f ? (double)(2.f * gs * rcpf(qs)) : 0.;
+    const float xr = A.xb.re.x + A.xb.re.y, xi = A.xb.im.x + A.xb.im.y;
+    qback = BSC ? x2inv * (double)(xr * xr + xi * xi) : 0.;
 }
 
 // The longwave pair of mie_pair_su in this arithmetic: every lane prepares its own source of D_n -- the packed-fp32
@@ -757,7 +792,7 @@ __device__ __forceinline__ void mie_pairM_su(double x1, cplx m1, double x2, cplx
             d2 = csub(crecip(csub(ny2, d2)), ny2);
             D = pack2(d1, d2);
         }
-        if (n <= nstopm) mie_termM<false, false>(A, P, n, D, c, mie_n(n, make_double2(0., 0.)));
+        if (n <= nstopm) mie_termM(A, P, n, D, c, mie_n(n, make_double2(0., 0.)));
     }
     // beyond eight terms only upward lanes are left
     for (int n0 = OPT_MB2; n0 < nstopm; n0 += 4) {
@@ -768,7 +803,7 @@ __device__ __forceinline__ void mie_pairM_su(double x1, cplx m1, double x2, cplx
             const cplx ny1 = {en * s1.yinv.re, en * s1.yinv.im}, ny2 = {en * s2.yinv.re, en * s2.yinv.im};
             d1 = csub(crecip(csub(ny1, d1)), ny1);
             d2 = csub(crecip(csub(ny2, d2)), ny2);
-            if (n <= nstopm) mie_termM<false, false>(A, P, n, pack2(d1, d2), c, c_mn[n]);
+            if (n <= nstopm) mie_termM(A, P, n, pack2(d1, d2), c, c_mn[n]);
         }
     }
     const double f1 = 2. * s1.xinv * s1.xinv, f2 = 2. * s2.xinv * s2.xinv;
@@ -821,7 +856,7 @@ __device__ __forceinline__ cplx mix_index(const double *vol, double vwet, int mi
 // badly: 1.7 of 3 waves per SIMD resident; wavelength-major order fixed that, 5.38 -> 4.19 ms per 1.6 M cells; per
 // cell: 3.94 ms.)  The downward fallback keeps 4 checkpoints per thread (segments of 64 terms).
 constexpr int OPT_NCK_SWC = 4;
-template <bool BSC, bool MIXED = false>   // BSC: a backscatter output (bscoef) is requested; MIXED: wavelength pairs in mixed arithmetic (precision 1)
+template <bool BSC, bool MIXED = false>   // BSC: a backscatter output (bscoef) is requested; MIXED: the series in mixed arithmetic (precision 1)
 __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double2 *s_ck, double *s_acc)
 {
     const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
@@ -885,21 +920,15 @@ __device__ __forceinline__ void optics_sw_cell(const OpticsKernelArgs &a, double
         };
         if (MIXED) {
 #pragma unroll 1
-            for (int w = 0; w < OPT_NSW; w += 2) {   // the output groups are complete or absent: a pair is wanted or not
+            for (int w = 0; w < OPT_NSW; ++w) {
                 if (!((want >> w) & 1)) continue;
-                const cplx m1 = mix_index(vol, vwet, a.mix, w), m2 = mix_index(vol, vwet, a.mix, w + 1);
-                double x1, cbx1, x2, cbx2;
-                size_of(w, x1, cbx1);
-                size_of(w + 1, x2, cbx2);
-                double qe[2], qs[2], g[2] = {0., 0.}, qb[2] = {0., 0.};
-                if (mie_upward_ok(x1, m1) && mie_upward_ok(x2, m2)) {
-                    mie_pairM_up<BSC>(x1, m1, cbx1, x2, m2, cbx2, qe, qs, g, qb);
-                } else {   // very small or strongly absorbing: the fp64 evaluation, one wavelength after the other
-                    mie_sphere<true, OPT_NCK_SWC, BSC>(x1, m1, cbx1, ck, qe[0], qs[0], g[0], qb[0]);
-                    mie_sphere<true, OPT_NCK_SWC, BSC>(x2, m2, cbx2, ck, qe[1], qs[1], g[1], qb[1]);
-                }
-                add(w, qe[0], qs[0], g[0], qb[0]);
-                add(w + 1, qe[1], qs[1], g[1], qb[1]);
+                const cplx m = mix_index(vol, vwet, a.mix, w);
+                double x, cbx;
+                size_of(w, x, cbx);
+                double qe, qs, g = 0., qb = 0.;
+                if (mie_upward_ok(x, m)) mie_sphereM_up<BSC>(x, m, cbx, qe, qs, g, qb);
+                else mie_sphere_down<true, OPT_NCK_SWC, BSC>(x, m, ck, qe, qs, g, qb);   // very small or strongly absorbing: fp64
+                add(w, qe, qs, g, qb);
             }
         } else {
 #pragma unroll 1
@@ -1089,7 +1118,7 @@ optics_lw_kernel(const OpticsKernelArgs a)
     __shared__ double s_acc[2 * OPT_NLW * OPT_THREADS];
     optics_lw_cell<false>(a, s_ck, s_acc);
 }
-// mixed path: the shortwave cell loop over wavelength pairs in mixed arithmetic (with / without the backscatter sums)
+// mixed path: the shortwave cell loop with the series in mixed arithmetic (with / without the backscatter sums)
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_mix_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
@@ -1130,6 +1159,13 @@ hipError_t optics_upload_tables(const OpticsTables &t)
                      (float)gw[n].x, (float)gw[n].y, 0.f};
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_mn), mn, sizeof mn);
+    if (e != hipSuccess) return e;
+    static MieN2 mp[OPT_NPAIR];
+    for (int q = 0; q < OPT_NPAIR; ++q) {
+        const MieN &a = mn[2 * q + 1], &b = mn[2 * q + 2 < OPT_NMIE + 10 ? 2 * q + 2 : 2 * q + 1];
+        mp[q] = MieN2{a.en, b.en, a.tnm1, b.tnm1, {a.fen, b.fen}, {a.ftn, b.ftn}, {a.fw2, b.fw2}, {a.fgx, b.fgx}, {a.fgy, b.fgy}, {0.f, 0.f}};
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_mp), mp, sizeof mp);
     if (e != hipSuccess) return e;
     double pil[2][OPT_NWAVE];
     for (int w = 0; w < OPT_NWAVE; ++w) {

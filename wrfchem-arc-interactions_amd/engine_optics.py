@@ -179,7 +179,8 @@ def modal_to_sections(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
 
 
 def optics_precision(mode):
-    """"f64" / 0: fp64 throughout (default); "mixed" / 1: the optical averaging in packed fp32 (BASELINE configs[4])."""
+    """"f64" / 0: fp64 throughout (default); "mixed" / 1: the coefficients and sums of the Mie series in packed fp32,
+    its recurrences in fp64 (BASELINE configs[4])."""
     m = {"f64": 0, "mixed": 1}.get(mode, mode)
     lib = _lib()
     lib.rrtmg_hip_optics_precision.argtypes = [C.c_int, C.c_char_p]
