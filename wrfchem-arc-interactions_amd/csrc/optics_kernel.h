@@ -7,7 +7,7 @@
 namespace rrtmg {
 
 hipError_t optics_upload_tables(const OpticsTables &t);
-// precision: 0 = fp64 throughout, 1 = longwave bands in fp32 ("mixed")
+// precision: 0 = fp64 throughout, 1 = "mixed" (fp64 recurrences, packed-fp32 coefficients and sums)
 hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int precision);
 
 }  // namespace rrtmg
