@@ -1011,9 +1011,9 @@ __device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double
     if (!want) return;
     double2 *ck = s_ck + threadIdx.x;
     typedef typename std::conditional<MIXED, float, double>::type acc_t;   // the mixed path keeps its sums in fp32
-    acc_t *acc = s_acc + threadIdx.x;   // [band][ext, sca][thread]
+    acc_t *acc = s_acc + threadIdx.x;   // [band][thread]: absorption = extinction - scattering, summed per particle
 #pragma unroll
-    for (int i = 0; i < 2 * OPT_NLW; ++i) acc[i * OPT_THREADS] = (acc_t)0;
+    for (int i = 0; i < OPT_NLW; ++i) acc[i * OPT_THREADS] = (acc_t)0;
     const int it = (int)(cell % a.ni_t);
     const long r = cell / a.ni_t;
     const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
@@ -1081,17 +1081,14 @@ __device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double
                 const MieQ2 q1 = mie_sphere_down_call(x, m, ck), q2 = mie_sphere_down_call(xb, mb, ck);
                 qe = q1.qext; qs = q1.qsca; qe2 = q2.qext; qs2 = q2.qsca;
             }
-            acc_t *s = acc + (size_t)(4 * p) * OPT_THREADS;
-            s[0] += (acc_t)(cross * qe);
-            s[OPT_THREADS] += (acc_t)(cross * qs);
-            s[2 * OPT_THREADS] += (acc_t)(cross * qe2);
-            s[3 * OPT_THREADS] += (acc_t)(cross * qs2);
+            acc_t *s = acc + (size_t)(2 * p) * OPT_THREADS;
+            s[0] += (acc_t)(cross * (qe - qs));
+            s[OPT_THREADS] += (acc_t)(cross * (qe2 - qs2));
         }
     }
 #pragma unroll 1
     for (int ib = 0; ib < OPT_NLW; ++ib) {
-        const double ext = (double)acc[(size_t)(2 * ib) * OPT_THREADS], sca = (double)acc[(size_t)(2 * ib + 1) * OPT_THREADS];
-        const double ab = fmax(ext - sca, 0.);
+        const double ab = fmax((double)acc[(size_t)ib * OPT_THREADS], 0.);
         if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
         if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
     }
@@ -1111,11 +1108,14 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
     optics_sw_cell<true>(a, s_ck, s_acc);
 }
 
-__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef OPT_LW_WAVES
+#define OPT_LW_WAVES 2
+#endif
+__global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(OPT_LW_WAVES, OPT_LW_WAVES)))
 optics_lw_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK_LW * OPT_THREADS];
-    __shared__ double s_acc[2 * OPT_NLW * OPT_THREADS];
+    __shared__ double s_acc[OPT_NLW * OPT_THREADS];
     optics_lw_cell<false>(a, s_ck, s_acc);
 }
 // mixed path: the shortwave cell loop with the series in mixed arithmetic (with / without the backscatter sums)
@@ -1136,7 +1136,7 @@ __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_e
 optics_lw_mix_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK_LW * OPT_THREADS];
-    __shared__ float s_acc[2 * OPT_NLW * OPT_THREADS];
+    __shared__ float s_acc[OPT_NLW * OPT_THREADS];
     optics_lw_cell<true>(a, s_ck, s_acc);
 }
 
