@@ -275,7 +275,8 @@ typedef struct rrtmg_hip_optics_args {
     int mem;
     void *stream;
     int aer_op_opt;           /* registry.chem:4014-4018: 1/3 volume mixing, 2/4 Maxwell-Garnett (BC inclusions);
-                                 every option evaluates Mie theory per cell; 5 (shell_exact) is refused */
+                                 5 shell_exact (black carbon as a concentric core, coated-sphere Mie theory);
+                                 every option evaluates Mie theory per cell */
     int num_chem;
     int idx[RRTMG_HIP_MAXBIN][RRTMG_HIP_AER_NSPEC];
     const void *chem;         /* (ims:ime, kms:kme, jms:jme, num_chem), ug/kg-dryair, number #/kg-dryair */
@@ -286,6 +287,11 @@ typedef struct rrtmg_hip_optics_args {
     void *extaer[4], *bscoef[4];                /* extinction 1/km, backscatter 1/(km sr) */
     void *tauaerlw[16];                         /* layer absorption optical depth per LW band */
     void *extaerlw[16];                         /* absorption coefficient 1/km */
+    /* cloud-borne aerosol (the "_cw" tracers of the aqueous packages, registry.chem:3935-3936): 1-based index of the
+     * cloud-borne counterpart of species s of bin b, 0 = none (the water slot is ignored).  Where given, cloud-borne
+     * mass and number are added to the interstitial ones before the particle geometry is formed.  All zero = the
+     * interstitial aerosol alone. */
+    int idx_cw[RRTMG_HIP_MAXBIN][RRTMG_HIP_AER_NSPEC];
 } rrtmg_hip_optics_args;
 
 int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *args, char *err);

@@ -89,6 +89,86 @@ void optics_oracle_mie(double x, double mre, double mim, double *out4)
     out4[3] = (creal(xb) * creal(xb) + cimag(xb) * cimag(xb)) / (x * x);   /* Qback */
 }
 
+#ifndef ORACLE_COUNT_FLOPS   /* (the counting build covers aer_op_opt = 1, what bench.py runs) */
+/* Coated sphere (aer_op_opt = 5, shell_exact, registry.chem:4018): a core of size parameter x and index m1 inside a
+ * sphere of size parameter y >= x whose shell has index m2.  Bohren & Huffman (1983) appendix B (BHCOAT): the shell
+ * replaces D_n(m y) of the homogeneous sphere by two effective logarithmic derivatives, one for a_n and one for b_n,
+ *     Da_n = (D_n(m2 y) - A_n chi_n'(m2 y)) / (1 - A_n chi_n(m2 y)),   Db_n likewise with B_n,
+ * where A_n, B_n carry the core (they vanish with it).  Differences from the textbook routine: the three logarithmic
+ * derivatives D_n(m1 x), D_n(m2 x), D_n(m2 y) come from the DOWNWARD recurrence with the start order of
+ * optics_oracle_mie (BHCOAT carries them upward from cot z, which loses all accuracy for n > |z|, i.e. for every small
+ * particle); the core terms are dropped for good once they fall below 1e-14 of D_n(m2 y) (BHCOAT: 1e-8), which is what
+ * keeps chi_n(m2 x) -- growing like (2n-1)!!/z^n -- inside the floating-point range; the asymmetry parameter is summed
+ * as in optics_oracle_mie. */
+static void log_derivative_down(cplx_t z, int nstop, double xstop, cplx_t *D /* [0..nstop] filled for n >= 1 */)
+{
+    const double base = fmax(xstop, cabs(z));
+    int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
+    cplx_t d = CPLX(0., 0.);
+    for (int n = nmx; n >= 2; --n) {
+        const cplx_t nz = (double)n / z;
+        d = nz - 1. / (d + nz);
+        if (n - 1 <= nstop) D[n - 1] = d;
+    }
+}
+void optics_oracle_mie_coated(double x, double y, double m1re, double m1im, double m2re, double m2im, double *out4)
+{
+    static _Thread_local cplx_t Dx1[NMIE + 8], Dx2[NMIE + 8], Dy2[NMIE + 8];
+    const cplx_t m1 = CPLX(m1re, m1im), m2 = CPLX(m2re, m2im);
+    const cplx_t x1 = x * m1, x2 = x * m2, y2 = y * m2, refrel = m2 / m1;
+    const double ystop = y + 4. * cbrt(y) + 2.;
+    const int nstop = (int)ystop;
+    log_derivative_down(x1, nstop, ystop, Dx1);
+    log_derivative_down(x2, nstop, ystop, Dx2);
+    log_derivative_down(y2, nstop, ystop, Dy2);
+    double psi0 = cos(y), psi1 = sin(y), chi0 = -sin(y), chi1 = cos(y);
+    cplx_t chi0x2 = -csin(x2), chi1x2 = ccos(x2), chi0y2 = -csin(y2), chi1y2 = ccos(y2);
+    cplx_t an1 = CPLX(0., 0.), bn1 = CPLX(0., 0.), xb = CPLX(0., 0.);
+    double qs = 0., qe = 0., gs = 0., sgn = -1.;
+    int core_gone = 0;
+    for (int n = 1; n <= nstop; ++n) {
+        const double en = (double)n;
+        const double psi = (2. * en - 1.) * psi1 / y - psi0;
+        const double chi = (2. * en - 1.) * chi1 / y - chi0;
+        const cplx_t xi = CPLX(psi, -chi), xi1 = CPLX(psi1, -chi1);
+        cplx_t da = Dy2[n], db = Dy2[n];
+        if (!core_gone) {
+            const cplx_t chix2 = (2. * en - 1.) * chi1x2 / x2 - chi0x2, chiy2 = (2. * en - 1.) * chi1y2 / y2 - chi0y2;
+            const cplx_t chipx2 = chi1x2 - en * chix2 / x2, chipy2 = chi1y2 - en * chiy2 / y2;
+            const cplx_t wx = chix2 * Dx2[n] - chipx2, wy = chiy2 * Dy2[n] - chipy2;
+            const cplx_t brack = (refrel * Dx1[n] - Dx2[n]) / (refrel * Dx1[n] * chix2 - chipx2) / wx * wy;
+            const cplx_t crack = (refrel * Dx2[n] - Dx1[n]) / (refrel * chipx2 - Dx1[n] * chix2) / wx * wy;
+            const double del = 1.e-14, dmod = cabs(Dy2[n]);
+            if (cabs(brack * chipy2) > del * dmod || cabs(brack * chiy2) > del || cabs(crack * chipy2) > del * dmod ||
+                cabs(crack * chiy2) > del) {
+                da = (Dy2[n] - brack * chipy2) / (1. - brack * chiy2);
+                db = (Dy2[n] - crack * chipy2) / (1. - crack * chiy2);
+                chi0x2 = chi1x2; chi1x2 = chix2; chi0y2 = chi1y2; chi1y2 = chiy2;
+            } else {
+                core_gone = 1;
+            }
+        }
+        const cplx_t ta = da / m2 + en / y, tb = m2 * db + en / y;
+        const cplx_t an = (ta * psi - psi1) / (ta * xi - xi1);
+        const cplx_t bn = (tb * psi - psi1) / (tb * xi - xi1);
+        qs += (2. * en + 1.) * (creal(an) * creal(an) + cimag(an) * cimag(an) + creal(bn) * creal(bn) + cimag(bn) * cimag(bn));
+        qe += (2. * en + 1.) * (creal(an) + creal(bn));
+        gs += ((2. * en + 1.) / (en * (en + 1.))) * (creal(an) * creal(bn) + cimag(an) * cimag(bn));
+        if (n > 1)
+            gs += ((en - 1.) * (en + 1.) / en) *
+                  (creal(an1) * creal(an) + cimag(an1) * cimag(an) + creal(bn1) * creal(bn) + cimag(bn1) * cimag(bn));
+        xb += (sgn * (2. * en + 1.)) * (an - bn);
+        sgn = -sgn;
+        psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
+        an1 = an; bn1 = bn;
+    }
+    out4[0] = 2. * qe / (y * y);
+    out4[1] = 2. * qs / (y * y);
+    out4[2] = qs > 0. ? 2. * gs / qs : 0.;
+    out4[3] = (creal(xb) * creal(xb) + cimag(xb) * cimag(xb)) / (y * y);
+}
+#endif
+
 typedef struct optics_oracle_tables {
     double refr[NSPEC][NWAVE], refi[NSPEC][NWAVE];
     double dens[NSPEC];
@@ -125,10 +205,12 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
             cplx_t m;
             double sr = 0., si = 0.;
             for (int s = 0; s < NSPEC; ++s) {
-                if (mix == 1 && s == S_BC) continue;
+                if (mix >= 1 && s == S_BC) continue;
                 sr += vol[s] * t->refr[s][w];
                 si += vol[s] * t->refi[s][w];
             }
+            double xcore = 0.;      /* mix 2: size parameter of the black-carbon core, 0 = homogeneous sphere of index m */
+            cplx_t mcore = CPLX(0., 0.);
             if (mix == 0) {
                 m = CPLX(sr, si) / vwet;
             } else {
@@ -138,16 +220,23 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
                 else {
                     const cplx_t mm = CPLX(sr, si) / vmat;
                     if (!(vbc > 0.)) m = mm;
-                    else {
+                    else if (mix == 1) {
                         const double f = vbc / vwet;
                         const cplx_t em = mm * mm, ei = mbc * mbc;
                         m = csqrt(em * (ei + 2. * em + 2. * f * (ei - em)) / (ei + 2. * em - f * (ei - em)));
+                    } else {   /* shell_exact: black carbon as a concentric core, everything else (volume-mixed) around it */
+                        m = mm; mcore = mbc;
+                        xcore = cbrt(vbc / vwet);   /* times x below */
                     }
                 }
             }
             double x = pi * dwet / t->wavelength_um[w];
             if (x > XMAX) x = XMAX;
             double q[4];
+#ifndef ORACLE_COUNT_FLOPS
+            if (xcore > 0.) optics_oracle_mie_coated(xcore * x, x, creal(mcore), cimag(mcore), creal(m), cimag(m), q);
+            else
+#endif
             optics_oracle_mie(x, creal(m), cimag(m), q);
             const double dcm = dwet * 1.e-4;
             const double cross = (num / alt * 1.e-6) * (0.25 * pi * dcm * dcm);

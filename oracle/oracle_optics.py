@@ -24,6 +24,7 @@ def _lib():
     l = _baselib()
     if not getattr(l, "_optics_ready", False):
         l.optics_oracle_mie.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        l.optics_oracle_mie_coated.argtypes = [C.c_double] * 6 + [dp]
         l.optics_oracle_cell.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, dp, dp]
         l.optics_oracle_tile.argtypes = [C.c_void_p, C.c_int] + [C.c_int] * 9 + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp]
         l._optics_ready = True
@@ -34,6 +35,15 @@ def mie(x, m):
     """(Qext, Qsca, g, Qback) of a homogeneous sphere; m = n + ik with k >= 0."""
     out = np.zeros(4)
     _lib().optics_oracle_mie(float(x), float(np.real(m)), float(np.imag(m)), out.ctypes.data_as(dp))
+    return tuple(out)
+
+
+def mie_coated(x, y, m1, m2):
+    """(Qext, Qsca, g, Qback), referred to the outer radius, of a sphere of size parameter y and shell index m2 around
+    a core of size parameter x <= y and index m1."""
+    out = np.zeros(4)
+    _lib().optics_oracle_mie_coated(float(x), float(y), float(np.real(m1)), float(np.imag(m1)), float(np.real(m2)),
+                                    float(np.imag(m2)), out.ctypes.data_as(dp))
     return tuple(out)
 
 

@@ -26,7 +26,7 @@ def run_oracle_optics(wa, st, ms, tile=None, mix=0):
     return oo.tile(oracle_tables(wa, ms.nbin), ms.chem, ms.alt, ms.dz8w, ms.idx, optics_dims(st, tile), mix=mix)
 
 
-def run_hip_optics(wa, st, ms, device=True, real_bytes=8, tile=None, aer_op_opt=1, names=None):
+def run_hip_optics(wa, st, ms, device=True, real_bytes=8, tile=None, aer_op_opt=1, names=None, idx_cw=None):
     dt = np.float64 if real_bytes == 8 else np.float32
     names = SW_NAMES + LW_NAMES if names is None else names
     shape = ms.alt.shape
@@ -39,10 +39,10 @@ def run_hip_optics(wa, st, ms, device=True, real_bytes=8, tile=None, aer_op_opt=
         import torch
         dev_in = {n: torch.from_numpy(v).cuda() for n, v in host_in.items()}
         dev_out = {n: torch.from_numpy(v).cuda() for n, v in outs.items()}
-        eo.optical_averaging(idx=ms.idx, aer_op_opt=aer_op_opt, **d, **dev_in, **dev_out)
+        eo.optical_averaging(idx=ms.idx, idx_cw=idx_cw, aer_op_opt=aer_op_opt, **d, **dev_in, **dev_out)
         torch.cuda.synchronize()
         return {n: v.cpu().numpy().astype(np.float64) for n, v in dev_out.items()}
-    eo.optical_averaging(idx=ms.idx, aer_op_opt=aer_op_opt, **d, **host_in, **outs)
+    eo.optical_averaging(idx=ms.idx, idx_cw=idx_cw, aer_op_opt=aer_op_opt, **d, **host_in, **outs)
     return {n: v.astype(np.float64) for n, v in outs.items()}
 
 

@@ -32,13 +32,17 @@ def _compare(got, ref, mask, rtol, atol=1e-30):
     return worst
 
 
-@pytest.mark.parametrize("nbin,ni,nj,nk,opt", [(4, 9, 5, 40, 1), (8, 6, 4, 30, 1), (4, 5, 3, 20, 2), (8, 4, 3, 12, 4)])
+MIX_OF = {1: 0, 3: 0, 2: 1, 4: 1, 5: 2}   # aer_op_opt (registry.chem:4014-4018) -> volume, Maxwell-Garnett, core + shell
+
+
+@pytest.mark.parametrize("nbin,ni,nj,nk,opt", [(4, 9, 5, 40, 1), (8, 6, 4, 30, 1), (4, 5, 3, 20, 2), (8, 4, 3, 12, 4),
+                                               (8, 5, 3, 14, 5), (4, 6, 2, 20, 5)])
 def test_optics_matches_oracle(hip_lib, wa, nbin, ni, nj, nk, opt):
     _init(wa, nbin)
     st = wa.synth.make_wrf_state(ni, nj, nk, seed=20260300 + nbin + nk)
     ms = wa.synth_mosaic.make_mosaic_state(st, nbin=nbin, seed=20260310 + nk)
     got = run_hip_optics(wa, st, ms, aer_op_opt=opt)
-    ref = run_oracle_optics(wa, st, ms, mix=1 if opt in (2, 4) else 0)
+    ref = run_oracle_optics(wa, st, ms, mix=MIX_OF[opt])
     mask = tile_mask(st, ms.alt.shape)
     _compare(got, ref, mask, RTOL)
     t2 = got["tauaer2"][mask]
@@ -130,7 +134,7 @@ def test_optics_strong_absorbers_take_the_downward_path(hip_lib, wa):
         w = names.index(f"water_a{b:02d}")
         ms.chem[w][:, :, ::2] *= 0.05
     mask = tile_mask(st, ms.alt.shape)
-    for opt, mix in ((1, 0), (2, 1)):
+    for opt, mix in ((1, 0), (2, 1), (5, 2)):
         got = run_hip_optics(wa, st, ms, aer_op_opt=opt)
         ref = run_oracle_optics(wa, st, ms, mix=mix)
         _compare(got, ref, mask, RTOL)
@@ -194,8 +198,8 @@ def test_optics_groups_and_refusals(hip_lib, wa):
         np.testing.assert_array_equal(only_lw[n], full[n])
     with pytest.raises(wa.engine.WrfFatal, match="complete or not at all"):
         run_hip_optics(wa, st, ms, names=["tauaer1", "waer1", "gaer1"])
-    with pytest.raises(wa.engine.WrfFatal, match="shell_exact"):
-        run_hip_optics(wa, st, ms, aer_op_opt=5)
+    with pytest.raises(wa.engine.WrfFatal, match="aer_op_opt must be 1..5"):
+        run_hip_optics(wa, st, ms, aer_op_opt=6)
 
 
 def test_optics_feed_the_radiation(hip_lib, wa, sw_table_file, sw_oracle):
@@ -294,3 +298,84 @@ def test_optics_mixed_precision(hip_lib, wa):
     again = run_hip_optics(wa, st, ms)
     for n in SW_NAMES + LW_NAMES:
         np.testing.assert_array_equal(again[n], ref64[n], err_msg=n)          # switching back restores fp64
+
+
+def test_shell_exact_core_and_shell(hip_lib, wa):
+    """aer_op_opt = 5 (shell_exact): black carbon as a concentric core.  Without black carbon the particle is the
+    homogeneous sphere of the volume-mixing rule; with black carbon the result differs from both mixing rules and absorbs; host arrays (mem = 0) give the device-resident result; the mixed precision mode does not touch it."""
+    _init(wa, 8)
+    st = wa.synth.make_wrf_state(6, 4, 12, seed=20260390)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260391)
+    mask = tile_mask(st, ms.alt.shape)
+    shell = run_hip_optics(wa, st, ms, aer_op_opt=5)
+    vol, mg = run_hip_optics(wa, st, ms, aer_op_opt=1), run_hip_optics(wa, st, ms, aer_op_opt=2)
+    for other in (vol, mg):
+        d = np.abs(shell["waer2"][mask] - other["waer2"][mask])
+        assert d.max() > 1e-4
+    assert (shell["waer2"][mask] < 1.0).all() and (shell["tauaerlw8"][mask] > 0).all()
+    host = run_hip_optics(wa, st, ms, aer_op_opt=5, device=False)
+    for n in shell:
+        np.testing.assert_array_equal(shell[n], host[n], err_msg=n)
+    try:
+        wa.engine_optics.optics_precision("mixed")
+        again = run_hip_optics(wa, st, ms, aer_op_opt=5)
+    finally:
+        wa.engine_optics.optics_precision("f64")
+    for n in shell:
+        np.testing.assert_array_equal(shell[n], again[n], err_msg=n)
+    # no black carbon anywhere: the shell is the whole particle
+    ms0 = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260391)
+    for i, nm in enumerate(ms0.names):
+        if nm.startswith("bc_"):
+            ms0.chem[i][...] = 0.0
+    a, b = run_hip_optics(wa, st, ms0, aer_op_opt=5), run_oracle_optics(wa, st, ms0, mix=0)
+    _compare(a, b, mask, RTOL)
+
+
+@pytest.mark.parametrize("real_bytes", [8, 4])
+def test_cloud_borne_tracers_are_added_to_the_interstitial_ones(hip_lib, wa, real_bytes):
+    """idx_cw (the "_cw" tracers of the aqueous packages, registry.chem:3935-3936): cloud-borne mass and number are
+    added to the interstitial ones before the particle geometry is formed -- the call equals, bit for bit, the call
+    on tracers summed beforehand in the arrays' own type; device-resident and host arrays alike; no idx_cw = before."""
+    import copy
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(7, 9, 10, seed=20260395)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260396)
+    dt = np.float64 if real_bytes == 8 else np.float32
+    nsp = ms.chem.shape[0]
+    rng = np.random.default_rng(20260397)
+    idx = np.asarray(ms.idx)
+    # cloud-borne copies of every dry species and of the number, appended behind the interstitial tracers
+    idx_cw = np.zeros_like(idx)
+    extra = []
+    for b in range(idx.shape[0]):
+        for s in range(idx.shape[1]):
+            if s == 8 or idx[b, s] == 0:      # no cloud-borne water
+                continue
+            frac = rng.uniform(0.0, 0.6, size=ms.chem.shape[1:]) * (rng.uniform(size=ms.chem.shape[1:]) < 0.5)
+            extra.append(ms.chem[idx[b, s] - 1] * frac)
+            idx_cw[b, s] = nsp + len(extra)
+    both = copy.copy(ms)
+    both.chem = np.concatenate([ms.chem, np.stack(extra)], axis=0)
+    summed = copy.copy(ms)
+    chem = np.ascontiguousarray(both.chem, dtype=dt)
+    tot = chem[:nsp].copy()
+    for b in range(idx.shape[0]):
+        for s in range(idx.shape[1]):
+            if idx_cw[b, s]:
+                tot[idx[b, s] - 1] = chem[idx[b, s] - 1] + chem[idx_cw[b, s] - 1]
+    summed.chem = tot
+    ref = run_hip_optics(wa, st, summed, real_bytes=real_bytes)
+    plain = run_hip_optics(wa, st, ms, real_bytes=real_bytes)
+    assert np.abs(ref["tauaer2"] - plain["tauaer2"]).max() > 0
+    for device in (True, False):
+        got = run_hip_optics(wa, st, both, real_bytes=real_bytes, idx_cw=idx_cw, device=device)
+        for n in got:
+            np.testing.assert_array_equal(got[n], ref[n], err_msg=f"{n} device={device}")
+        none = run_hip_optics(wa, st, both, real_bytes=real_bytes, device=device)
+        for n in none:
+            np.testing.assert_array_equal(none[n], plain[n], err_msg=n)
+    with pytest.raises(wa.engine.WrfFatal, match="cloud-borne species index"):
+        bad = idx_cw.copy()
+        bad[0, 0] = both.chem.shape[0] + 1
+        run_hip_optics(wa, st, both, idx_cw=bad)

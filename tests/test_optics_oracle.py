@@ -167,3 +167,64 @@ def test_upward_recurrence_window(oo):
     bad = m.imag * x > 40.0
     rel = np.abs(dn[1] - up[1])[bad] / np.abs(dn[1][bad])
     assert np.nanmax(np.where(np.isfinite(rel), rel, 1.0)) > 1e-6
+
+
+# ---- coated sphere (aer_op_opt = 5, shell_exact) ----
+def test_coated_sphere_bohren_huffman_appendix_b_case(oo):
+    """The example printed with BHCOAT (Bohren & Huffman 1983, appendix B): core radius 0.171 um, n = 1.59 + 0.66i; total
+    radius 6.265 um, shell n = 1.409 + 0.1747i; wavelength 3 um -> QEXT 2.32803, QSCA 1.14341, QBACK 2.85099e-2."""
+    k = 2.0 * np.pi / 3.0
+    qext, qsca, g, qback = oo.mie_coated(k * 0.171, k * 6.265, 1.59 + 0.66j, 1.409 + 0.1747j)
+    assert abs(qext - 2.32803) < 6e-6 and abs(qsca - 1.14341) < 6e-6 and abs(qback - 2.85099e-2) < 6e-8
+    assert 0.0 < g < 1.0
+
+
+def _coated_scipy(x, y, m1, m2, nmax):
+    """Aden & Kerker's coefficients (Bohren & Huffman eq. 8.2) straight from spherical Bessel functions."""
+    from scipy.special import spherical_jn, spherical_yn
+    n = np.arange(1, nmax + 1)
+
+    def rb(z):   # psi, psi', chi, chi' with chi = -z y_n(z)
+        j, dj, yy, dy = spherical_jn(n, z), spherical_jn(n, z, derivative=True), spherical_yn(n, z), spherical_yn(n, z, derivative=True)
+        return z * j, j + z * dj, -z * yy, -(yy + z * dy)
+
+    p1, dp1, _, _ = rb(m1 * x)
+    p2, dp2, c2, dc2 = rb(m2 * x)
+    py, dpy, cy, dcy = rb(m2 * y)
+    pv, dpv, cv, dcv = rb(y + 0j)
+    xi, dxi = pv - 1j * cv, dpv - 1j * dcv
+    A = (m2 * p2 * dp1 - m1 * dp2 * p1) / (m2 * c2 * dp1 - m1 * dc2 * p1)
+    B = (m2 * p1 * dp2 - m1 * p2 * dp1) / (m2 * dc2 * p1 - m1 * dp1 * c2)
+    a = (pv * (dpy - A * dcy) - m2 * dpv * (py - A * cy)) / (xi * (dpy - A * dcy) - m2 * dxi * (py - A * cy))
+    b = (m2 * pv * (dpy - B * dcy) - dpv * (py - B * cy)) / (m2 * xi * (dpy - B * dcy) - dxi * (py - B * cy))
+    qext = 2.0 / y**2 * np.sum((2 * n + 1) * (a + b).real)
+    qsca = 2.0 / y**2 * np.sum((2 * n + 1) * (abs(a) ** 2 + abs(b) ** 2))
+    gs = np.sum(n[:-1] * (n[:-1] + 2) / (n[:-1] + 1) * (a[:-1] * a[1:].conj() + b[:-1] * b[1:].conj()).real)
+    gs += np.sum((2 * n + 1) / (n * (n + 1)) * (a * b.conj()).real)
+    return qext, qsca, 4.0 / y**2 * gs / qsca
+
+
+@pytest.mark.parametrize("x,y,m1,m2", [(0.3, 0.5, 1.85 + 0.71j, 1.45 + 1e-3j), (1.0, 2.5, 1.85 + 0.71j, 1.33 + 1e-8j),
+                                       (2.0, 8.0, 1.95 + 0.79j, 1.53 + 0.02j), (0.02, 0.05, 1.85 + 0.71j, 1.5 + 0.1j),
+                                       (7.0, 8.0, 1.85 + 0.71j, 1.4 + 0.0j), (0.5, 12.0, 1.85 + 0.71j, 1.33 + 1e-6j)])
+def test_coated_sphere_against_scipy_formulation(oo, x, y, m1, m2):
+    nmax = int(y + 4.0 * y ** (1.0 / 3.0) + 2.0)
+    ref = _coated_scipy(x, y, complex(m1), complex(m2), nmax)
+    got = oo.mie_coated(x, y, m1, m2)
+    for g, r in zip(got[:3], ref):
+        assert abs(g - r) <= 2e-9 * abs(r), (got, ref)
+
+
+def test_coated_sphere_limits(oo):
+    """Equal indices, a vanishing core and a vanishing shell give the homogeneous sphere; an absorbing core lowers the
+    single-scattering albedo of a weakly absorbing particle."""
+    for x, y, m in [(0.5, 1.0, 1.5 + 0.01j), (3.0, 10.0, 1.33 + 1e-6j), (0.001, 0.002, 1.8 + 0.7j), (20.0, 100.0, 1.5 + 1e-3j)]:
+        a, b = oo.mie_coated(x, y, m, m), oo.mie(y, m)
+        assert max(abs(p - q) for p, q in zip(a, b)) <= 1e-12 * max(abs(q) for q in b)
+    a, b = oo.mie_coated(1e-6, 5.0, 1.85 + 0.71j, 1.5 + 0.01j), oo.mie(5.0, 1.5 + 0.01j)
+    assert max(abs(p - q) / abs(q) for p, q in zip(a, b)) < 1e-12
+    a, b = oo.mie_coated(5.0 * (1 - 1e-12), 5.0, 1.85 + 0.71j, 1.5 + 0.01j), oo.mie(5.0, 1.85 + 0.71j)
+    assert max(abs(p - q) / abs(q) for p, q in zip(a, b)) < 1e-10
+    qe0, qs0, _, _ = oo.mie(2.0, 1.45 + 1e-6j)
+    qe1, qs1, _, _ = oo.mie_coated(1.0, 2.0, 1.85 + 0.71j, 1.45 + 1e-6j)
+    assert qs1 / qe1 < 0.9 < qs0 / qe0

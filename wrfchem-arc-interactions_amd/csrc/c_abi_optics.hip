@@ -109,8 +109,8 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
 {
     if (!g_opt.ready) return failo(err, "rrtmg_hip_optical_averaging: rrtmg_hip_optics_init has not been called");
     if (a->real_bytes != 4 && a->real_bytes != 8) return failo(err, "rrtmg_hip_optical_averaging: real_bytes must be 4 or 8");
-    if (a->aer_op_opt < 1 || a->aer_op_opt > 4)
-        return failo(err, "rrtmg_hip_optical_averaging: aer_op_opt must be 1..4 (5 = shell_exact is not implemented)");
+    if (a->aer_op_opt < 1 || a->aer_op_opt > 5)
+        return failo(err, "rrtmg_hip_optical_averaging: aer_op_opt must be 1..5 (registry.chem:4014-4018)");
     const int ni_m = a->ime - a->ims + 1, nk_m = a->kme - a->kms + 1, nj_m = a->jme - a->jms + 1;
     const int ni_t = a->ite - a->its + 1, nj_t = a->jte - a->jts + 1, nk_t = a->kte - a->kts + 1;
     if (ni_t <= 0 || nj_t <= 0) return 0;   // an empty tile: the reference's i/j loops do not execute
@@ -126,6 +126,17 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
             const int id = b < nbin ? a->idx[b][s] : 0;
             if (id < 0 || id > a->num_chem) return failo(err, "rrtmg_hip_optical_averaging: species index outside 1..num_chem");
             k.idx[b][s] = id - 1;
+        }
+    // cloud-borne counterparts (optional): combined with the interstitial tracers by a pre-pass, so that the Mie kernels
+    // see one set of tracers and stay as they are
+    int cw[OPT_MAXBIN][OPT_NSLOT];
+    bool any_cw = false;
+    for (int b = 0; b < OPT_MAXBIN; ++b)
+        for (int s = 0; s < OPT_NSLOT; ++s) {
+            const int id = (b < nbin && s != OS_WATER) ? a->idx_cw[b][s] : 0;
+            if (id < 0 || id > a->num_chem) return failo(err, "rrtmg_hip_optical_averaging: cloud-borne species index outside 1..num_chem");
+            cw[b][s] = id - 1;
+            any_cw = any_cw || id > 0;
         }
     auto group = [](void *const *p, int n) {
         int cnt = 0;
@@ -144,7 +155,7 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
     k.i0 = a->its - a->ims; k.k0 = a->kts - a->kms; k.j0 = a->jts - a->jms;
     k.ni_t = ni_t; k.nk_t = nk_t; k.nj_t = nj_t;
     k.real4 = a->real_bytes == 4;
-    k.mix = (a->aer_op_opt == 2 || a->aer_op_opt == 4) ? 1 : 0;
+    k.mix = a->aer_op_opt == 5 ? 2 : ((a->aer_op_opt == 2 || a->aer_op_opt == 4) ? 1 : 0);   // volume, Maxwell-Garnett, core + shell
     k.nbin = nbin;
     // mem = 0: tile-only staging through this thread's buffers (tile_staging.h); of the tracer array only the span of
     // species the sections use travels (MOSAIC's aerosol tracers are contiguous in the Registry)
@@ -160,11 +171,14 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
         int lo = a->num_chem, hi = -1;
         for (int b = 0; b < nbin; ++b)
             for (int sp = 0; sp < OPT_NSLOT; ++sp)
-                if (k.idx[b][sp] >= 0) { lo = k.idx[b][sp] < lo ? k.idx[b][sp] : lo; hi = k.idx[b][sp] > hi ? k.idx[b][sp] : hi; }
+                for (const int id : {k.idx[b][sp], cw[b][sp]})
+                    if (id >= 0) { lo = id < lo ? id : lo; hi = id > hi ? id : hi; }
         if (hi < lo) { lo = 0; hi = 0; }
         for (int b = 0; b < nbin; ++b)
-            for (int sp = 0; sp < OPT_NSLOT; ++sp)
+            for (int sp = 0; sp < OPT_NSLOT; ++sp) {
                 if (k.idx[b][sp] >= 0) k.idx[b][sp] -= lo;
+                if (cw[b][sp] >= 0) cw[b][sp] -= lo;
+            }
         k.ni_m = ni_t; k.nj_m = nj_t; k.i0 = 0; k.j0 = 0;   // packed arrays: memory = tile (k unchanged)
         const size_t sspec = (size_t)ni_m * nk_m * nj_m * a->real_bytes;
         stg.in(static_cast<const char *>(a->chem) + (size_t)lo * sspec, nk_m, hi - lo + 1, &k.chem);
@@ -190,7 +204,22 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
             HIPCHK(stg.stage(c));
             k.nj_m = k.nj_t = stg.chunk_nj(c);
         }
-        HIPCHK(optics_launch(k, stream, g_opt.precision));
+        if (any_cw) {
+            // stream-ordered temporary of nbin * 10 fields in the memory shape of this launch
+            const size_t ncell = (size_t)k.ni_m * k.nk_m * k.nj_m;
+            void *tmp = nullptr;
+            HIPCHK(hipMallocAsync(&tmp, (size_t)nbin * OPT_NSLOT * ncell * a->real_bytes, stream));
+            HIPCHK(optics_combine_cw(k.chem, tmp, k.idx, cw, nbin, ncell, k.real4, stream));
+            OpticsKernelArgs kc = k;
+            kc.chem = tmp;
+            for (int b = 0; b < OPT_MAXBIN; ++b)
+                for (int s = 0; s < OPT_NSLOT; ++s) kc.idx[b][s] = b < nbin ? b * OPT_NSLOT + s : -1;
+            const hipError_t e = optics_launch(kc, stream, g_opt.precision);
+            (void)hipFreeAsync(tmp, stream);
+            HIPCHK(e);
+        } else {
+            HIPCHK(optics_launch(k, stream, g_opt.precision));
+        }
         if (a->mem != 1) HIPCHK(stg.fetch(c));
     }
     if (a->mem != 1) {

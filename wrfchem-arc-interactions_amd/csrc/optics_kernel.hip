@@ -1094,6 +1094,236 @@ __device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double
     }
 }
 
+// ---- aer_op_opt = 5 (shell_exact, registry.chem:4018): black carbon as a concentric core ----
+// A core of size parameter x and index m1 inside a sphere of size parameter y and shell index m2 (everything but black
+// carbon, volume-mixed), after Bohren & Huffman (1983) appendix B: the shell replaces D_n(m y) of the homogeneous
+// sphere by two effective logarithmic derivatives, one for a_n and one for b_n,
+//     Da_n = (D_n(m2 y) - A_n chi_n'(m2 y)) / (1 - A_n chi_n(m2 y)),   Db_n likewise with B_n,
+// where A_n, B_n carry the core.  As in the oracle (oracle/optics_oracle.c: optics_oracle_mie_coated, pinned on the
+// published BHCOAT example and on Aden & Kerker's coefficients from scipy's Bessel functions) the three logarithmic
+// derivatives D_n(m1 x), D_n(m2 x), D_n(m2 y) come from the DOWNWARD recurrence -- carried upward from cot z, as the
+// textbook routine does, they lose all accuracy for n > |z|, i.e. for every small particle -- and the core terms are
+// dropped for good once they are below 1e-14 of D_n(m2 y), which keeps chi_n(m2 x) ~ (2n-1)!!/z^n inside the fp64 range.
+// The option is a diagnostic configuration, not the production path: its kernel keeps the three derivative ladders in
+// per-lane scratch arrays (12 KB per lane) instead of the checkpoint schemes above, and is a kernel of its own so that
+// the production kernels' register allocation is untouched.
+__device__ __forceinline__ cplx cdivc(cplx a, cplx b) { return cmul(a, crecip(b)); }
+__device__ __forceinline__ double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
+__device__ __forceinline__ void csincos(cplx z, cplx &sn, cplx &cs)
+{
+    double s, c;
+    sincos(z.re, &s, &c);
+    const double e = exp(z.im), ei = frcp(e);
+    const double ch = 0.5 * (e + ei), sh = 0.5 * (e - ei);
+    sn = {s * ch, c * sh};
+    cs = {c * ch, -s * sh};
+}
+__device__ __noinline__ void log_derivative_down(cplx z, int nstop, double xstop, cplx *D /* [1..nstop] */)
+{
+    const double base = fmax(xstop, sqrt(cabs2(z)));
+    const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
+    const cplx zinv = crecip(z);
+    cplx d = {0., 0.};
+    for (int n = nmx; n >= 2; --n) {
+        const double en = (double)n;
+        const cplx nz = {en * zinv.re, en * zinv.im};
+        d = csub(nz, crecip(cadd(d, nz)));
+        if (n - 1 <= nstop) D[n - 1] = d;
+    }
+}
+__device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, double cby, cplx *Dx1, cplx *Dx2, cplx *Dy2,
+                                        double &qext, double &qsca, double &gasy, double &qback)
+{
+    const cplx x1 = {x * m1.re, x * m1.im}, x2 = {x * m2.re, x * m2.im}, y2 = {y * m2.re, y * m2.im};
+    const cplx refrel = cdivc(m2, m1), m2inv = crecip(m2), x2inv = crecip(x2), y2inv = crecip(y2);
+    const double ystop = y + 4. * cby + 2.;
+    const int nstop = (int)ystop;
+    log_derivative_down(x1, nstop, ystop, Dx1);
+    log_derivative_down(x2, nstop, ystop, Dx2);
+    log_derivative_down(y2, nstop, ystop, Dy2);
+    MieAcc A;
+    {
+        double sn, cs;
+        sincos(y, &sn, &cs);
+        mie_acc_start(A, sn, cs);
+    }
+    cplx chi0x2, chi1x2, chi0y2, chi1y2;
+    {
+        cplx sn, cs;
+        csincos(x2, sn, cs);
+        chi0x2 = {-sn.re, -sn.im}; chi1x2 = cs;
+        csincos(y2, sn, cs);
+        chi0y2 = {-sn.re, -sn.im}; chi1y2 = cs;
+    }
+    const double yinv = frcp(y);
+    bool core_gone = false;
+    for (int n = 1; n <= nstop; ++n) {
+        const double en = (double)n, tn = 2. * en - 1.;
+        const cplx dy = Dy2[n];
+        cplx da = dy, db = dy;
+        if (!core_gone) {
+            const cplx dx1 = Dx1[n], dx2 = Dx2[n];
+            const cplx tx = {tn * x2inv.re, tn * x2inv.im}, ty = {tn * y2inv.re, tn * y2inv.im};
+            const cplx chix2 = csub(cmul(tx, chi1x2), chi0x2), chiy2 = csub(cmul(ty, chi1y2), chi0y2);
+            const cplx nx = {en * x2inv.re, en * x2inv.im}, ny = {en * y2inv.re, en * y2inv.im};
+            const cplx chipx2 = csub(chi1x2, cmul(nx, chix2)), chipy2 = csub(chi1y2, cmul(ny, chiy2));
+            const cplx wx = csub(cmul(chix2, dx2), chipx2), wy = csub(cmul(chiy2, dy), chipy2);
+            const cplx rd = cmul(refrel, dx1);
+            const cplx brack = cmul(cdivc(cdivc(csub(rd, dx2), csub(cmul(rd, chix2), chipx2)), wx), wy);
+            const cplx crack = cmul(cdivc(cdivc(csub(cmul(refrel, dx2), dx1), csub(cmul(refrel, chipx2), cmul(dx1, chix2))), wx), wy);
+            const double del2 = 1.e-28, dm2 = cabs2(dy);
+            if (cabs2(cmul(brack, chipy2)) > del2 * dm2 || cabs2(cmul(brack, chiy2)) > del2 ||
+                cabs2(cmul(crack, chipy2)) > del2 * dm2 || cabs2(cmul(crack, chiy2)) > del2) {
+                const cplx one = {1., 0.};
+                da = cdivc(csub(dy, cmul(brack, chipy2)), csub(one, cmul(brack, chiy2)));
+                db = cdivc(csub(dy, cmul(crack, chipy2)), csub(one, cmul(crack, chiy2)));
+                chi0x2 = chi1x2; chi1x2 = chix2; chi0y2 = chi1y2; chi1y2 = chiy2;
+            } else {
+                core_gone = true;
+            }
+        }
+        // the homogeneous sphere's term with Da_n in a_n and Db_n in b_n
+        const double nxr = en * yinv;
+        const double psi1 = A.psi[0], chi1 = A.chi[0];
+        const double psi = tn * yinv * psi1 - A.psi[1];
+        const double chi = tn * yinv * chi1 - A.chi[1];
+        A.psi[1] = psi1; A.psi[0] = psi; A.chi[1] = chi1; A.chi[0] = chi;
+        cplx t = cmul(da, m2inv);
+        t.re += nxr;
+        const cplx na = {t.re * psi - psi1, t.im * psi};
+        const cplx dna = {na.re + t.im * chi, na.im - (t.re * chi - chi1)};   // (t xi_n - xi_(n-1)), xi = psi - i chi
+        t = cmul(m2, db);
+        t.re += nxr;
+        const cplx nb = {t.re * psi - psi1, t.im * psi};
+        const cplx dnb = {nb.re + t.im * chi, nb.im - (t.re * chi - chi1)};
+        const cplx an = cdivc(na, dna), bn = cdivc(nb, dnb);
+        const double w2 = 2. * en + 1.;
+        A.qs += w2 * (cabs2(an) + cabs2(bn));
+        A.qe += w2 * (an.re + bn.re);
+        A.gs += (w2 / (en * (en + 1.))) * (an.re * bn.re + an.im * bn.im);
+        if (n > 1)
+            A.gs += ((en - 1.) * (en + 1.) / en) * (A.an[0].re * an.re + A.an[0].im * an.im + A.bn[0].re * bn.re + A.bn[0].im * bn.im);
+        A.xb.re += A.sgn * w2 * (an.re - bn.re);
+        A.xb.im += A.sgn * w2 * (an.im - bn.im);
+        A.sgn = -A.sgn;
+        A.an[0] = an; A.bn[0] = bn;
+    }
+    const double y2i = yinv * yinv;
+    qsca = 2. * y2i * A.qs;
+    qext = 2. * y2i * A.qe;
+    gasy = A.qs > 0. ? 2. * A.gs / A.qs : 0.;
+    qback = y2i * cabs2(A.xb);
+}
+
+// one thread per cell, all twenty wavelengths; the cell's 32 sums (4 x 4 shortwave, 16 longwave absorption) in LDS
+__global__ void __launch_bounds__(OPT_THREADS) optics_shell_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double s_acc[(4 * OPT_NSW + OPT_NLW) * OPT_THREADS];
+    __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
+    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
+    if (cell >= ncell) return;
+    unsigned want = 0;
+#pragma unroll
+    for (int w = 0; w < OPT_NSW; ++w)
+        if (a.tauaer[w] || a.extaer[w] || a.bscoef[w]) want |= 1u << w;
+#pragma unroll
+    for (int b = 0; b < OPT_NLW; ++b)
+        if (a.tauaerlw[b] || a.extaerlw[b]) want |= 1u << (OPT_NSW + b);
+    if (!want) return;
+    cplx Dx1[OPT_NMIE + 2], Dx2[OPT_NMIE + 2], Dy2[OPT_NMIE + 2];   // per-lane scratch
+    double *acc = s_acc + threadIdx.x;
+    double2 *ck = s_ck + threadIdx.x;
+    for (int i = 0; i < 4 * OPT_NSW + OPT_NLW; ++i) acc[i * OPT_THREADS] = 0.;
+    const int it = (int)(cell % a.ni_t);
+    const long r = cell / a.ni_t;
+    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
+    const int r4 = a.real4;
+    const double alt = ldr(a.alt, q, r4), dz = ldr(a.dz8w, q, r4);
+    const double pi = 3.14159265358979323846;
+    for (int ib = 0; ib < a.nbin; ++ib) {
+        double vol[OPT_NSPEC];
+        double vdry = 0.;
+#pragma unroll
+        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+            const int id = a.idx[ib][sp];
+            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
+            vol[sp] = mass * c_opt.rdens[sp];
+            if (sp != OS_WATER) vdry += vol[sp];
+        }
+        const int idn = a.idx[ib][OS_NUM];
+        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
+        if (!(vdry > 1.e-25)) continue;
+        const double vwet = vdry + vol[OS_WATER];
+        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));
+        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
+        if (ddry < dlo || ddry > dhi) {
+            ddry = ddry < dlo ? dlo : dhi;
+            const double dcm = ddry * 1.e-4;
+            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
+        }
+        const double dwet = ddry * cbrt(vwet * frcp(vdry));
+        const double cbd = cbrt(dwet);
+        const double dcm = dwet * 1.e-4;
+        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);
+        const double vbc = vol[OS_BC], vmat = vwet - vbc;
+        const double rcore = vbc > 0. ? cbrt(vbc * frcp(vwet)) : 0.;   // core radius / particle radius
+#pragma unroll 1
+        for (int w = 0; w < OPT_NWAVE; ++w) {
+            if (!((want >> w) & 1)) continue;
+            double sr = 0., si = 0.;
+#pragma unroll
+            for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+                if (sp == OS_BC) continue;
+                sr += vol[sp] * c_opt.refr[sp][w];
+                si += vol[sp] * c_opt.refi[sp][w];
+            }
+            const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
+            double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
+            const bool capped = x > OPT_XMAX;
+            x = capped ? OPT_XMAX : x;
+            const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
+            double qe, qs, g = 0., qb = 0.;
+            if (!(vmat > 1.e-30 * vwet)) {                  // nothing but black carbon
+                mie_sphere_down<true, OPT_NCK_SWC, true>(x, mbc, ck, qe, qs, g, qb);
+            } else {
+                const double vi = frcp(vmat);
+                const cplx mm = {sr * vi, si * vi};
+                if (!(vbc > 0.)) mie_sphere_down<true, OPT_NCK_SWC, true>(x, mm, ck, qe, qs, g, qb);   // no core
+                else mie_coated(rcore * x, x, mbc, mm, cbx, Dx1, Dx2, Dy2, qe, qs, g, qb);
+            }
+            if (w < OPT_NSW) {
+                double *s = acc + (size_t)(4 * w) * OPT_THREADS;
+                s[0] += cross * qe;
+                s[OPT_THREADS] += cross * qs;
+                s[2 * OPT_THREADS] += cross * qs * g;
+                s[3 * OPT_THREADS] += cross * qb * (0.25 / pi);
+            } else {
+                acc[(size_t)(4 * OPT_NSW + (w - OPT_NSW)) * OPT_THREADS] += cross * (qe - qs);
+            }
+        }
+    }
+    for (int w = 0; w < OPT_NSW; ++w) {
+        const double *s = acc + (size_t)(4 * w) * OPT_THREADS;
+        const double ext = s[0], sca = s[OPT_THREADS], gsca = s[2 * OPT_THREADS], bsc = s[3 * OPT_THREADS];
+        if (a.tauaer[w]) {
+            str(a.tauaer[w], q, r4, ext * 100. * dz);
+            str(a.waer[w], q, r4, ext > 0. ? sca * frcp(ext) : 0.);
+            str(a.gaer[w], q, r4, sca > 0. ? gsca * frcp(sca) : 0.);
+        }
+        if (a.extaer[w]) str(a.extaer[w], q, r4, ext * 1.e5);
+        if (a.bscoef[w]) str(a.bscoef[w], q, r4, bsc * 1.e5);
+    }
+    for (int ib = 0; ib < OPT_NLW; ++ib) {
+        const double ab = fmax(acc[(size_t)(4 * OPT_NSW + ib) * OPT_THREADS], 0.);
+        if (a.tauaerlw[ib]) str(a.tauaerlw[ib], q, r4, ab * 100. * dz);
+        if (a.extaerlw[ib]) str(a.extaerlw[ib], q, r4, ab * 1.e5);
+    }
+}
+
 __global__ void __launch_bounds__(OPT_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) optics_kernel(const OpticsKernelArgs a)
 {
     __shared__ double2 s_ck[OPT_NCK_SWC * OPT_THREADS];
@@ -1177,6 +1407,46 @@ hipError_t optics_upload_tables(const OpticsTables &t)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_opt), &t, sizeof(OpticsTables));
 }
 
+namespace {
+// interstitial + cloud-borne tracers of every (section, slot) into a compact array of nbin * 10 fields
+struct CombineArgs {
+    const void *chem;
+    void *out;
+    int ia[OPT_MAXBIN][OPT_NSLOT], ic[OPT_MAXBIN][OPT_NSLOT];   // species numbers in chem, -1 = absent
+    size_t ncell;
+    int nbin, real4;
+};
+__global__ void optics_combine_cw_kernel(const CombineArgs a)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.ncell) return;
+    for (int b = 0; b < a.nbin; ++b)
+        for (int s = 0; s < OPT_NSLOT; ++s) {
+            const int i = a.ia[b][s], c = a.ic[b][s];
+            const size_t o = (size_t)(b * OPT_NSLOT + s) * a.ncell + q;
+            if (a.real4) {
+                const float *p = static_cast<const float *>(a.chem);
+                static_cast<float *>(a.out)[o] = (i >= 0 ? p[(size_t)i * a.ncell + q] : 0.f) + (c >= 0 ? p[(size_t)c * a.ncell + q] : 0.f);
+            } else {
+                const double *p = static_cast<const double *>(a.chem);
+                static_cast<double *>(a.out)[o] = (i >= 0 ? p[(size_t)i * a.ncell + q] : 0.) + (c >= 0 ? p[(size_t)c * a.ncell + q] : 0.);
+            }
+        }
+}
+}  // namespace
+
+// out: nbin * 10 fields of ncell values in the tracers' type; field b * 10 + s = chem[ia[b][s]] + chem[ic[b][s]]
+hipError_t optics_combine_cw(const void *chem, void *out, const int (*ia)[OPT_NSLOT], const int (*ic)[OPT_NSLOT], int nbin,
+                             size_t ncell, int real4, hipStream_t stream)
+{
+    CombineArgs a{};
+    a.chem = chem; a.out = out; a.ncell = ncell; a.nbin = nbin; a.real4 = real4;
+    for (int b = 0; b < OPT_MAXBIN; ++b)
+        for (int s = 0; s < OPT_NSLOT; ++s) { a.ia[b][s] = ia[b][s]; a.ic[b][s] = ic[b][s]; }
+    hipLaunchKernelGGL(optics_combine_cw_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int precision)
 {
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
@@ -1186,6 +1456,12 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
+    if (a.mix == 2) {   // shell_exact: one kernel for all twenty wavelengths, fp64 whatever the precision mode
+        if (any_sw || any_lw)
+            hipLaunchKernelGGL(optics_shell_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                               stream, a);
+        return hipGetLastError();
+    }
     if (any_sw) {   // one thread per cell; the backscatter sums only when a bscoef output is there
         bool bsc = false;
         for (int w = 0; w < OPT_NSW; ++w) bsc = bsc || a.bscoef[w];

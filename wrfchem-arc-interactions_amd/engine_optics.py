@@ -30,7 +30,8 @@ class OpticsArgs(C.Structure):
                    ("chem", C.c_void_p), ("alt", C.c_void_p), ("dz8w", C.c_void_p),
                    ("tauaer", C.c_void_p * 4), ("waer", C.c_void_p * 4), ("gaer", C.c_void_p * 4),
                    ("extaer", C.c_void_p * 4), ("bscoef", C.c_void_p * 4),
-                   ("tauaerlw", C.c_void_p * 16), ("extaerlw", C.c_void_p * 16)])
+                   ("tauaerlw", C.c_void_p * 16), ("extaerlw", C.c_void_p * 16),
+                   ("idx_cw", (C.c_int * NSLOT) * MAXBIN)])
 
 
 EXPORTS_OPTICS = ["rrtmg_hip_optics_init", "rrtmg_hip_optical_averaging", "rrtmg_hip_optics_finalize",
@@ -80,9 +81,10 @@ def table_info():
 
 
 def optical_averaging(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte, chem, alt, dz8w, idx,
-                      aer_op_opt=1, stream=None, **outputs):
+                      aer_op_opt=1, stream=None, idx_cw=None, **outputs):
     """chem: (num_chem, nj_m, nk_m, ni_m) C-order == Fortran chem(i,k,j,species); idx[bin][slot] 1-based species
-    numbers (0 = not carried) in the SPECIES order; outputs by registry name: tauaer1..4, waer1..4, gaer1..4,
+    numbers (0 = not carried) in the SPECIES order; idx_cw: the same for the cloud-borne counterparts ("_cw" tracers,
+    added to the interstitial ones; None = none); outputs by registry name: tauaer1..4, waer1..4, gaer1..4,
     extaer1..4, bscoef1..4, tauaerlw1..16, extaerlw1..16 (each group complete or absent)."""
     lib = _lib()
     a = OpticsArgs()
@@ -96,6 +98,13 @@ def optical_averaging(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
     for b in range(idx.shape[0]):
         for s in range(NSLOT):
             a.idx[b][s] = int(idx[b, s])
+    if idx_cw is not None:
+        idx_cw = np.asarray(idx_cw, dtype=np.int64)
+        if idx_cw.shape != idx.shape:
+            raise ValueError("idx_cw must have the shape of idx")
+        for b in range(idx_cw.shape[0]):
+            for s in range(NSLOT):
+                a.idx_cw[b][s] = int(idx_cw[b, s])
     a.num_chem = int(chem.shape[0])
     dev = size = None
 

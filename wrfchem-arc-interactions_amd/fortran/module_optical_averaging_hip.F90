@@ -37,6 +37,7 @@ MODULE module_optical_averaging_hip
       TYPE(c_ptr) :: chem, alt, dz8w
       TYPE(c_ptr) :: tauaer(4), waer(4), gaer(4), extaer(4), bscoef(4)
       TYPE(c_ptr) :: tauaerlw(16), extaerlw(16)
+      INTEGER(c_int) :: idx_cw(aer_nspec, aer_maxbin)     ! C: idx_cw[bin][species]
    END TYPE optics_args
 
    ! mirrors struct rrtmg_hip_modal_args of include/rrtmg_hip.h
@@ -159,7 +160,9 @@ CONTAINS
 
 !------------------------------------------------------------------
 !  idx(species, bin): species number in chem of aer_so4 .. aer_num for each section (0 = not carried), e.g.
-!  idx(aer_so4,1) = p_so4_a01.  aer_op_opt: registry.chem:4014-4018.
+!  idx(aer_so4,1) = p_so4_a01.  aer_op_opt: registry.chem:4014-4018.  idx_cw (optional): the same for the cloud-borne
+!  counterparts of the aqueous packages (idx_cw(aer_so4,1) = p_so4_cw01, registry.chem:3935-3936), whose mass and
+!  number are added to the interstitial ones; absent = interstitial aerosol alone.
    SUBROUTINE optical_averaging_hip(nbin_o, aer_op_opt, num_chem, idx, chem, dz8w, alt,          &
                        tauaer1, tauaer2, tauaer3, tauaer4,                                       &
                        gaer1, gaer2, gaer3, gaer4,                                               &
@@ -172,9 +175,10 @@ CONTAINS
                        its,ite, jts,jte, kts,kte,                                                &
                        extaer1, extaer2, extaer3, extaer4,                                       &
                        bscoef1, bscoef2, bscoef3, bscoef4,                                       &
-                       extaerlw)
+                       extaerlw, idx_cw)
       INTEGER, INTENT(IN) :: nbin_o, aer_op_opt, num_chem
       INTEGER, INTENT(IN) :: idx(aer_nspec, nbin_o)
+      INTEGER, INTENT(IN), OPTIONAL :: idx_cw(aer_nspec, nbin_o)
       INTEGER, INTENT(IN) :: ids,ide, jds,jde, kds,kde, ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme, num_chem), INTENT(IN), TARGET :: chem
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme), INTENT(IN), TARGET :: dz8w, alt
@@ -201,9 +205,11 @@ CONTAINS
       a%aer_op_opt = aer_op_opt
       a%num_chem = num_chem
       a%idx = 0
+      a%idx_cw = 0
       DO b = 1, nbin_o
          DO s = 1, aer_nspec
             a%idx(s, b) = idx(s, b)
+            IF (PRESENT(idx_cw)) a%idx_cw(s, b) = idx_cw(s, b)
          END DO
       END DO
       a%chem = c_loc(chem); a%alt = c_loc(alt); a%dz8w = c_loc(dz8w)
