@@ -292,6 +292,11 @@ typedef struct rrtmg_hip_optics_args {
      * mass and number are added to the interstitial ones before the particle geometry is formed.  All zero = the
      * interstitial aerosol alone. */
     int idx_cw[RRTMG_HIP_MAXBIN][RRTMG_HIP_AER_NSPEC];
+    /* l2aer..l7aer (registry.chem:1382-1387), each (ims:ime, kms:kme, jms:jme, 4): Legendre moments chi_2..chi_7 of the
+     * phase function at the four shortwave wavelengths, p(mu) = sum_k (2k+1) chi_k P_k(mu) with chi_0 = 1 and chi_1 =
+     * gaer; scattering-weighted mean over the sections.  All six or none (NULL).  A diagnostic for schemes outside
+     * this path (the radiation calls do not read it): evaluated by an extra kernel only when passed. */
+    void *laer[6];
 } rrtmg_hip_optics_args;
 
 int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *args, char *err);

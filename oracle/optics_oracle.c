@@ -46,6 +46,17 @@ typedef double complex cplx_t;
  * max(xstop,|mx|)+15, which leaves errors up to 1e-4 .. 1 in D_n for |mx| > 10 (the start value decays only
  * where n exceeds |mx| by several |mx|^(1/3)); the start is therefore raised by 8 |mx|^(1/3), after which D_n
  * equals the converged value to the last bit in a 20 000-case sweep. */
+#ifndef ORACLE_COUNT_FLOPS
+/* the coefficients of the last evaluation on this thread, for the Legendre moments (optics_oracle_last_moments) */
+static _Thread_local cplx_t last_an[NMIE + 8], last_bn[NMIE + 8];
+static _Thread_local int last_nstop;
+static _Thread_local double last_x;
+#define KEEP_COEFFS(n, a, b) do { if ((n) < NMIE + 8) { last_an[n] = (a); last_bn[n] = (b); } } while (0)
+#define KEEP_END(ns, xx) do { last_nstop = (ns) < NMIE + 7 ? (ns) : NMIE + 7; last_x = (xx); } while (0)
+#else
+#define KEEP_COEFFS(n, a, b) do { } while (0)
+#define KEEP_END(ns, xx) do { } while (0)
+#endif
 void optics_oracle_mie(double x, double mre, double mim, double *out4)
 {
     static _Thread_local cplx_t D[4096];
@@ -81,8 +92,10 @@ void optics_oracle_mie(double x, double mre, double mim, double *out4)
         xb += (sgn * (2. * en + 1.)) * (an - bn);
         sgn = -sgn;
         psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
+        KEEP_COEFFS(n, an, bn);
         an1 = an; bn1 = bn;
     }
+    KEEP_END(nstop, x);
     out4[0] = 2. * qe / (x * x);                           /* Qext */
     out4[1] = 2. * qs / (x * x);                           /* Qsca */
     out4[2] = qs > 0. ? 2. * gs / qs : 0.;                 /* asymmetry parameter */
@@ -160,12 +173,77 @@ void optics_oracle_mie_coated(double x, double y, double m1re, double m1im, doub
         xb += (sgn * (2. * en + 1.)) * (an - bn);
         sgn = -sgn;
         psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
+        KEEP_COEFFS(n, an, bn);
         an1 = an; bn1 = bn;
     }
+    KEEP_END(nstop, y);
     out4[0] = 2. * qe / (y * y);
     out4[1] = 2. * qs / (y * y);
     out4[2] = qs > 0. ? 2. * gs / qs : 0.;
     out4[3] = (creal(xb) * creal(xb) + cimag(xb) * cimag(xb)) / (y * y);
+}
+#endif
+
+#ifndef ORACLE_COUNT_FLOPS
+/* Gauss-Legendre nodes and weights on [-1, 1] (Newton iteration on P_N from the Chebyshev-like first guess) */
+static void gauss_legendre(int N, double *xq, double *wq)
+{
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        double z = cos(pi * (i + 0.75) / (N + 0.5)), pp = 1.;
+        for (int it = 0; it < 100; ++it) {
+            double p1 = 1., p2 = 0.;
+            for (int j = 1; j <= N; ++j) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = ((2. * j - 1.) * z * p2 - (j - 1.) * p3) / j;
+            }
+            pp = N * (z * p1 - p2) / (z * z - 1.);
+            const double dz = p1 / pp;
+            z -= dz;
+            if (fabs(dz) < 1e-15) break;
+        }
+        xq[i] = -z; xq[N - 1 - i] = z;
+        wq[i] = wq[N - 1 - i] = 2. / ((1. - z * z) * pp * pp);
+    }
+}
+/* Legendre moments chi_0..chi_7 of the normalised phase function of the last particle evaluated on this thread:
+ * p(mu) = sum_k (2k+1) chi_k P_k(mu), chi_0 = 1, chi_1 = the asymmetry parameter.  The intensity
+ * i(mu) = (|S1|^2 + |S2|^2) / 2 from the amplitude functions S1 = sum_n c_n (a_n pi_n + b_n tau_n), S2 = sum_n c_n
+ * (a_n tau_n + b_n pi_n), c_n = (2n+1)/(n(n+1)) (Bohren & Huffman eq. 4.74), is a polynomial of degree 2 nstop in mu, so
+ * a Gauss-Legendre rule of N >= nstop + 4 nodes integrates i(mu) P_k(mu), k <= 7, exactly; N is the next multiple of 8.
+ * chi_k = sum_q w_q i(mu_q) P_k(mu_q) / sum_q w_q i(mu_q). */
+void optics_oracle_last_moments(double *chi8)
+{
+    static _Thread_local double xq[NMIE + 24], wq[NMIE + 24];
+    const int nstop = last_nstop;
+    const int N = 8 * ((nstop + 4 + 7) / 8);
+    gauss_legendre(N, xq, wq);
+    double m[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    for (int q = 0; q < N; ++q) {
+        const double mu = xq[q];
+        double pi0 = 0., pi1 = 1.;
+        cplx_t s1 = CPLX(0., 0.), s2 = CPLX(0., 0.);
+        for (int n = 1; n <= nstop; ++n) {
+            const double en = (double)n;
+            const double tau = en * mu * pi1 - (en + 1.) * pi0;
+            const double c = (2. * en + 1.) / (en * (en + 1.));
+            s1 += c * (last_an[n] * pi1 + last_bn[n] * tau);
+            s2 += c * (last_an[n] * tau + last_bn[n] * pi1);
+            const double pin = ((2. * en + 1.) * mu * pi1 - (en + 1.) * pi0) / en;
+            pi0 = pi1; pi1 = pin;
+        }
+        const double inten = 0.5 * (creal(s1) * creal(s1) + cimag(s1) * cimag(s1) + creal(s2) * creal(s2) + cimag(s2) * cimag(s2));
+        double p0 = 1., p1 = mu;
+        m[0] += wq[q] * inten;
+        m[1] += wq[q] * inten * mu;
+        for (int k = 2; k < 8; ++k) {
+            const double pk = ((2. * k - 1.) * mu * p1 - (k - 1.) * p0) / k;
+            m[k] += wq[q] * inten * pk;
+            p0 = p1; p1 = pk;
+        }
+    }
+    for (int k = 0; k < 8; ++k) chi8[k] = m[0] > 0. ? m[k] / m[0] : (k == 0 ? 1. : 0.);
 }
 #endif
 
@@ -179,12 +257,14 @@ typedef struct optics_oracle_tables {
 
 /* one grid cell: mass[b][s] ug/kg (s = so4 no3 cl nh4 na oin oc bc water), num[b] #/kg, alt m3/kg, dz m.
  * out_sw[w][5] = tau, omega, g, ext (1/km), backscatter (1/(km sr)); out_lw[b][2] = absorption tau, coefficient (1/km) */
-void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *mass /*[nbin][9]*/,
-                        const double *numb /*[nbin]*/, double alt, double dz, double *out_sw, double *out_lw)
+static void cell_impl(const optics_oracle_tables *t, int mix, const double *mass /*[nbin][9]*/,
+                      const double *numb /*[nbin]*/, double alt, double dz, double *out_sw, double *out_lw,
+                      double *out_leg /* NULL or [4 wavelengths][6]: l2..l7 */)
 {
     const double pi = 3.14159265358979323846;
     for (int w = 0; w < NWAVE; ++w) {
         double ext = 0., sca = 0., gsca = 0., bsc = 0.;
+        double lsum[6] = {0., 0., 0., 0., 0., 0.};
         for (int b = 0; b < t->nbin; ++b) {
             double vol[NSPEC], vdry = 0.;
             for (int s = 0; s < NSPEC; ++s) {
@@ -244,7 +324,16 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
             sca += cross * q[1];
             gsca += cross * q[1] * q[2];
             bsc += cross * q[3] * (0.25 / pi);
+#ifndef ORACLE_COUNT_FLOPS
+            if (out_leg && w < NSW) {   /* scattering-weighted Legendre moments of the phase function, k = 2..7 */
+                double chi[8];
+                optics_oracle_last_moments(chi);
+                for (int k = 2; k < 8; ++k) lsum[k - 2] += cross * q[1] * chi[k];
+            }
+#endif
         }
+        if (out_leg && w < NSW)
+            for (int k = 0; k < 6; ++k) out_leg[w * 6 + k] = sca > 0. ? lsum[k] / sca : 0.;
         if (w < NSW) {
             double *o = out_sw + w * 5;
             o[0] = ext * 100. * dz;
@@ -261,11 +350,25 @@ void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *ma
     }
 }
 
+void optics_oracle_cell(const optics_oracle_tables *t, int mix, const double *mass, const double *numb, double alt,
+                        double dz, double *out_sw, double *out_lw)
+{
+    cell_impl(t, mix, mass, numb, alt, dz, out_sw, out_lw, NULL);
+}
+#ifndef ORACLE_COUNT_FLOPS
+/* the same with l2aer..l7aer (registry.chem:1382-1387): out_leg[w][k-2], w = 300/400/600/999 nm */
+void optics_oracle_cell_legendre(const optics_oracle_tables *t, int mix, const double *mass, const double *numb, double alt,
+                                 double dz, double *out_sw, double *out_lw, double *out_leg)
+{
+    cell_impl(t, mix, mass, numb, alt, dz, out_sw, out_lw, out_leg);
+}
+#endif
+
 /* a WRF tile: chem(ni_m,nk_m,nj_m,num_chem) i fastest, idx[b][10] 0-based (-1 absent); outputs are 3-D arrays
  * of the memory shape, [field][ni_m*nk_m*nj_m]: sw5 = 4 wavelengths x (tau,omega,g,ext,bsc), lw2 = 16 x (tau,ext) */
-void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0, int j0,
-                        int ni_t, int nk_t, int nj_t, int num_chem, const int *idx /*[8][10]*/, const double *chem,
-                        const double *alt, const double *dz8w, double *sw5, double *lw2)
+static void tile_impl(const optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0, int j0,
+                      int ni_t, int nk_t, int nj_t, int num_chem, const int *idx /*[8][10]*/, const double *chem,
+                      const double *alt, const double *dz8w, double *sw5, double *lw2, double *leg /* NULL or [4][6][n3] */)
 {
     const size_t n3 = (size_t)ni_m * nk_m * nj_m;
     (void)num_chem;
@@ -274,7 +377,7 @@ void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk
         for (int k = 0; k < nk_t; ++k)
             for (int it = 0; it < ni_t; ++it) {
                 const size_t q = ((size_t)(j0 + jt) * nk_m + (k0 + k)) * ni_m + (i0 + it);
-                double mass[8 * NSPEC], num[8], osw[NSW * 5], olw[16 * 2];
+                double mass[8 * NSPEC], num[8], osw[NSW * 5], olw[16 * 2], oleg[NSW * 6];
                 for (int b = 0; b < t->nbin; ++b) {
                     for (int s = 0; s < NSPEC; ++s) {
                         const int id = idx[b * NSLOT + s];
@@ -283,13 +386,29 @@ void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk
                     const int id = idx[b * NSLOT + S_NUM];
                     num[b] = id >= 0 ? chem[(size_t)id * n3 + q] : 0.;
                 }
-                optics_oracle_cell(t, mix, mass, num, alt[q], dz8w[q], osw, olw);
+                cell_impl(t, mix, mass, num, alt[q], dz8w[q], osw, olw, leg ? oleg : NULL);
+                if (leg)
+                    for (int f = 0; f < NSW * 6; ++f) leg[(size_t)f * n3 + q] = oleg[f];
                 for (int w = 0; w < NSW; ++w)
                     for (int f = 0; f < 5; ++f) sw5[((size_t)w * 5 + f) * n3 + q] = osw[w * 5 + f];
                 for (int b = 0; b < 16; ++b)
                     for (int f = 0; f < 2; ++f) lw2[((size_t)b * 2 + f) * n3 + q] = olw[b * 2 + f];
             }
 }
+void optics_oracle_tile(const optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0, int j0,
+                        int ni_t, int nk_t, int nj_t, int num_chem, const int *idx, const double *chem, const double *alt,
+                        const double *dz8w, double *sw5, double *lw2)
+{
+    tile_impl(t, mix, ni_m, nk_m, nj_m, i0, k0, j0, ni_t, nk_t, nj_t, num_chem, idx, chem, alt, dz8w, sw5, lw2, NULL);
+}
+#ifndef ORACLE_COUNT_FLOPS
+void optics_oracle_tile_legendre(const optics_oracle_tables *t, int mix, int ni_m, int nk_m, int nj_m, int i0, int k0,
+                                 int j0, int ni_t, int nk_t, int nj_t, int num_chem, const int *idx, const double *chem,
+                                 const double *alt, const double *dz8w, double *sw5, double *lw2, double *leg)
+{
+    tile_impl(t, mix, ni_m, nk_m, nj_m, i0, k0, j0, ni_t, nk_t, nj_t, num_chem, idx, chem, alt, dz8w, sw5, lw2, leg);
+}
+#endif
 
 /* Modal (MADE/SORGAM-type) aerosol -> sections: the specification of modal_sections.hip restated for one cell.
  * mass[nmode][9] (ug/kg, species order of the optics), num[nmode] (#/kg), sigma[nmode] -> secmass[nbin][9],

@@ -25,6 +25,9 @@ def _lib():
     if not getattr(l, "_optics_ready", False):
         l.optics_oracle_mie.argtypes = [C.c_double, C.c_double, C.c_double, dp]
         l.optics_oracle_mie_coated.argtypes = [C.c_double] * 6 + [dp]
+        l.optics_oracle_last_moments.argtypes = [dp]
+        l.optics_oracle_tile_legendre.argtypes = ([C.c_void_p, C.c_int] + [C.c_int] * 9
+                                                  + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp, dp])
         l.optics_oracle_cell.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, dp, dp]
         l.optics_oracle_tile.argtypes = [C.c_void_p, C.c_int] + [C.c_int] * 9 + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp]
         l._optics_ready = True
@@ -45,6 +48,18 @@ def mie_coated(x, y, m1, m2):
     _lib().optics_oracle_mie_coated(float(x), float(y), float(np.real(m1)), float(np.imag(m1)), float(np.real(m2)),
                                     float(np.imag(m2)), out.ctypes.data_as(dp))
     return tuple(out)
+
+
+def moments(x, m, core=None):
+    """Legendre moments chi_0..chi_7 of the normalised phase function of a homogeneous sphere (x, m), or of a coated
+    one with core = (x_core, m_core) inside it."""
+    if core is None:
+        mie(x, m)
+    else:
+        mie_coated(core[0], x, core[1], m)
+    out = np.zeros(8)
+    _lib().optics_oracle_last_moments(out.ctypes.data_as(dp))
+    return out
 
 
 def make_tables(nbin, dlo_um, dhi_um, wavelength_um, refindex, density):
@@ -76,7 +91,7 @@ def cell(tables, mass, num, alt, dz, mix=0):
     return osw, olw
 
 
-def tile(tables, chem, alt, dz8w, idx, dims, mix=0):
+def tile(tables, chem, alt, dz8w, idx, dims, mix=0, legendre=False):
     """chem (num_chem, nj_m, nk_m, ni_m) C-order == Fortran (i,k,j,species); alt, dz8w (nj_m, nk_m, ni_m); idx
     [nbin][10] 1-based (0 = absent); dims = dict(ims..kte).  Returns dict of 3-D arrays named like the registry."""
     chem = np.ascontiguousarray(chem, dtype=np.float64)
@@ -90,13 +105,19 @@ def tile(tables, chem, alt, dz8w, idx, dims, mix=0):
     idx0[: idx.shape[0], :] = idx - 1
     sw5 = np.zeros((NSW, 5, nj_m, nk_m, ni_m))
     lw2 = np.zeros((NLW, 2, nj_m, nk_m, ni_m))
-    _lib().optics_oracle_tile(C.addressof(tables), int(mix), ni_m, nk_m, nj_m,
-                              d["its"] - d["ims"], d["kts"] - d["kms"], d["jts"] - d["jms"],
-                              d["ite"] - d["its"] + 1, d["kte"] - d["kts"] + 1, d["jte"] - d["jts"] + 1,
-                              num_chem, idx0.ctypes.data_as(C.POINTER(C.c_int)), chem.ctypes.data_as(dp),
-                              alt.ctypes.data_as(dp), dz8w.ctypes.data_as(dp), sw5.ctypes.data_as(dp),
-                              lw2.ctypes.data_as(dp))
+    args = [C.addressof(tables), int(mix), ni_m, nk_m, nj_m,
+            d["its"] - d["ims"], d["kts"] - d["kms"], d["jts"] - d["jms"],
+            d["ite"] - d["its"] + 1, d["kte"] - d["kts"] + 1, d["jte"] - d["jts"] + 1,
+            num_chem, idx0.ctypes.data_as(C.POINTER(C.c_int)), chem.ctypes.data_as(dp),
+            alt.ctypes.data_as(dp), dz8w.ctypes.data_as(dp), sw5.ctypes.data_as(dp), lw2.ctypes.data_as(dp)]
     out = {}
+    if legendre:   # l2aer..l7aer as (4, nj_m, nk_m, ni_m) == Fortran (i,k,j,4)
+        leg = np.zeros((NSW, 6, nj_m, nk_m, ni_m))
+        _lib().optics_oracle_tile_legendre(*args, leg.ctypes.data_as(dp))
+        for k in range(6):
+            out[f"l{k + 2}aer"] = np.ascontiguousarray(leg[:, k])
+    else:
+        _lib().optics_oracle_tile(*args)
     for w in range(NSW):
         out[f"tauaer{w + 1}"] = sw5[w, 0]
         out[f"waer{w + 1}"] = sw5[w, 1]

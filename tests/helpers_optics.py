@@ -21,9 +21,13 @@ def oracle_tables(wa, nbin):
     return oo.make_tables(nbin, wa.engine_optics.MOSAIC_DLO_UM, wa.engine_optics.MOSAIC_DHI_UM, wl, ref, den)
 
 
-def run_oracle_optics(wa, st, ms, tile=None, mix=0):
+def run_oracle_optics(wa, st, ms, tile=None, mix=0, legendre=False):
     from oracle import oracle_optics as oo
-    return oo.tile(oracle_tables(wa, ms.nbin), ms.chem, ms.alt, ms.dz8w, ms.idx, optics_dims(st, tile), mix=mix)
+    return oo.tile(oracle_tables(wa, ms.nbin), ms.chem, ms.alt, ms.dz8w, ms.idx, optics_dims(st, tile), mix=mix,
+                   legendre=legendre)
+
+
+LEG_NAMES = [f"l{k}aer" for k in range(2, 8)]   # (4, nj_m, nk_m, ni_m) == Fortran (i,k,j,4)
 
 
 def run_hip_optics(wa, st, ms, device=True, real_bytes=8, tile=None, aer_op_opt=1, names=None, idx_cw=None):
@@ -32,7 +36,7 @@ def run_hip_optics(wa, st, ms, device=True, real_bytes=8, tile=None, aer_op_opt=
     shape = ms.alt.shape
     host_in = dict(chem=np.ascontiguousarray(ms.chem, dtype=dt), alt=np.ascontiguousarray(ms.alt, dtype=dt),
                    dz8w=np.ascontiguousarray(ms.dz8w, dtype=dt))
-    outs = {n: np.full(shape, SENTINEL, dtype=dt) for n in names}
+    outs = {n: np.full((4,) + tuple(shape) if n in LEG_NAMES else shape, SENTINEL, dtype=dt) for n in names}
     d = optics_dims(st, tile)
     eo = wa.engine_optics
     if device:

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from helpers import SENTINEL
-from helpers_optics import LW_NAMES, SW_NAMES, run_hip_optics, run_oracle_optics, tile_mask
+from helpers_optics import LEG_NAMES, LW_NAMES, SW_NAMES, run_hip_optics, run_oracle_optics, tile_mask
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-8
@@ -379,3 +379,32 @@ def test_cloud_borne_tracers_are_added_to_the_interstitial_ones(hip_lib, wa, rea
         bad = idx_cw.copy()
         bad[0, 0] = both.chem.shape[0] + 1
         run_hip_optics(wa, st, both, idx_cw=bad)
+
+
+@pytest.mark.parametrize("opt", [1, 2, 5])
+def test_legendre_moments_match_oracle(hip_lib, wa, opt):
+    """l2aer..l7aer (registry.chem:1382-1387): scattering-weighted Legendre moments of the phase function at the four
+    shortwave wavelengths, against the oracle's quadrature; device-resident and host arrays alike; asking for them does
+    not change the other outputs; the group is all six or none."""
+    _init(wa, 4)
+    st = wa.synth.make_wrf_state(5, 4, 9, seed=20260398)
+    ms = wa.synth_mosaic.make_mosaic_state(st, nbin=4, seed=20260399)
+    names = SW_NAMES + LW_NAMES + LEG_NAMES
+    got = run_hip_optics(wa, st, ms, aer_op_opt=opt, names=names)
+    ref = run_oracle_optics(wa, st, ms, mix=MIX_OF[opt], legendre=True)
+    mask = tile_mask(st, ms.alt.shape)
+    for n in LEG_NAMES:
+        for w in range(4):
+            g, r = got[n][w][mask], ref[n][w][mask]
+            assert np.isfinite(g).all() and np.abs(g - r).max() <= 1e-9, (n, w, float(np.abs(g - r).max()))
+            assert (got[n][w][~mask] == SENTINEL).all()
+        assert np.abs(got[n][:, mask]).max() <= 1.0
+    assert got["l2aer"][1][mask].max() > 0.2          # forward-peaked phase functions
+    plain = run_hip_optics(wa, st, ms, aer_op_opt=opt)
+    for n in plain:
+        np.testing.assert_array_equal(plain[n], got[n], err_msg=n)
+    host = run_hip_optics(wa, st, ms, aer_op_opt=opt, names=LEG_NAMES, device=False)
+    for n in LEG_NAMES:
+        np.testing.assert_array_equal(host[n], got[n], err_msg=n)
+    with pytest.raises(wa.engine.WrfFatal, match="complete or not at all"):
+        run_hip_optics(wa, st, ms, names=["l2aer", "l3aer"])

@@ -228,3 +228,54 @@ def test_coated_sphere_limits(oo):
     qe0, qs0, _, _ = oo.mie(2.0, 1.45 + 1e-6j)
     qe1, qs1, _, _ = oo.mie_coated(1.0, 2.0, 1.85 + 0.71j, 1.45 + 1e-6j)
     assert qs1 / qe1 < 0.9 < qs0 / qe0
+
+
+# ---- Legendre moments of the phase function (l2aer..l7aer) ----
+def test_legendre_moments_known_answers(oo):
+    """chi_0 = 1; chi_1 -- from the quadrature of the intensity -- equals the asymmetry parameter of the series (an
+    independent formula); the Rayleigh phase function 3/4 (1 + mu^2) has chi_2 = 1/10 and nothing else; a coated sphere
+    likewise."""
+    c = oo.moments(0.01, 1.5 + 0.0j)
+    assert abs(c[0] - 1.0) < 1e-14 and abs(c[2] - 0.1) < 1e-5 and np.abs(c[3:]).max() < 1e-5
+    for x, m in [(0.3, 1.45 + 1e-3j), (1.0, 1.5 + 0.01j), (10.0, 1.33 + 1e-6j), (50.0, 1.55 + 0.006j), (3.0, 1.85 + 0.71j),
+                 (224.0, 1.4 + 1e-4j)]:
+        g = oo.mie(x, m)[2]
+        c = oo.moments(x, m)
+        assert abs(c[0] - 1.0) < 1e-14 and abs(c[1] - g) < 1e-11, (x, m, c[1], g)
+        assert (np.abs(c) <= 1.0 + 1e-12).all()
+    g = oo.mie_coated(2.0, 5.0, 1.85 + 0.71j, 1.5 + 0.01j)[2]
+    c = oo.moments(5.0, 1.5 + 0.01j, core=(2.0, 1.85 + 0.71j))
+    assert abs(c[1] - g) < 1e-11
+
+
+def test_legendre_moments_reconstruct_the_phase_function(oo):
+    """p(mu) = sum_k (2k+1) chi_k P_k(mu): for a small particle (x = 0.8: moments beyond k = 7 below 1e-5) the eight
+    moments rebuild the phase function of the amplitude functions, evaluated here with scipy's Bessel functions."""
+    from numpy.polynomial import legendre as L
+    x, m = 0.8, 1.5 + 0.02j
+    c = oo.moments(x, m)
+    nmax = int(x + 4.0 * x ** (1.0 / 3.0) + 2.0)
+    from scipy.special import spherical_jn, spherical_yn
+    n = np.arange(1, nmax + 1)
+    z = m * x
+    jx, djx, yx, dyx = spherical_jn(n, x), spherical_jn(n, x, derivative=True), spherical_yn(n, x), spherical_yn(n, x, derivative=True)
+    jz, djz = spherical_jn(n, z), spherical_jn(n, z, derivative=True)
+    psi_x, dpsi_x = x * jx, jx + x * djx
+    xi_x, dxi_x = x * (jx + 1j * yx), (jx + 1j * yx) + x * (djx + 1j * dyx)
+    psi_z, dpsi_z = z * jz, jz + z * djz
+    a = (m * psi_z * dpsi_x - psi_x * dpsi_z) / (m * psi_z * dxi_x - xi_x * dpsi_z)
+    b = (psi_z * dpsi_x - m * psi_x * dpsi_z) / (psi_z * dxi_x - m * xi_x * dpsi_z)
+    mu = np.linspace(-1, 1, 41)
+    pi0, pi1 = np.zeros_like(mu), np.ones_like(mu)
+    s1 = np.zeros_like(mu, dtype=complex); s2 = np.zeros_like(mu, dtype=complex)
+    for k in range(1, nmax + 1):
+        tau = k * mu * pi1 - (k + 1) * pi0
+        cn = (2 * k + 1) / (k * (k + 1))
+        s1 += cn * (a[k - 1] * pi1 + b[k - 1] * tau)
+        s2 += cn * (a[k - 1] * tau + b[k - 1] * pi1)
+        pi0, pi1 = pi1, ((2 * k + 1) * mu * pi1 - (k + 1) * pi0) / k
+    inten = 0.5 * (abs(s1) ** 2 + abs(s2) ** 2)
+    qsca = 2.0 / x**2 * np.sum((2 * n + 1) * (abs(a) ** 2 + abs(b) ** 2))
+    p_true = 4.0 * inten / (x**2 * qsca)                        # integral over mu = 2
+    p_fit = L.legval(mu, [(2 * k + 1) * c[k] for k in range(8)])
+    assert np.abs(p_fit - p_true).max() < 2e-5

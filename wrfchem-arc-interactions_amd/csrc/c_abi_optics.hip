@@ -146,9 +146,9 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
     void *const sw3[12] = {a->tauaer[0], a->tauaer[1], a->tauaer[2], a->tauaer[3], a->waer[0], a->waer[1],
                            a->waer[2], a->waer[3], a->gaer[0], a->gaer[1], a->gaer[2], a->gaer[3]};
     if (group(sw3, 12) < 0 || group(a->extaer, 4) < 0 || group(a->bscoef, 4) < 0 || group(a->tauaerlw, 16) < 0 ||
-        group(a->extaerlw, 16) < 0)
+        group(a->extaerlw, 16) < 0 || group(a->laer, 6) < 0)
         return failo(err, "rrtmg_hip_optical_averaging: an output group (tauaer/waer/gaer, extaer, bscoef, tauaerlw, "
-                          "extaerlw) must be passed complete or not at all");
+                          "extaerlw, l2aer..l7aer) must be passed complete or not at all");
     HIPCHK(hipSetDevice(g_opt.device));
     hipStream_t stream = a->mem == 1 ? static_cast<hipStream_t>(a->stream) : nullptr;
     k.ni_m = ni_m; k.nk_m = nk_m; k.nj_m = nj_m;
@@ -167,6 +167,7 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
             k.extaer[w] = a->extaer[w]; k.bscoef[w] = a->bscoef[w];
         }
         for (int b = 0; b < OPT_NLW; ++b) { k.tauaerlw[b] = a->tauaerlw[b]; k.extaerlw[b] = a->extaerlw[b]; }
+        for (int l = 0; l < 6; ++l) k.laer[l] = a->laer[l];
     } else {
         int lo = a->num_chem, hi = -1;
         for (int b = 0; b < nbin; ++b)
@@ -192,6 +193,7 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
         for (int b = 0; b < OPT_NLW; ++b) {
             stg.out(a->tauaerlw[b], nk_m, 1, &k.tauaerlw[b]); stg.out(a->extaerlw[b], nk_m, 1, &k.extaerlw[b]);
         }
+        for (int l = 0; l < 6; ++l) stg.out(a->laer[l], nk_m, OPT_NSW, &k.laer[l]);   // (i, k, j, 4)
         // chunks of the tile, all on this thread's own stream (tile_staging.h): this stage moves the most bytes per
         // column of the three (80 tracers in, 28 fields out per cell), so the overlap of packing, copies and kernels
         // matters most here

@@ -100,12 +100,13 @@ struct OpticsKernelArgs {
     int i0, k0, j0;                // tile origin inside memory (0-based)
     int ni_t, nk_t, nj_t;          // tile dimensions
     int real4;
-    int mix;                       // 0 volume mixing, 1 Maxwell-Garnett with BC inclusions
+    int mix;                       // 0 volume mixing, 1 Maxwell-Garnett with BC inclusions, 2 BC core + shell
     int nbin;
     int idx[OPT_MAXBIN][OPT_NSLOT];   // 0-based species index into chem, -1 = absent
     const void *chem, *alt, *dz8w;
     void *tauaer[OPT_NSW], *waer[OPT_NSW], *gaer[OPT_NSW], *extaer[OPT_NSW], *bscoef[OPT_NSW];
     void *tauaerlw[OPT_NLW], *extaerlw[OPT_NLW];
+    void *laer[6];                 // l2aer..l7aer, each [4 wavelengths][memory shape]; all or none
 };
 
 }  // namespace rrtmg

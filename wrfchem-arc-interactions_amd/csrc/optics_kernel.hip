@@ -46,6 +46,10 @@ __constant__ MieN c_mn[OPT_NMIE + 10];
 struct MieN2 { double en0, en1, tn0, tn1; float fen[2], ftn[2], fw2[2], fgx[2], fgy[2], pad_[2]; };
 constexpr int OPT_NPAIR = (OPT_NMIE + 10) / 2;
 __constant__ MieN2 c_mp[OPT_NPAIR];
+// Gauss-Legendre rules of N = 8, 16, .. 264 nodes (the Legendre moments l2aer..l7aer): rule j = N / 8 starts at entry
+// 4 j (j - 1); nodes in g_gl[0][..], weights in g_gl[1][..]
+constexpr int OPT_NGL = 33, OPT_GL_ENTRIES = 4 * OPT_NGL * (OPT_NGL + 1);
+__device__ double g_gl[2][OPT_GL_ENTRIES];
 __device__ __forceinline__ MieN mie_n(int n, double2 gw)   // the same from n (folds where n is a compile-time constant)
 {
     const double en = (double)n;
@@ -1132,7 +1136,8 @@ __device__ __noinline__ void log_derivative_down(cplx z, int nstop, double xstop
     }
 }
 __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, double cby, cplx *Dx1, cplx *Dx2, cplx *Dy2,
-                                        double &qext, double &qsca, double &gasy, double &qback)
+                                        double &qext, double &qsca, double &gasy, double &qback,
+                                        cplx *an_out = nullptr, cplx *bn_out = nullptr /* [1..nstop] when given */)
 {
     const cplx x1 = {x * m1.re, x * m1.im}, x2 = {x * m2.re, x * m2.im}, y2 = {y * m2.re, y * m2.im};
     const cplx refrel = cdivc(m2, m1), m2inv = crecip(m2), x2inv = crecip(x2), y2inv = crecip(y2);
@@ -1207,12 +1212,181 @@ __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, do
         A.xb.im += A.sgn * w2 * (an.im - bn.im);
         A.sgn = -A.sgn;
         A.an[0] = an; A.bn[0] = bn;
+        if (an_out) { an_out[n] = an; bn_out[n] = bn; }
     }
     const double y2i = yinv * yinv;
     qsca = 2. * y2i * A.qs;
     qext = 2. * y2i * A.qe;
     gasy = A.qs > 0. ? 2. * A.gs / A.qs : 0.;
     qback = y2i * cabs2(A.xb);
+}
+
+// ---- l2aer..l7aer (registry.chem:1382-1387): Legendre moments of the phase function at the four shortwave wavelengths ----
+// chi_k of p(mu) = sum_k (2k+1) chi_k P_k(mu), chi_0 = 1, chi_1 = the asymmetry parameter; per cell the scattering-
+// weighted mean over the sections, k = 2..7.  A diagnostic for schemes outside this path (the radiation calls take tau,
+// omega, g), evaluated only when its arrays are passed, by a kernel of its own: coefficients a_n, b_n of a particle
+// into per-lane scratch arrays (homogeneous sphere: downward D_n; aer_op_opt 5: mie_coated), then the intensity
+// i(mu) = (|S1|^2 + |S2|^2) / 2 from the amplitude functions (Bohren & Huffman eq. 4.74) on a Gauss-Legendre rule of
+// N >= nstop + 4 nodes (next multiple of 8), which integrates i(mu) P_k(mu), k <= 7, exactly (i is a polynomial of
+// degree 2 nstop in mu).  The oracle does the same (optics_oracle_last_moments; its chi_1 equals the asymmetry parameter
+// of the series, an independent formula, and the Rayleigh limit gives chi_2 = 1/10: tests/test_optics_oracle.py).
+__device__ __noinline__ void mie_coeffs_down(double x, cplx m, double cbx, cplx *D, cplx *an_out, cplx *bn_out, int &nstop,
+                                             double &qsca)
+{
+    const double xstop = x + 4. * cbx + 2.;
+    nstop = (int)xstop;
+    log_derivative_down({x * m.re, x * m.im}, nstop, xstop, D);
+    double psi0, psi1, chi0, chi1;
+    {
+        double sn, cs;
+        sincos(x, &sn, &cs);
+        psi0 = cs; psi1 = sn; chi0 = -sn; chi1 = cs;
+    }
+    const double xinv = frcp(x);
+    const cplx minv = crecip(m);
+    double qs = 0.;
+    for (int n = 1; n <= nstop; ++n) {
+        const double en = (double)n, tn = 2. * en - 1.;
+        const double psi = tn * xinv * psi1 - psi0, chi = tn * xinv * chi1 - chi0;
+        const cplx d = D[n];
+        cplx t = cmul(d, minv);
+        t.re += en * xinv;
+        const cplx na = {t.re * psi - psi1, t.im * psi};
+        const cplx da = {na.re + t.im * chi, na.im - (t.re * chi - chi1)};
+        t = cmul(m, d);
+        t.re += en * xinv;
+        const cplx nb = {t.re * psi - psi1, t.im * psi};
+        const cplx db = {nb.re + t.im * chi, nb.im - (t.re * chi - chi1)};
+        const cplx an = cdivc(na, da), bn = cdivc(nb, db);
+        an_out[n] = an; bn_out[n] = bn;
+        qs += (2. * en + 1.) * (cabs2(an) + cabs2(bn));
+        psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
+    }
+    qsca = 2. * xinv * xinv * qs;
+}
+__device__ __noinline__ void legendre_moments(const cplx *an, const cplx *bn, int nstop, double *chi /* [8] */)
+{
+    const int j = (nstop + 4 + 7) / 8, N = 8 * j;
+    const double *xq = g_gl[0] + 4 * j * (j - 1), *wq = g_gl[1] + 4 * j * (j - 1);
+    double m[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    for (int q = 0; q < N; ++q) {
+        const double mu = xq[q];
+        double pi0 = 0., pi1 = 1.;
+        cplx s1 = {0., 0.}, s2 = {0., 0.};
+        for (int n = 1; n <= nstop; ++n) {
+            const double en = (double)n;
+            const double tau = en * mu * pi1 - (en + 1.) * pi0;
+            const double c = (2. * en + 1.) / (en * (en + 1.));
+            const cplx a = an[n], b = bn[n];
+            s1.re += c * (a.re * pi1 + b.re * tau); s1.im += c * (a.im * pi1 + b.im * tau);
+            s2.re += c * (a.re * tau + b.re * pi1); s2.im += c * (a.im * tau + b.im * pi1);
+            const double pin = ((2. * en + 1.) * mu * pi1 - (en + 1.) * pi0) / en;
+            pi0 = pi1; pi1 = pin;
+        }
+        const double wi = wq[q] * 0.5 * (cabs2(s1) + cabs2(s2));
+        double p0 = 1., p1 = mu;
+        m[0] += wi;
+        m[1] += wi * mu;
+#pragma unroll
+        for (int k = 2; k < 8; ++k) {
+            const double pk = ((2. * k - 1.) * mu * p1 - (k - 1.) * p0) / k;
+            m[k] += wi * pk;
+            p0 = p1; p1 = pk;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) chi[k] = m[0] > 0. ? m[k] / m[0] : (k == 0 ? 1. : 0.);
+}
+__global__ void __launch_bounds__(OPT_THREADS) optics_legendre_kernel(const OpticsKernelArgs a)
+{
+    __shared__ double s_acc[7 * OPT_NSW * OPT_THREADS];   // per wavelength: scattering sum, six weighted moments
+    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
+    if (cell >= ncell) return;
+    cplx Da[OPT_NMIE + 2], Db[OPT_NMIE + 2], Dc[OPT_NMIE + 2], An[OPT_NMIE + 2], Bn[OPT_NMIE + 2];   // per-lane scratch
+    double *acc = s_acc + threadIdx.x;
+    for (int i = 0; i < 7 * OPT_NSW; ++i) acc[i * OPT_THREADS] = 0.;
+    const int it = (int)(cell % a.ni_t);
+    const long r = cell / a.ni_t;
+    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
+    const int r4 = a.real4;
+    const double alt = ldr(a.alt, q, r4);
+    const double pi = 3.14159265358979323846;
+    for (int ib = 0; ib < a.nbin; ++ib) {
+        double vol[OPT_NSPEC];
+        double vdry = 0.;
+#pragma unroll
+        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+            const int id = a.idx[ib][sp];
+            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
+            vol[sp] = mass * c_opt.rdens[sp];
+            if (sp != OS_WATER) vdry += vol[sp];
+        }
+        const int idn = a.idx[ib][OS_NUM];
+        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
+        if (!(vdry > 1.e-25)) continue;
+        const double vwet = vdry + vol[OS_WATER];
+        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));
+        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
+        if (ddry < dlo || ddry > dhi) {
+            ddry = ddry < dlo ? dlo : dhi;
+            const double dcm = ddry * 1.e-4;
+            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
+        }
+        const double dwet = ddry * cbrt(vwet * frcp(vdry));
+        const double cbd = cbrt(dwet);
+        const double dcm = dwet * 1.e-4;
+        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);
+        const double vbc = vol[OS_BC], vmat = vwet - vbc;
+#pragma unroll 1
+        for (int w = 0; w < OPT_NSW; ++w) {
+            double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
+            const bool capped = x > OPT_XMAX;
+            x = capped ? OPT_XMAX : x;
+            const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
+            int nstop = (int)(x + 4. * cbx + 2.);
+            double qs;
+            cplx m = mix_index(vol, vwet, a.mix == 2 ? 1 : a.mix, w);   // (mix 2: replaced below)
+            bool coated = false;
+            if (a.mix == 2) {
+                const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
+                if (!(vmat > 1.e-30 * vwet)) m = mbc;
+                else {
+                    double sr = 0., si = 0.;
+#pragma unroll
+                    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+                        if (sp == OS_BC) continue;
+                        sr += vol[sp] * c_opt.refr[sp][w];
+                        si += vol[sp] * c_opt.refi[sp][w];
+                    }
+                    const double vi = frcp(vmat);
+                    m = {sr * vi, si * vi};
+                    if (vbc > 0.) {
+                        double qe, g, qb;
+                        mie_coated(cbrt(vbc * frcp(vwet)) * x, x, mbc, m, cbx, Da, Db, Dc, qe, qs, g, qb, An, Bn);
+                        coated = true;
+                    }
+                }
+            }
+            if (!coated) mie_coeffs_down(x, m, cbx, Da, An, Bn, nstop, qs);
+            double chi[8];
+            legendre_moments(An, Bn, nstop, chi);
+            double *s = acc + (size_t)(7 * w) * OPT_THREADS;
+            const double wsca = cross * qs;
+            s[0] += wsca;
+#pragma unroll
+            for (int kk = 2; kk < 8; ++kk) s[(kk - 1) * OPT_THREADS] += wsca * chi[kk];
+        }
+    }
+    for (int w = 0; w < OPT_NSW; ++w) {
+        const double *s = acc + (size_t)(7 * w) * OPT_THREADS;
+        const double sca = s[0];
+        for (int kk = 2; kk < 8; ++kk)
+            str(a.laer[kk - 2], (size_t)w * sspec + q, r4, sca > 0. ? s[(kk - 1) * OPT_THREADS] * frcp(sca) : 0.);
+    }
 }
 
 // one thread per cell, all twenty wavelengths; the cell's 32 sums (4 x 4 shortwave, 16 longwave absorption) in LDS
@@ -1397,6 +1571,33 @@ hipError_t optics_upload_tables(const OpticsTables &t)
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_mp), mp, sizeof mp);
     if (e != hipSuccess) return e;
+    {   // Gauss-Legendre nodes and weights: Newton iteration on P_N from the Chebyshev-like first guess
+        static double gl[2][OPT_GL_ENTRIES];
+        const double pi = 3.14159265358979323846;
+        for (int j = 1; j <= OPT_NGL; ++j) {
+            const int N = 8 * j;
+            double *xq = gl[0] + 4 * j * (j - 1), *wq = gl[1] + 4 * j * (j - 1);
+            for (int i = 0; i < (N + 1) / 2; ++i) {
+                double z = std::cos(pi * (i + 0.75) / (N + 0.5)), pp = 1.;
+                for (int it = 0; it < 100; ++it) {
+                    double p1 = 1., p2 = 0.;
+                    for (int q = 1; q <= N; ++q) {
+                        const double p3 = p2;
+                        p2 = p1;
+                        p1 = ((2. * q - 1.) * z * p2 - (q - 1.) * p3) / q;
+                    }
+                    pp = N * (z * p1 - p2) / (z * z - 1.);
+                    const double dz = p1 / pp;
+                    z -= dz;
+                    if (std::fabs(dz) < 1e-15) break;
+                }
+                xq[i] = -z; xq[N - 1 - i] = z;
+                wq[i] = wq[N - 1 - i] = 2. / ((1. - z * z) * pp * pp);
+            }
+        }
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_gl), gl, sizeof gl);
+        if (e != hipSuccess) return e;
+    }
     double pil[2][OPT_NWAVE];
     for (int w = 0; w < OPT_NWAVE; ++w) {
         pil[0][w] = 3.14159265358979323846 / t.wavelength_um[w];
@@ -1456,6 +1657,9 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
+    if (a.laer[0])   // the Legendre moments, when asked for (fp64 whatever the precision mode)
+        hipLaunchKernelGGL(optics_legendre_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
+                           stream, a);
     if (a.mix == 2) {   // shell_exact: one kernel for all twenty wavelengths, fp64 whatever the precision mode
         if (any_sw || any_lw)
             hipLaunchKernelGGL(optics_shell_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,

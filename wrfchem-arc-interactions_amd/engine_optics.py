@@ -31,7 +31,7 @@ class OpticsArgs(C.Structure):
                    ("tauaer", C.c_void_p * 4), ("waer", C.c_void_p * 4), ("gaer", C.c_void_p * 4),
                    ("extaer", C.c_void_p * 4), ("bscoef", C.c_void_p * 4),
                    ("tauaerlw", C.c_void_p * 16), ("extaerlw", C.c_void_p * 16),
-                   ("idx_cw", (C.c_int * NSLOT) * MAXBIN)])
+                   ("idx_cw", (C.c_int * NSLOT) * MAXBIN), ("laer", C.c_void_p * 6)])
 
 
 EXPORTS_OPTICS = ["rrtmg_hip_optics_init", "rrtmg_hip_optical_averaging", "rrtmg_hip_optics_finalize",
@@ -84,7 +84,8 @@ def optical_averaging(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
                       aer_op_opt=1, stream=None, idx_cw=None, **outputs):
     """chem: (num_chem, nj_m, nk_m, ni_m) C-order == Fortran chem(i,k,j,species); idx[bin][slot] 1-based species
     numbers (0 = not carried) in the SPECIES order; idx_cw: the same for the cloud-borne counterparts ("_cw" tracers,
-    added to the interstitial ones; None = none); outputs by registry name: tauaer1..4, waer1..4, gaer1..4,
+    added to the interstitial ones; None = none); l2aer..l7aer: (4, nj_m, nk_m, ni_m) == Fortran (i,k,j,4), Legendre
+    moments of the phase function (all six or none); outputs by registry name: tauaer1..4, waer1..4, gaer1..4,
     extaer1..4, bscoef1..4, tauaerlw1..16, extaerlw1..16 (each group complete or absent)."""
     lib = _lib()
     a = OpticsArgs()
@@ -121,6 +122,9 @@ def optical_averaging(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, 
 
     a.chem, a.alt, a.dz8w = put(chem), put(alt), put(dz8w)
     for n, v in outputs.items():
+        if len(n) == 5 and n[0] == "l" and n[1] in "234567" and n[2:] == "aer":
+            a.laer[int(n[1]) - 2] = put(v)
+            continue
         for stem in _LW_OUT + _SW_OUT:   # 'tauaerlw' before 'tauaer'
             if n.startswith(stem) and n[len(stem):].isdigit():
                 i = int(n[len(stem):]) - 1

@@ -38,6 +38,7 @@ MODULE module_optical_averaging_hip
       TYPE(c_ptr) :: tauaer(4), waer(4), gaer(4), extaer(4), bscoef(4)
       TYPE(c_ptr) :: tauaerlw(16), extaerlw(16)
       INTEGER(c_int) :: idx_cw(aer_nspec, aer_maxbin)     ! C: idx_cw[bin][species]
+      TYPE(c_ptr) :: laer(6)
    END TYPE optics_args
 
    ! mirrors struct rrtmg_hip_modal_args of include/rrtmg_hip.h
@@ -175,10 +176,13 @@ CONTAINS
                        its,ite, jts,jte, kts,kte,                                                &
                        extaer1, extaer2, extaer3, extaer4,                                       &
                        bscoef1, bscoef2, bscoef3, bscoef4,                                       &
-                       extaerlw, idx_cw)
+                       extaerlw, idx_cw, l2aer, l3aer, l4aer, l5aer, l6aer, l7aer)
       INTEGER, INTENT(IN) :: nbin_o, aer_op_opt, num_chem
       INTEGER, INTENT(IN) :: idx(aer_nspec, nbin_o)
       INTEGER, INTENT(IN), OPTIONAL :: idx_cw(aer_nspec, nbin_o)
+      ! Legendre moments of the phase function at the four wavelengths (registry.chem:1382-1387): all six or none
+      REAL, DIMENSION(ims:ime, kms:kme, jms:jme, 4), INTENT(INOUT), OPTIONAL, TARGET ::           &
+            l2aer, l3aer, l4aer, l5aer, l6aer, l7aer
       INTEGER, INTENT(IN) :: ids,ide, jds,jde, kds,kde, ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme, num_chem), INTENT(IN), TARGET :: chem
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme), INTENT(IN), TARGET :: dz8w, alt
@@ -228,6 +232,13 @@ CONTAINS
          a%extaerlw(b) = c_null_ptr
          IF (PRESENT(extaerlw)) a%extaerlw(b) = c_loc(extaerlw(ims, kms, jms, b))
       END DO
+      a%laer = c_null_ptr
+      IF (PRESENT(l2aer)) a%laer(1) = c_loc(l2aer)
+      IF (PRESENT(l3aer)) a%laer(2) = c_loc(l3aer)
+      IF (PRESENT(l4aer)) a%laer(3) = c_loc(l4aer)
+      IF (PRESENT(l5aer)) a%laer(4) = c_loc(l5aer)
+      IF (PRESENT(l6aer)) a%laer(5) = c_loc(l6aer)
+      IF (PRESENT(l7aer)) a%laer(6) = c_loc(l7aer)
       err = c_null_char
       rc = rrtmg_hip_optical_averaging(a, err)
       IF (rc /= 0) CALL fatal_from_c(err)
