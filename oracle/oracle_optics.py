@@ -24,10 +24,11 @@ def _lib():
     l = _baselib()
     if not getattr(l, "_optics_ready", False):
         l.optics_oracle_mie.argtypes = [C.c_double, C.c_double, C.c_double, dp]
-        l.optics_oracle_mie_coated.argtypes = [C.c_double] * 6 + [dp]
-        l.optics_oracle_last_moments.argtypes = [dp]
-        l.optics_oracle_tile_legendre.argtypes = ([C.c_void_p, C.c_int] + [C.c_int] * 9
-                                                  + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp, dp])
+        if hasattr(l, "optics_oracle_mie_coated"):   # (not in the operation-counting build, oracle/count)
+            l.optics_oracle_mie_coated.argtypes = [C.c_double] * 6 + [dp]
+            l.optics_oracle_last_moments.argtypes = [dp]
+            l.optics_oracle_tile_legendre.argtypes = ([C.c_void_p, C.c_int] + [C.c_int] * 9
+                                                      + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp, dp])
         l.optics_oracle_cell.argtypes = [C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, dp, dp]
         l.optics_oracle_tile.argtypes = [C.c_void_p, C.c_int] + [C.c_int] * 9 + [C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp]
         l._optics_ready = True
