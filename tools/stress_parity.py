@@ -1,0 +1,115 @@
+"""Randomised parity sweep, device against oracle: many small random configurations of the three entry points (layer
+counts, tile shapes, clouds with and without radii, night fractions, profiles on / off, clean call on / off, both memory
+modes, all mixing rules), each compared at the tolerance of the GPU tests.  A development aid for spare GPU time, not
+part of the test suite (tests/ covers fixed cases of the same kinds):
+    gpurun -- 'python tools/stress_parity.py --minutes 8 --seed 1 > gpurun_out/stress.log 2>&1'
+Prints a line per case; the last line is "stress: N cases, M failures"."""
+import argparse
+import importlib
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [root, os.path.join(root, "tests")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    wa = importlib.import_module("wrfchem-arc-interactions_amd")
+    from oracle import oracle as orc
+    from oracle import oracle_lw
+    orc.build()
+    from helpers import compare_sw, run_hip_swrad, run_oracle_swrad
+    from helpers_lw import run_hip_lwrad, run_oracle_lwrad
+    from helpers_optics import LEG_NAMES, LW_NAMES, SW_NAMES, run_hip_optics, run_oracle_optics, tile_mask
+
+    tmp = tempfile.mkdtemp(prefix="stress_")
+    sw_tab, lw_tab = os.path.join(tmp, "RRTMG_SW_DATA"), os.path.join(tmp, "RRTMG_LW_DATA")
+    wa.synth.write_sw_data(sw_tab, seed=20260001, real_bytes=8)
+    wa.synth.write_lw_data(lw_tab, seed=20260003, real_bytes=8)
+    wa.engine.rrtmg_swinit(sw_tab, device=0)
+    sw_orc = orc.SwOracle(sw_tab)
+    lw_orc = oracle_lw.LwOracle(lw_tab)
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + 60.0 * args.minutes
+    ncase = nfail = 0
+    while time.time() < t_end:
+        ncase += 1
+        kind = ["sw", "lw", "optics"][int(rng.integers(0, 3))]
+        ni, nj = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+        nk = int(rng.choice([12, 20, 28, 33, 40, 50, 57, 64, 80, 100]))
+        seed = int(rng.integers(1, 2**31 - 1))
+        st = wa.synth.make_wrf_state(ni, nj, nk, seed=seed, night_fraction=float(rng.choice([0.0, 0.1, 0.5])))
+        tile = None
+        if rng.uniform() < 0.3 and ni > 2 and nj > 2:
+            its, jts = int(rng.integers(1, ni)), int(rng.integers(1, nj))
+            tile = dict(its=its, ite=int(rng.integers(its, ni + 1)), jts=jts, jte=int(rng.integers(jts, nj + 1)))
+        desc = f"{kind} {ni}x{nj}x{nk} seed {seed} tile {tile}"
+        try:
+            if kind in ("sw", "lw"):
+                cloud = None
+                if rng.uniform() < 0.5:
+                    cloud = wa.synth_clouds.add_clouds(st, seed=seed + 1, cloudy_fraction=float(rng.choice([0.3, 0.6, 1.0])),
+                                                       with_radii=bool(rng.integers(0, 2)))
+                kw = dict(tile=tile, cloud=cloud, profiles=bool(rng.integers(0, 2)), clean=int(rng.integers(0, 2)),
+                          aer=int(rng.integers(0, 2)))
+                device = bool(rng.integers(0, 2))
+                r4 = cloud is None and rng.uniform() < 0.25     # a stock (REAL*4) build's arrays, cloud-free
+                if r4:
+                    for dd in (st.a2, st.a3):
+                        for n in dd:
+                            dd[n] = dd[n].astype(np.float32).astype(np.float64)
+                rb = 4 if r4 else 8
+                desc += f" cloud {cloud is not None} {kw['profiles']=} {kw['clean']=} {kw['aer']=} {device=} {r4=}"
+                if kind == "sw":
+                    got = run_hip_swrad(wa.engine, st, device=device, real_bytes=rb, **kw)
+                    ref = run_oracle_swrad(sw_orc, st, **kw)
+                else:
+                    wa.engine_lw.rrtmg_lwinit(5000.0, lw_tab, kme=nk + 1, device=0)
+                    nlay = wa.engine_lw.lw_nlayers(nk + 1, 5000.0, real_bytes=rb)
+                    got = run_hip_lwrad(wa.engine_lw, st, device=device, real_bytes=rb, **kw)
+                    ref = run_oracle_lwrad(lw_orc, st, nlay, **kw)
+                # the diffuse surface fluxes are differences of two fluxes a hundred times their size: 1e-8
+                if r4:
+                    compare_sw(got, ref, 3e-7, 1e-6)
+                else:
+                    compare_sw(got, ref, 1e-9, 1e-9, names=[n for n in got if not n.endswith("dif")])
+                    compare_sw(got, ref, 1e-8, 1e-8, names=[n for n in got if n.endswith("dif")])
+            else:
+                nbin = int(rng.choice([4, 8]))
+                nk = min(nk, 20)
+                st = wa.synth.make_wrf_state(ni, nj, nk, seed=seed)
+                wa.engine_optics.optics_init(nbin, device=0)
+                ms = wa.synth_mosaic.make_mosaic_state(st, nbin=nbin, seed=seed + 2)
+                opt = int(rng.choice([1, 2, 3, 4, 5]))
+                leg = rng.uniform() < 0.25
+                device = bool(rng.integers(0, 2))
+                if tile is not None:
+                    tile = dict(tile, kts=int(rng.integers(1, 3)), kte=int(rng.integers(nk - 2, nk + 1)))
+                desc = f"optics {ni}x{nj}x{nk} nbin {nbin} opt {opt} leg {leg} seed {seed} tile {tile} {device=}"
+                names = SW_NAMES + LW_NAMES + (LEG_NAMES if leg else [])
+                got = run_hip_optics(wa, st, ms, aer_op_opt=opt, names=names, tile=tile, device=device)
+                ref = run_oracle_optics(wa, st, ms, mix={1: 0, 3: 0, 2: 1, 4: 1, 5: 2}[opt], legendre=leg, tile=tile)
+                mask = tile_mask(st, ms.alt.shape, tile)
+                for n in names:
+                    g, r = (got[n][:, mask], ref[n][:, mask]) if n in LEG_NAMES else (got[n][mask], ref[n][mask])
+                    tol = 1e-9 + (0 if n in LEG_NAMES else 1e-8 * np.abs(r))
+                    if not (np.isfinite(g).all() and (np.abs(g - r) <= tol + 1e-30).all()):
+                        raise AssertionError(f"{n}: max diff {np.abs(g - r).max():.3e} (rel {np.max(np.abs(g - r) / (np.abs(r) + 1e-300)):.3e})")
+            print(f"ok   {desc}", flush=True)
+        except Exception as e:   # noqa: BLE001 -- every kind of failure is a finding
+            nfail += 1
+            print(f"FAIL {desc}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+    print(f"stress: {ncase} cases, {nfail} failures", flush=True)
+    return 1 if nfail else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
