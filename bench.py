@@ -749,11 +749,14 @@ def main():
                     if do_lw:
                         engl.rrtmg_lwrad(aer_ra_feedback=1, clean_atm_diag=1, icloud=0, **dh, **lin, **lout)
                 host_step()
-                t1 = time.perf_counter()
-                for _ in range(2):
+                reps = []
+                for _ in range(5):   # the host side of this path shares the box's cores with other tenants: median of five
+                    t1 = time.perf_counter()
                     host_step()
-                hs = (time.perf_counter() - t1) / 2
+                    reps.append(time.perf_counter() - t1)
+                hs = float(np.median(reps))
                 line["host_path"] = {"columns_per_s": rows * ni / hs, "columns": rows * ni, "seconds_per_call_pair": hs,
+                                     "best_of_5_columns_per_s": rows * ni / min(reps),
                                      "what": "rrtmg_hip_swrad" + (" + rrtmg_hip_lwrad" if do_lw else "") +
                                              " with mem = 0 (host arrays: packed in j-chunks, staged over PCIe and "
                                              "run on the calling thread's stream, chunks overlapping -- the call the "
@@ -767,10 +770,12 @@ def main():
                     def host_opt():
                         wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **dh, **oh_in, **oh_out)
                     host_opt()
-                    t1 = time.perf_counter()
-                    for _ in range(2):
+                    reps = []
+                    for _ in range(3):
+                        t1 = time.perf_counter()
                         host_opt()
-                    ho = (time.perf_counter() - t1) / 2
+                        reps.append(time.perf_counter() - t1)
+                    ho = float(np.median(reps))
                     line["host_path"]["optics"] = {
                         "columns_per_s": rows * ni / ho, "seconds_per_call": ho,
                         "what": "rrtmg_hip_optical_averaging with mem = 0 on the same rows: the section tracers of every "
