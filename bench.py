@@ -755,8 +755,21 @@ def main():
                     host_step()
                     reps.append(time.perf_counter() - t1)
                 hs = float(np.median(reps))
+                # the same with the arrays pinned in place (RRTMG_HIP_REGISTER_HOST=1, csrc/tile_staging.h: no packing pass on
+                # the host; an opt-in for hosts whose arrays live as long as the run, as WRF's do -- these do)
+                os.environ["RRTMG_HIP_REGISTER_HOST"] = "1"
+                try:
+                    host_step()
+                    reps_reg = []
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        host_step()
+                        reps_reg.append(time.perf_counter() - t1)
+                finally:
+                    os.environ["RRTMG_HIP_REGISTER_HOST"] = "0"
                 line["host_path"] = {"columns_per_s": rows * ni / hs, "columns": rows * ni, "seconds_per_call_pair": hs,
                                      "best_of_5_columns_per_s": rows * ni / min(reps),
+                                     "registered_columns_per_s": rows * ni / float(np.median(reps_reg)),
                                      "what": "rrtmg_hip_swrad" + (" + rrtmg_hip_lwrad" if do_lw else "") +
                                              " with mem = 0 (host arrays: packed in j-chunks, staged over PCIe and "
                                              "run on the calling thread's stream, chunks overlapping -- the call the "

@@ -33,6 +33,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace rrtmg {
@@ -148,6 +149,43 @@ private:
     bool stop_ = false;
 };
 
+// ---- RRTMG_HIP_REGISTER_HOST=1: the caller's arrays pinned in place, no packing ----
+// The packing above is a second pass over every byte on the host (and the scatter a third); on a box whose cores are
+// busy it, not the link or the kernels, sets the pace of a mem = 0 call.  A host model's arrays live as long as the
+// run, so they can be pinned where they are (hipHostRegister, once per array, remembered by base address) and the
+// chunks travel by pitched copies straight between the caller's tile and the device buffers -- the host thread only
+// enqueues.  OPT-IN, because the engine cannot see an array die: memory that is unmapped while registered and mapped
+// again at the same address (a large temporary of a scripting host) would be read through the stale pinning.  Use it
+// where the arrays passed to the engine are allocated once (WRF's grid fields); rrtmg_hip_finalize & co. unpin.
+// An array that cannot be registered still travels correctly (the runtime stages pageable memory itself), only slower.
+inline bool host_registration_enabled()   // (read at every call: a host may switch it per phase)
+{
+    const char *e = std::getenv("RRTMG_HIP_REGISTER_HOST");
+    return e && e[0] == '1';
+}
+struct HostRegistry {
+    std::mutex m;
+    std::unordered_map<const void *, size_t> bytes;   // base address -> registered bytes (0: registration refused)
+    static HostRegistry &instance() { static HostRegistry r; return r; }
+    void ensure(const void *p, size_t n)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        auto it = bytes.find(p);
+        if (it != bytes.end() && (it->second >= n || it->second == 0)) return;
+        if (it != bytes.end()) (void)hipHostUnregister(const_cast<void *>(p));   // grew: pin the larger range
+        const hipError_t e = hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault);
+        if (e != hipSuccess) (void)hipGetLastError();
+        bytes[p] = (e == hipSuccess || e == hipErrorHostMemoryAlreadyRegistered) ? n : 0;
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (auto &kv : bytes)
+            if (kv.second) { if (hipHostUnregister(const_cast<void *>(kv.first)) != hipSuccess) (void)hipGetLastError(); }
+        bytes.clear();
+    }
+};
+
 // ---- per-thread staging buffers and stream ----
 struct StagePool {
     void *pin = nullptr, *dev = nullptr;
@@ -199,6 +237,7 @@ inline StagePool &thread_stage_pool()
 // more (c_abi.hip: stage_pools_release_if_idle); a host must not finalize while other threads are inside a call.
 inline void stage_pools_release()
 {
+    HostRegistry::instance().release_all();
     std::lock_guard<std::mutex> lock(stage_pools_mutex());
     for (StagePool *p : stage_pools()) {
         for (hipStream_t *q : {&p->stream, &p->h2d, &p->d2h})
@@ -269,6 +308,13 @@ public:
     hipError_t begin(long cols_per_chunk)
     {
         if (!pool_) { hipError_t e = open(); if (e != hipSuccess) return e; }
+        direct_ = host_registration_enabled();
+        if (direct_) {
+            for (const Req &r : reqs_)
+                HostRegistry::instance().ensure(r.hin, (size_t)r.nblk * g_.nj_m * r.kext * g_.ni_m * g_.rb);
+            cols_per_chunk += cols_per_chunk / 2;   // every (array, chunk) is a copy of its own: fewer, larger chunks
+                                                    // (measured: 6 000 columns per chunk best, 10 000 too few chunks to overlap)
+        }
         std::stable_partition(reqs_.begin(), reqs_.end(), [](const Req &r) { return r.hout == nullptr; });
         long rows = cols_per_chunk / (g_.ni_t > 0 ? g_.ni_t : 1);
         if (rows < 1) rows = 1;
@@ -293,12 +339,13 @@ public:
         }
         used_ = off;
         StagePool &p = *pool_;
-        if (p.pin_cap < used_) {
+        const size_t pin_need = direct_ ? 4096 : used_;   // (direct: the status words alone)
+        if (p.pin_cap < pin_need) {
             if (p.pin) (void)hipHostFree(p.pin);
             p.pin = nullptr; p.pin_cap = 0;
-            hipError_t e = hipHostMalloc(&p.pin, used_ + used_ / 4, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc(&p.pin, pin_need + pin_need / 4, hipHostMallocDefault);
             if (e != hipSuccess) return e;
-            p.pin_cap = used_ + used_ / 4;
+            p.pin_cap = pin_need + pin_need / 4;
         }
         if (p.dev_cap < used_) {
             if (p.dev) (void)hipFree(p.dev);   // the previous call on these buffers ended with a wait for all of its work
@@ -321,14 +368,19 @@ public:
     {
         const Chunk &ch = chunks_[c];
         StagePool &p = *pool_;
-        copy_chunk(ch, true, false);
+        if (!direct_) copy_chunk(ch, true, false);
         for (size_t r = 0; r < reqs_.size(); ++r) {
             char *d = static_cast<char *>(p.dev) + ch.req_off[r];
             if (reqs_[r].in_target) *reqs_[r].in_target = d;
             if (reqs_[r].out_target) *reqs_[r].out_target = d;
         }
-        hipError_t e = hipMemcpyAsync(static_cast<char *>(p.dev) + ch.off, static_cast<char *>(p.pin) + ch.off,
-                                      ch.end - ch.off, hipMemcpyHostToDevice, p.h2d);
+        hipError_t e = hipSuccess;
+        if (direct_) {
+            for (size_t r = 0; r < reqs_.size() && e == hipSuccess; ++r) e = direct_copy(ch, r, true, p.h2d);
+        } else {
+            e = hipMemcpyAsync(static_cast<char *>(p.dev) + ch.off, static_cast<char *>(p.pin) + ch.off,
+                               ch.end - ch.off, hipMemcpyHostToDevice, p.h2d);
+        }
         if (e == hipSuccess) e = hipEventRecord(p.ev_in[c], p.h2d);
         if (e == hipSuccess) e = hipStreamWaitEvent(p.stream, p.ev_in[c], 0);   // the chunk's kernels wait for it
         return e;
@@ -341,6 +393,11 @@ public:
         hipError_t e = hipEventRecord(p.ev_k[c], p.stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(p.d2h, p.ev_k[c], 0);
         if (e != hipSuccess || ch.out_off == SIZE_MAX) return e;
+        if (direct_) {   // straight into the caller's tile
+            for (size_t r = 0; r < reqs_.size() && e == hipSuccess; ++r)
+                if (reqs_[r].hout) e = direct_copy(ch, r, false, p.d2h);
+            return e;
+        }
         return hipMemcpyAsync(static_cast<char *>(p.pin) + ch.out_off, static_cast<char *>(p.dev) + ch.out_off,
                               ch.end - ch.out_off, hipMemcpyDeviceToHost, p.d2h);
     }
@@ -359,7 +416,8 @@ public:
             const int s = static_cast<const int *>(p.pin)[c];
             if (s != 0) { *status = s; if (chunk) *chunk = c; break; }
         }
-        for (const Chunk &ch : chunks_) copy_chunk(ch, false, true);
+        if (!direct_)
+            for (const Chunk &ch : chunks_) copy_chunk(ch, false, true);
         return hipSuccess;
     }
     size_t staged_bytes() const { return used_; }
@@ -381,6 +439,30 @@ private:
     {
         const size_t b = (size_t)nblk * nj * kext * g_.ni_t * g_.rb;
         return (b + 63) & ~size_t(63);
+    }
+    // direct mode: the chunk's rows of request ri between the caller's array (rows of ni_t elements at a pitch of ni_m;
+    // the (j, k) rows of a block follow one another) and its packed place on the device, one pitched copy per block
+    hipError_t direct_copy(const Chunk &ch, size_t ri, bool to_device, hipStream_t s) const
+    {
+        const Req &r = reqs_[ri];
+        const size_t row = (size_t)g_.ni_t * g_.rb, pitch = (size_t)g_.ni_m * g_.rb;
+        const size_t height = (size_t)ch.nj * r.kext;
+        char *d = static_cast<char *>(pool_->dev) + ch.req_off[ri];
+        for (int b = 0; b < r.nblk; ++b) {
+            const size_t h = ((((size_t)b * g_.nj_m + (g_.j0 + ch.j0)) * r.kext) * g_.ni_m + g_.i0) * g_.rb;
+            char *dd = d + (size_t)b * height * row;
+            hipError_t e;
+            if (row == pitch) {   // the tile spans the memory's i range: one contiguous block
+                if (to_device) e = hipMemcpyAsync(dd, static_cast<const char *>(r.hin) + h, height * row, hipMemcpyHostToDevice, s);
+                else e = hipMemcpyAsync(static_cast<char *>(r.hout) + h, dd, height * row, hipMemcpyDeviceToHost, s);
+            } else if (to_device) {
+                e = hipMemcpy2DAsync(dd, row, static_cast<const char *>(r.hin) + h, pitch, row, height, hipMemcpyHostToDevice, s);
+            } else {
+                e = hipMemcpy2DAsync(static_cast<char *>(r.hout) + h, pitch, dd, row, row, height, hipMemcpyDeviceToHost, s);
+            }
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     // one (request, row) item: the row's kext x nblk segments of ni_t elements
     void copy_row(const Chunk &ch, size_t ri, int j, bool to_pinned) const
@@ -414,6 +496,7 @@ private:
     std::vector<Chunk> chunks_;
     size_t used_ = 0;
     StagePool *pool_ = nullptr;
+    bool direct_ = false;   // RRTMG_HIP_REGISTER_HOST: pitched copies between the caller's arrays and the device
 };
 
 }  // namespace rrtmg
