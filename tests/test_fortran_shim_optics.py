@@ -43,7 +43,10 @@ def test_optics_shim_plumbing_4x4x40(hip_lib, wa, oracle_mod, tmp_path, fflags, 
         f.write(np.ascontiguousarray(ms.dz8w, dtype=dt).tobytes())
     r = subprocess.run([exe, "in.bin", "out.bin"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    raw = np.fromfile(tmp_path / "out.bin", dtype=dt).astype(np.float64).reshape(28, st.nj, st.nk + 1, st.ni)
+    raw = np.fromfile(tmp_path / "out.bin", dtype=dt).astype(np.float64)
+    n3 = st.nj * (st.nk + 1) * st.ni
+    legs = raw[28 * n3:].reshape(6, 4, st.nj, st.nk + 1, st.ni)      # Fortran leg(i,k,j,4,6): l2..l7 at four wavelengths
+    raw = raw[:28 * n3].reshape(28, st.nj, st.nk + 1, st.ni)
     names = ([f"tauaer{w}" for w in range(1, 5)] + [f"gaer{w}" for w in range(1, 5)] + [f"waer{w}" for w in range(1, 5)]
              + [f"tauaerlw{b}" for b in range(1, 17)])
     ref = run_oracle_optics(wa, st, ms)
@@ -52,3 +55,9 @@ def test_optics_shim_plumbing_4x4x40(hip_lib, wa, oracle_mod, tmp_path, fflags, 
         g, e = raw[i], ref[n]
         assert np.all(np.abs(g[mask] - e[mask]) <= rtol * np.abs(e[mask]) + 1e-30), n
         assert np.all(g[~mask] == -7777.0), n
+    # the optional tail of the argument list: idx_cw (all zero: nothing changes) and the six Legendre-moment arrays
+    refl = run_oracle_optics(wa, st, ms, legendre=True)
+    for k in range(6):
+        g, e = legs[k], refl[f"l{k + 2}aer"]
+        assert np.all(np.abs(g[:, mask] - e[:, mask]) <= max(rtol, 1e-9) * 10 + 1e-30), k
+        assert np.all(g[:, ~mask] == -7777.0), k
