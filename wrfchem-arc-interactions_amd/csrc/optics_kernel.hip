@@ -42,6 +42,7 @@ __constant__ double2 c_gw[OPT_NMIE + 10];
 // three conversions and as many multiply-adds per term)
 struct MieN { double en, tnm1, w2, gx, gy; float fen, ftn, fw2, fgx, fgy, pad_; };   // n, 2n - 1, 2n + 1, the two asymmetry weights; the same in fp32 (mixed path)
 __constant__ MieN c_mn[OPT_NMIE + 10];
+__constant__ double c_rn[OPT_NMIE + 10];   // 1 / n
 // the same for the term pair (2q + 1, 2q + 2): the fp32 values as the two halves of packed operands
 struct MieN2 { double en0, en1, tn0, tn1; float fen[2], ftn[2], fw2[2], fgx[2], fgy[2], pad_[2]; };
 constexpr int OPT_NPAIR = (OPT_NMIE + 10) / 2;
@@ -1122,7 +1123,8 @@ __device__ __forceinline__ void csincos(cplx z, cplx &sn, cplx &cs)
     sn = {s * ch, c * sh};
     cs = {c * ch, -s * sh};
 }
-__device__ __noinline__ void log_derivative_down(cplx z, int nstop, double xstop, cplx *D /* [1..nstop] */)
+__device__ __noinline__ void log_derivative_down(cplx z, int nstop, double xstop, cplx *D /* [n * dstride], n = 1..nstop */,
+                                                 int dstride)
 {
     const double base = fmax(xstop, sqrt(cabs2(z)));
     const int nmx = (int)(base + (base > 8. ? 8. * cbrt(base) : 0.)) + 16;
@@ -1132,20 +1134,21 @@ __device__ __noinline__ void log_derivative_down(cplx z, int nstop, double xstop
         const double en = (double)n;
         const cplx nz = {en * zinv.re, en * zinv.im};
         d = csub(nz, crecip(cadd(d, nz)));
-        if (n - 1 <= nstop) D[n - 1] = d;
+        if (n - 1 <= nstop) D[(size_t)(n - 1) * dstride] = d;
     }
 }
 __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, double cby, cplx *Dx1, cplx *Dx2, cplx *Dy2,
                                         double &qext, double &qsca, double &gasy, double &qback,
-                                        cplx *an_out = nullptr, cplx *bn_out = nullptr /* [1..nstop] when given */)
+                                        cplx *an_out = nullptr, cplx *bn_out = nullptr /* [n * cstride], n = 1..nstop, when given */,
+                                        int cstride = 1, int dstride = 1 /* of the three ladders */)
 {
     const cplx x1 = {x * m1.re, x * m1.im}, x2 = {x * m2.re, x * m2.im}, y2 = {y * m2.re, y * m2.im};
     const cplx refrel = cdivc(m2, m1), m2inv = crecip(m2), x2inv = crecip(x2), y2inv = crecip(y2);
     const double ystop = y + 4. * cby + 2.;
     const int nstop = (int)ystop;
-    log_derivative_down(x1, nstop, ystop, Dx1);
-    log_derivative_down(x2, nstop, ystop, Dx2);
-    log_derivative_down(y2, nstop, ystop, Dy2);
+    log_derivative_down(x1, nstop, ystop, Dx1, dstride);
+    log_derivative_down(x2, nstop, ystop, Dx2, dstride);
+    log_derivative_down(y2, nstop, ystop, Dy2, dstride);
     MieAcc A;
     {
         double sn, cs;
@@ -1164,10 +1167,10 @@ __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, do
     bool core_gone = false;
     for (int n = 1; n <= nstop; ++n) {
         const double en = (double)n, tn = 2. * en - 1.;
-        const cplx dy = Dy2[n];
+        const cplx dy = Dy2[(size_t)n * dstride];
         cplx da = dy, db = dy;
         if (!core_gone) {
-            const cplx dx1 = Dx1[n], dx2 = Dx2[n];
+            const cplx dx1 = Dx1[(size_t)n * dstride], dx2 = Dx2[(size_t)n * dstride];
             const cplx tx = {tn * x2inv.re, tn * x2inv.im}, ty = {tn * y2inv.re, tn * y2inv.im};
             const cplx chix2 = csub(cmul(tx, chi1x2), chi0x2), chiy2 = csub(cmul(ty, chi1y2), chi0y2);
             const cplx nx = {en * x2inv.re, en * x2inv.im}, ny = {en * y2inv.re, en * y2inv.im};
@@ -1212,7 +1215,7 @@ __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, do
         A.xb.im += A.sgn * w2 * (an.im - bn.im);
         A.sgn = -A.sgn;
         A.an[0] = an; A.bn[0] = bn;
-        if (an_out) { an_out[n] = an; bn_out[n] = bn; }
+        if (an_out) { an_out[(size_t)n * cstride] = an; bn_out[(size_t)n * cstride] = bn; }
     }
     const double y2i = yinv * yinv;
     qsca = 2. * y2i * A.qs;
@@ -1230,12 +1233,12 @@ __device__ __noinline__ void mie_coated(double x, double y, cplx m1, cplx m2, do
 // N >= nstop + 4 nodes (next multiple of 8), which integrates i(mu) P_k(mu), k <= 7, exactly (i is a polynomial of
 // degree 2 nstop in mu).  The oracle does the same (optics_oracle_last_moments; its chi_1 equals the asymmetry parameter
 // of the series, an independent formula, and the Rayleigh limit gives chi_2 = 1/10: tests/test_optics_oracle.py).
-__device__ __noinline__ void mie_coeffs_down(double x, cplx m, double cbx, cplx *D, cplx *an_out, cplx *bn_out, int &nstop,
-                                             double &qsca)
+__device__ __noinline__ void mie_coeffs_down(double x, cplx m, double cbx, cplx *D, int dstride, cplx *an_out, cplx *bn_out,
+                                             int cstride, int &nstop, double &qsca)
 {
     const double xstop = x + 4. * cbx + 2.;
     nstop = (int)xstop;
-    log_derivative_down({x * m.re, x * m.im}, nstop, xstop, D);
+    log_derivative_down({x * m.re, x * m.im}, nstop, xstop, D, dstride);
     double psi0, psi1, chi0, chi1;
     {
         double sn, cs;
@@ -1248,7 +1251,7 @@ __device__ __noinline__ void mie_coeffs_down(double x, cplx m, double cbx, cplx 
     for (int n = 1; n <= nstop; ++n) {
         const double en = (double)n, tn = 2. * en - 1.;
         const double psi = tn * xinv * psi1 - psi0, chi = tn * xinv * chi1 - chi0;
-        const cplx d = D[n];
+        const cplx d = D[(size_t)n * dstride];
         cplx t = cmul(d, minv);
         t.re += en * xinv;
         const cplx na = {t.re * psi - psi1, t.im * psi};
@@ -1258,134 +1261,194 @@ __device__ __noinline__ void mie_coeffs_down(double x, cplx m, double cbx, cplx 
         const cplx nb = {t.re * psi - psi1, t.im * psi};
         const cplx db = {nb.re + t.im * chi, nb.im - (t.re * chi - chi1)};
         const cplx an = cdivc(na, da), bn = cdivc(nb, db);
-        an_out[n] = an; bn_out[n] = bn;
+        an_out[(size_t)n * cstride] = an; bn_out[(size_t)n * cstride] = bn;
         qs += (2. * en + 1.) * (cabs2(an) + cabs2(bn));
         psi0 = psi1; psi1 = psi; chi0 = chi1; chi1 = chi;
     }
     qsca = 2. * xinv * xinv * qs;
 }
-__device__ __noinline__ void legendre_moments(const cplx *an, const cplx *bn, int nstop, double *chi /* [8] */)
+// Mapping: a WAVE takes one particle at a time with its lanes on the quadrature nodes.  First every lane forms the
+// coefficients of its own cell's particle (lanes = cells, as everywhere in this file) and leaves them in the wave's
+// block of a global work area ([n][a_n | b_n][lane], coalesced); then the wave walks through its 64 particles: lane q
+// carries node mu_q, reads a_n, b_n of the particle at hand (one address for the whole wave), sums the amplitude
+// functions, and six wave reductions give the particle's moments to the lane that owns its cell.  With the lanes on
+// their own particles instead (the first version) every lane ran its own N x nstop loop with the coefficients coming
+// back from per-lane scratch: 865 ms per 1.6 M cells x 4 sections; this way 158 ms.  The normaliser needs no
+// quadrature: the integral of i(mu) is x^2 Q_sca / 2 = sum_n (2n+1) (|a_n|^2 + |b_n|^2).
+constexpr int LEG_WAVES = 2048;                        // workgroups (one wave each) of the launch: grid-stride over cell groups
+                                                       // (2.7 GB of work area at most)
+constexpr int LEG_SLOTS = 5;                           // a_n, b_n and the three derivative ladders
+constexpr size_t LEG_AREA = (size_t)(OPT_NMIE + 2) * LEG_SLOTS * 64;   // cplx per wave: [n][slot][lane]
+__device__ __forceinline__ double wave_sum(double v)
 {
-    const int j = (nstop + 4 + 7) / 8, N = 8 * j;
-    const double *xq = g_gl[0] + 4 * j * (j - 1), *wq = g_gl[1] + 4 * j * (j - 1);
-    double m[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-    for (int q = 0; q < N; ++q) {
-        const double mu = xq[q];
-        double pi0 = 0., pi1 = 1.;
-        cplx s1 = {0., 0.}, s2 = {0., 0.};
-        for (int n = 1; n <= nstop; ++n) {
-            const double en = (double)n;
-            const double tau = en * mu * pi1 - (en + 1.) * pi0;
-            const double c = (2. * en + 1.) / (en * (en + 1.));
-            const cplx a = an[n], b = bn[n];
-            s1.re += c * (a.re * pi1 + b.re * tau); s1.im += c * (a.im * pi1 + b.im * tau);
-            s2.re += c * (a.re * tau + b.re * pi1); s2.im += c * (a.im * tau + b.im * pi1);
-            const double pin = ((2. * en + 1.) * mu * pi1 - (en + 1.) * pi0) / en;
-            pi0 = pi1; pi1 = pin;
-        }
-        const double wi = wq[q] * 0.5 * (cabs2(s1) + cabs2(s2));
-        double p0 = 1., p1 = mu;
-        m[0] += wi;
-        m[1] += wi * mu;
 #pragma unroll
-        for (int k = 2; k < 8; ++k) {
-            const double pk = ((2. * k - 1.) * mu * p1 - (k - 1.) * p0) / k;
-            m[k] += wi * pk;
-            p0 = p1; p1 = pk;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) chi[k] = m[0] > 0. ? m[k] / m[0] : (k == 0 ? 1. : 0.);
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
-__global__ void __launch_bounds__(OPT_THREADS) optics_legendre_kernel(const OpticsKernelArgs a)
+__global__ void __launch_bounds__(64) optics_legendre_kernel(const OpticsKernelArgs a, cplx *work)
 {
-    __shared__ double s_acc[7 * OPT_NSW * OPT_THREADS];   // per wavelength: scattering sum, six weighted moments
-    const long cell = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    __shared__ double s_acc[7 * OPT_NSW * 64];   // per wavelength: scattering sum, six weighted moments; [.][lane]
+    __shared__ cplx s_ab[2 * (OPT_NMIE + 2)];    // a_n, b_n of the particle at hand
+    const int lane = threadIdx.x;
+    // element n of a lane's sequence at [n * LEG_STRIDE]; nothing of it in per-lane scratch: 12 KB of scratch per lane --
+    // the first versions -- throttle the waves a CU may hold
+    constexpr int LEG_STRIDE = LEG_SLOTS * 64;
+    cplx *An = work + (size_t)blockIdx.x * LEG_AREA + lane, *Bn = An + 64, *Da = An + 128, *Db = An + 192, *Dc = An + 256;
     const long ncell = (long)a.ni_t * a.nk_t * a.nj_t;
-    if (cell >= ncell) return;
-    cplx Da[OPT_NMIE + 2], Db[OPT_NMIE + 2], Dc[OPT_NMIE + 2], An[OPT_NMIE + 2], Bn[OPT_NMIE + 2];   // per-lane scratch
-    double *acc = s_acc + threadIdx.x;
-    for (int i = 0; i < 7 * OPT_NSW; ++i) acc[i * OPT_THREADS] = 0.;
-    const int it = (int)(cell % a.ni_t);
-    const long r = cell / a.ni_t;
-    const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
-    const size_t q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+    const long ngroups = (ncell + 63) / 64;
     const size_t sspec = (size_t)a.ni_m * a.nk_m * a.nj_m;
     const int r4 = a.real4;
-    const double alt = ldr(a.alt, q, r4);
     const double pi = 3.14159265358979323846;
-    for (int ib = 0; ib < a.nbin; ++ib) {
-        double vol[OPT_NSPEC];
-        double vdry = 0.;
-#pragma unroll
-        for (int sp = 0; sp < OPT_NSPEC; ++sp) {
-            const int id = a.idx[ib][sp];
-            const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
-            vol[sp] = mass * c_opt.rdens[sp];
-            if (sp != OS_WATER) vdry += vol[sp];
+    double *acc = s_acc + lane;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long cell = grp * 64 + lane;
+        const bool live = cell < ncell;
+        for (int i = 0; i < 7 * OPT_NSW; ++i) acc[i * 64] = 0.;
+        size_t q = 0;
+        double alt = 1.;
+        if (live) {
+            const int it = (int)(cell % a.ni_t);
+            const long r = cell / a.ni_t;
+            const int k = (int)(r % a.nk_t), jt = (int)(r / a.nk_t);
+            q = ((size_t)(a.j0 + jt) * a.nk_m + (a.k0 + k)) * a.ni_m + (a.i0 + it);
+            alt = ldr(a.alt, q, r4);
         }
-        const int idn = a.idx[ib][OS_NUM];
-        double num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
-        if (!(vdry > 1.e-25)) continue;
-        const double vwet = vdry + vol[OS_WATER];
-        const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));
-        double ddry = 1.e4 * cbrt(vpart * (6. / pi));
-        const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
-        if (ddry < dlo || ddry > dhi) {
-            ddry = ddry < dlo ? dlo : dhi;
-            const double dcm = ddry * 1.e-4;
-            num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
-        }
-        const double dwet = ddry * cbrt(vwet * frcp(vdry));
-        const double cbd = cbrt(dwet);
-        const double dcm = dwet * 1.e-4;
-        const double cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);
-        const double vbc = vol[OS_BC], vmat = vwet - vbc;
-#pragma unroll 1
-        for (int w = 0; w < OPT_NSW; ++w) {
-            double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
-            const bool capped = x > OPT_XMAX;
-            x = capped ? OPT_XMAX : x;
-            const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
-            int nstop = (int)(x + 4. * cbx + 2.);
-            double qs;
-            cplx m = mix_index(vol, vwet, a.mix == 2 ? 1 : a.mix, w);   // (mix 2: replaced below)
-            bool coated = false;
-            if (a.mix == 2) {
-                const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
-                if (!(vmat > 1.e-30 * vwet)) m = mbc;
-                else {
-                    double sr = 0., si = 0.;
+        for (int ib = 0; ib < a.nbin; ++ib) {
+            double vol[OPT_NSPEC];
+            double vdry = 0., num = 0.;
+            if (live) {
 #pragma unroll
-                    for (int sp = 0; sp < OPT_NSPEC; ++sp) {
-                        if (sp == OS_BC) continue;
-                        sr += vol[sp] * c_opt.refr[sp][w];
-                        si += vol[sp] * c_opt.refi[sp][w];
-                    }
-                    const double vi = frcp(vmat);
-                    m = {sr * vi, si * vi};
-                    if (vbc > 0.) {
-                        double qe, g, qb;
-                        mie_coated(cbrt(vbc * frcp(vwet)) * x, x, mbc, m, cbx, Da, Db, Dc, qe, qs, g, qb, An, Bn);
-                        coated = true;
-                    }
+                for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+                    const int id = a.idx[ib][sp];
+                    const double mass = id >= 0 ? fmax(ldr(a.chem, (size_t)id * sspec + q, r4), 0.) : 0.;
+                    vol[sp] = mass * c_opt.rdens[sp];
+                    if (sp != OS_WATER) vdry += vol[sp];
                 }
-            }
-            if (!coated) mie_coeffs_down(x, m, cbx, Da, An, Bn, nstop, qs);
-            double chi[8];
-            legendre_moments(An, Bn, nstop, chi);
-            double *s = acc + (size_t)(7 * w) * OPT_THREADS;
-            const double wsca = cross * qs;
-            s[0] += wsca;
+                const int idn = a.idx[ib][OS_NUM];
+                num = idn >= 0 ? fmax(ldr(a.chem, (size_t)idn * sspec + q, r4), 0.) : 0.;
+            } else {
 #pragma unroll
-            for (int kk = 2; kk < 8; ++kk) s[(kk - 1) * OPT_THREADS] += wsca * chi[kk];
+                for (int sp = 0; sp < OPT_NSPEC; ++sp) vol[sp] = 0.;
+            }
+            const bool valid = live && vdry > 1.e-25;
+            double vwet = 1., dwet = 1., cbd = 1., cross = 0., vbc = 0., vmat = 1.;
+            if (valid) {
+                vwet = vdry + vol[OS_WATER];
+                const double vpart = vdry * 1.e-6 * frcp(fmax(num, 1.e-30));
+                double ddry = 1.e4 * cbrt(vpart * (6. / pi));
+                const double dlo = c_opt.dlo_um[ib], dhi = c_opt.dhi_um[ib];
+                if (ddry < dlo || ddry > dhi) {
+                    ddry = ddry < dlo ? dlo : dhi;
+                    const double dcm = ddry * 1.e-4;
+                    num = vdry * 1.e-6 * frcp((pi / 6.) * dcm * dcm * dcm);
+                }
+                dwet = ddry * cbrt(vwet * frcp(vdry));
+                cbd = cbrt(dwet);
+                const double dcm = dwet * 1.e-4;
+                cross = (num * frcp(alt) * 1.e-6) * (0.25 * pi * dcm * dcm);
+                vbc = vol[OS_BC]; vmat = vwet - vbc;
+            }
+            if (!__any(valid)) continue;
+#pragma unroll 1
+            for (int w = 0; w < OPT_NSW; ++w) {
+                // ---- the lanes' own particles: coefficients into the wave's work area ----
+                int nstop = 0;
+                double wsca = 0.;   // cross section x Q_sca / (integral of the intensity): the weight of the node sums
+                if (valid) {
+                    double x = pi * dwet * frcp(c_opt.wavelength_um[w]);
+                    const bool capped = x > OPT_XMAX;
+                    x = capped ? OPT_XMAX : x;
+                    const double cbx = capped ? 6.0822019955734001 /* 225^(1/3) */ : cbd * c_pil[1][w];
+                    nstop = (int)(x + 4. * cbx + 2.);
+                    double qs;
+                    cplx m = mix_index(vol, vwet, a.mix == 2 ? 1 : a.mix, w);   // (mix 2: replaced below)
+                    bool coated = false;
+                    if (a.mix == 2) {
+                        const cplx mbc = {c_opt.refr[OS_BC][w], c_opt.refi[OS_BC][w]};
+                        if (!(vmat > 1.e-30 * vwet)) m = mbc;
+                        else {
+                            double sr = 0., si = 0.;
+#pragma unroll
+                            for (int sp = 0; sp < OPT_NSPEC; ++sp) {
+                                if (sp == OS_BC) continue;
+                                sr += vol[sp] * c_opt.refr[sp][w];
+                                si += vol[sp] * c_opt.refi[sp][w];
+                            }
+                            const double vi = frcp(vmat);
+                            m = {sr * vi, si * vi};
+                            if (vbc > 0.) {
+                                double qe, g, qb;
+                                mie_coated(cbrt(vbc * frcp(vwet)) * x, x, mbc, m, cbx, Da, Db, Dc, qe, qs, g, qb, An, Bn, LEG_STRIDE, LEG_STRIDE);
+                                coated = true;
+                            }
+                        }
+                    }
+                    if (!coated) mie_coeffs_down(x, m, cbx, Da, LEG_STRIDE, An, Bn, LEG_STRIDE, nstop, qs);
+                    // Q_sca = 2 / x^2 sum_n (2n+1)(|a_n|^2 + |b_n|^2) and the integral of i(mu) is that sum
+                    wsca = qs > 0. ? cross * 2. * frcp(x * x) : 0.;
+                    acc[(7 * w) * 64] += cross * qs;
+                }
+                __syncthreads();
+                // ---- the wave on one particle after the other: lanes = quadrature nodes ----
+                unsigned long long todo = __ballot(valid && wsca > 0.);
+                while (todo) {
+                    const int p = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const int ns = __shfl(nstop, p, 64);
+                    const int j = (ns + 4 + 7) / 8, N = 8 * j;
+                    const double *xq = g_gl[0] + 4 * j * (j - 1), *wq = g_gl[1] + 4 * j * (j - 1);
+                    {   // the particle's coefficients into LDS: 64 reads at a time instead of one after the other
+                        const cplx *ap = work + (size_t)blockIdx.x * LEG_AREA + p, *bp = ap + 64;
+                        for (int n = 1 + lane; n <= ns; n += 64) {
+                            s_ab[2 * n] = ap[(size_t)n * LEG_STRIDE];
+                            s_ab[2 * n + 1] = bp[(size_t)n * LEG_STRIDE];
+                        }
+                        __syncthreads();
+                    }
+                    double mk[6] = {0., 0., 0., 0., 0., 0.};
+                    for (int q0 = 0; q0 < N; q0 += 64) {
+                        const int qn = q0 + lane;
+                        const bool on = qn < N;
+                        const double mu = on ? xq[qn] : 0., wg = on ? wq[qn] : 0.;
+                        double pi0 = 0., pi1 = 1.;
+                        cplx s1 = {0., 0.}, s2 = {0., 0.};
+#pragma unroll 4
+                        for (int n = 1; n <= ns; ++n) {
+                            // (per-term constants from the series' records: no division in this loop)
+                            const double en = c_mn[n].en, c = c_mn[n].gx;
+                            const double tau = en * mu * pi1 - (en + 1.) * pi0;
+                            const cplx ca = s_ab[2 * n], cb = s_ab[2 * n + 1];
+                            s1.re += c * (ca.re * pi1 + cb.re * tau); s1.im += c * (ca.im * pi1 + cb.im * tau);
+                            s2.re += c * (ca.re * tau + cb.re * pi1); s2.im += c * (ca.im * tau + cb.im * pi1);
+                            const double pin = (c_mn[n].w2 * mu * pi1 - (en + 1.) * pi0) * c_rn[n];
+                            pi0 = pi1; pi1 = pin;
+                        }
+                        const double wi = wg * 0.5 * (cabs2(s1) + cabs2(s2));
+                        double p0 = mu, p1 = 0.5 * (3. * mu * mu - 1.);   // P_1, P_2
+                        mk[0] += wi * p1;
+#pragma unroll
+                        for (int k = 3; k < 8; ++k) {
+                            const double pk = ((2. * k - 1.) * mu * p1 - (k - 1.) * p0) * (1. / k);
+                            mk[k - 2] += wi * pk;
+                            p0 = p1; p1 = pk;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double tot = wave_sum(mk[k]);
+                        if (lane == p) acc[(7 * w + 1 + k) * 64] += wsca * tot;
+                    }
+                    __syncthreads();   // s_ab is rewritten for the next particle
+                }
+                __syncthreads();   // the work area is rewritten for the next wavelength
+            }
         }
-    }
-    for (int w = 0; w < OPT_NSW; ++w) {
-        const double *s = acc + (size_t)(7 * w) * OPT_THREADS;
-        const double sca = s[0];
-        for (int kk = 2; kk < 8; ++kk)
-            str(a.laer[kk - 2], (size_t)w * sspec + q, r4, sca > 0. ? s[(kk - 1) * OPT_THREADS] * frcp(sca) : 0.);
+        if (live)
+            for (int w = 0; w < OPT_NSW; ++w) {
+                const double sca = acc[(7 * w) * 64];
+                for (int kk = 0; kk < 6; ++kk)
+                    str(a.laer[kk], (size_t)w * sspec + q, r4, sca > 0. ? acc[(7 * w + 1 + kk) * 64] * frcp(sca) : 0.);
+            }
     }
 }
 
@@ -1564,6 +1627,13 @@ hipError_t optics_upload_tables(const OpticsTables &t)
     }
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_mn), mn, sizeof mn);
     if (e != hipSuccess) return e;
+    {
+        static double rn[OPT_NMIE + 10];
+        rn[0] = 0.;
+        for (int n = 1; n < OPT_NMIE + 10; ++n) rn[n] = 1. / (double)n;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_rn), rn, sizeof rn);
+        if (e != hipSuccess) return e;
+    }
     static MieN2 mp[OPT_NPAIR];
     for (int q = 0; q < OPT_NPAIR; ++q) {
         const MieN &a = mn[2 * q + 1], &b = mn[2 * q + 2 < OPT_NMIE + 10 ? 2 * q + 2 : 2 * q + 1];
@@ -1657,9 +1727,17 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     bool any_sw = false, any_lw = false;
     for (int w = 0; w < OPT_NSW; ++w) any_sw = any_sw || a.tauaer[w] || a.extaer[w] || a.bscoef[w];
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
-    if (a.laer[0])   // the Legendre moments, when asked for (fp64 whatever the precision mode)
-        hipLaunchKernelGGL(optics_legendre_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
-                           stream, a);
+    if (a.laer[0]) {   // the Legendre moments, when asked for (fp64 whatever the precision mode)
+        const long ngroups = (ncell + 63) / 64;
+        const unsigned nwg = (unsigned)(ngroups < LEG_WAVES ? ngroups : LEG_WAVES);
+        void *work = nullptr;   // stream-ordered work area: the coefficients of the waves' particles
+        hipError_t e = hipMallocAsync(&work, (size_t)nwg * LEG_AREA * sizeof(cplx), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(optics_legendre_kernel, dim3(nwg), dim3(64), 0, stream, a, static_cast<cplx *>(work));
+        e = hipGetLastError();
+        (void)hipFreeAsync(work, stream);
+        if (e != hipSuccess) return e;
+    }
     if (a.mix == 2) {   // shell_exact: one kernel for all twenty wavelengths, fp64 whatever the precision mode
         if (any_sw || any_lw)
             hipLaunchKernelGGL(optics_shell_kernel, dim3((unsigned)((ncell + OPT_THREADS - 1) / OPT_THREADS)), dim3(OPT_THREADS), 0,
