@@ -1729,9 +1729,14 @@ hipError_t optics_launch(const OpticsKernelArgs &a, hipStream_t stream, int prec
     for (int b = 0; b < OPT_NLW; ++b) any_lw = any_lw || a.tauaerlw[b] || a.extaerlw[b];
     if (a.laer[0]) {   // the Legendre moments, when asked for (fp64 whatever the precision mode)
         const long ngroups = (ncell + 63) / 64;
-        const unsigned nwg = (unsigned)(ngroups < LEG_WAVES ? ngroups : LEG_WAVES);
+        unsigned nwg = (unsigned)(ngroups < LEG_WAVES ? ngroups : LEG_WAVES);
         void *work = nullptr;   // stream-ordered work area: the coefficients of the waves' particles
         hipError_t e = hipMallocAsync(&work, (size_t)nwg * LEG_AREA * sizeof(cplx), stream);
+        while (e == hipErrorOutOfMemory && nwg > 64) {   // a device that cannot spare it: fewer waves, same result
+            (void)hipGetLastError();
+            nwg /= 2;
+            e = hipMallocAsync(&work, (size_t)nwg * LEG_AREA * sizeof(cplx), stream);
+        }
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(optics_legendre_kernel, dim3(nwg), dim3(64), 0, stream, a, static_cast<cplx *>(work));
         e = hipGetLastError();
