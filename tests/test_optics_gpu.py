@@ -263,7 +263,8 @@ def test_optics_full_size_properties_200x200x40(hip_lib, wa):
         np.testing.assert_array_equal(got3[n], got[n][..., perm], err_msg=n)
 
 
-def test_optics_mixed_precision(hip_lib, wa):
+@pytest.mark.parametrize("opt", [1, 2])
+def test_optics_mixed_precision(hip_lib, wa, opt):
     """The "mixed" path (BASELINE configs[4]): psi_n and the upward D_n in fp64, chi_n, a_n, b_n and the sums as packed
     fp32 pairs (two wavelengths / two longwave bands of a particle), the small-argument ladder in packed fp32.  Against the
     fp64 oracle: shortwave optical depths and coefficients within 2e-5 (measured 6e-7), single-scattering albedo and
@@ -272,13 +273,13 @@ def test_optics_mixed_precision(hip_lib, wa):
     _init(wa, 8)
     st = wa.synth.make_wrf_state(9, 6, 30, seed=20260370)
     ms = wa.synth_mosaic.make_mosaic_state(st, nbin=8, seed=20260371)
-    ref64 = run_hip_optics(wa, st, ms)
+    ref64 = run_hip_optics(wa, st, ms, aer_op_opt=opt)
     try:
         wa.engine_optics.optics_precision("mixed")
-        got = run_hip_optics(wa, st, ms)
+        got = run_hip_optics(wa, st, ms, aer_op_opt=opt)
     finally:
         wa.engine_optics.optics_precision("f64")
-    orc = run_oracle_optics(wa, st, ms)
+    orc = run_oracle_optics(wa, st, ms, mix=MIX_OF[opt])
     mask = tile_mask(st, ms.alt.shape)
     worst = 0.0
     for n in SW_NAMES + LW_NAMES:
@@ -295,7 +296,7 @@ def test_optics_mixed_precision(hip_lib, wa):
         assert rel.max() < tol, (n, float(rel.max()))
         assert (g[~big] <= 1e-9 * r.max() + 2 * r[~big]).all(), n
     assert not np.array_equal(got["tauaerlw8"], ref64["tauaerlw8"]) and not np.array_equal(got["tauaer2"], ref64["tauaer2"])
-    again = run_hip_optics(wa, st, ms)
+    again = run_hip_optics(wa, st, ms, aer_op_opt=opt)
     for n in SW_NAMES + LW_NAMES:
         np.testing.assert_array_equal(again[n], ref64[n], err_msg=n)          # switching back restores fp64
 

@@ -1064,7 +1064,11 @@ __device__ __forceinline__ void optics_lw_cell(const OpticsKernelArgs &a, double
             if (!((want >> p) & 1)) continue;
             const int w = OPT_NSW + 2 * p, w2 = w + 1;
             cplx m, mb;
-            if (MIXED) {   // the mixture's index from fp32 volumes: nine registers instead of eighteen across the band loop
+            if (MIXED && a.mix == 0) {   // volume mixing is linear: from fp32 volumes, nine registers instead of eighteen across
+                                         // the band loop.  (Maxwell-Garnett takes the root of a complex number whose
+                                         // imaginary part is small: in fp32 the absorption index of a weakly absorbing
+                                         // mixture -- and with it the longwave absorption -- was off by up to 4e-3;
+                                         // found by tools/stress_parity.py --mixed)
                 const cf32 f1 = mix_index32(volf, (float)vwet, a.mix, w), f2 = mix_index32(volf, (float)vwet, a.mix, w2);
                 m = {(double)f1.re, (double)f1.im}; mb = {(double)f2.re, (double)f2.im};
             } else {
