@@ -62,7 +62,7 @@ def main():
                 kw = dict(tile=tile, cloud=cloud, profiles=bool(rng.integers(0, 2)), clean=int(rng.integers(0, 2)),
                           aer=int(rng.integers(0, 2)))
                 device = bool(rng.integers(0, 2))
-                r4 = cloud is None and rng.uniform() < 0.25     # a stock (REAL*4) build's arrays, cloud-free
+                r4 = rng.uniform() < 0.25     # a stock (REAL*4) build's arrays (with clouds: single-precision McICA seeds)
                 if r4:
                     for dd in (st.a2, st.a3):
                         for n in dd:
@@ -71,15 +71,15 @@ def main():
                 desc += f" cloud {cloud is not None} {kw['profiles']=} {kw['clean']=} {kw['aer']=} {device=} {r4=}"
                 if kind == "sw":
                     got = run_hip_swrad(wa.engine, st, device=device, real_bytes=rb, **kw)
-                    ref = run_oracle_swrad(sw_orc, st, **kw)
+                    ref = run_oracle_swrad(sw_orc, st, seed_real4=int(r4), **kw)
                 else:
                     wa.engine_lw.rrtmg_lwinit(5000.0, lw_tab, kme=nk + 1, device=0)
                     nlay = wa.engine_lw.lw_nlayers(nk + 1, 5000.0, real_bytes=rb)
                     got = run_hip_lwrad(wa.engine_lw, st, device=device, real_bytes=rb, **kw)
-                    ref = run_oracle_lwrad(lw_orc, st, nlay, **kw)
+                    ref = run_oracle_lwrad(lw_orc, st, nlay, seed_real4=int(r4), **kw)
                 # the diffuse surface fluxes are differences of two fluxes a hundred times their size: 1e-8
                 if r4:
-                    compare_sw(got, ref, 3e-7, 1e-6)
+                    compare_sw(got, ref, 3e-7, 2e-4 if cloud is not None else 1e-6)
                 else:
                     compare_sw(got, ref, 1e-9, 1e-9, names=[n for n in got if not n.endswith("dif")])
                     compare_sw(got, ref, 1e-8, 1e-8, names=[n for n in got if n.endswith("dif")])
@@ -97,12 +97,20 @@ def main():
                 desc = f"optics {ni}x{nj}x{nk} nbin {nbin} opt {opt} leg {leg} seed {seed} tile {tile} {device=}"
                 names = SW_NAMES + LW_NAMES + (LEG_NAMES if leg else [])
                 wa.engine_optics.optics_precision("mixed" if args.mixed else "f64")
-                got = run_hip_optics(wa, st, ms, aer_op_opt=opt, names=names, tile=tile, device=device)
+                o4 = (not args.mixed) and rng.uniform() < 0.2
+                if o4:
+                    ms.chem = ms.chem.astype(np.float32).astype(np.float64)
+                    ms.alt = ms.alt.astype(np.float32).astype(np.float64)
+                    ms.dz8w = ms.dz8w.astype(np.float32).astype(np.float64)
+                    desc += " r4"
+                got = run_hip_optics(wa, st, ms, aer_op_opt=opt, names=names, tile=tile, device=device, real_bytes=4 if o4 else 8)
                 ref = run_oracle_optics(wa, st, ms, mix={1: 0, 3: 0, 2: 1, 4: 1, 5: 2}[opt], legendre=leg, tile=tile)
                 mask = tile_mask(st, ms.alt.shape, tile)
                 for n in names:
                     g, r = (got[n][:, mask], ref[n][:, mask]) if n in LEG_NAMES else (got[n][mask], ref[n][mask])
                     tol = 1e-9 + (0 if n in LEG_NAMES else 1e-8 * np.abs(r))
+                    if o4:
+                        tol = 3e-7 * np.abs(r) + 1e-6 * (1.0 if n in LEG_NAMES else np.abs(r).max())
                     if args.mixed:   # the bounds of tests/test_optics_gpu.py::test_optics_mixed_precision
                         rel = 2e-4 if n.startswith("bscoef") else (1e-4 if "lw" in n else 2e-5)
                         tol = 1e-5 if n.startswith(("waer", "gaer")) else rel * np.abs(r) + 1e-9 * np.abs(r).max()
