@@ -59,6 +59,20 @@ def main():
                 if rng.uniform() < 0.5:
                     cloud = wa.synth_clouds.add_clouds(st, seed=seed + 1, cloudy_fraction=float(rng.choice([0.3, 0.6, 1.0])),
                                                        with_radii=bool(rng.integers(0, 2)))
+                if cloud is not None and rng.uniform() < 0.4:   # the hydrometeor variants of the wrapper (SW:10461-10492, 10883-10898)
+                    variant = ["f_ice_phy", "fer_hires", "cammgmp", "warm_rain"][int(rng.integers(0, 4))]
+                    if variant == "f_ice_phy":
+                        cloud.update(f_ice_phy=1, absent=("qi3d",))
+                        st.a3["qs3d"] = st.a3["qs3d"] + st.a3["qi3d"]
+                    elif variant == "fer_hires":
+                        cloud.update(mp_physics=5)
+                    elif variant == "cammgmp":
+                        cloud.update(is_cammgmp_used=1)
+                        st.a3["lradius"] = rng.uniform(1.0, 70.0, st.a3["qc3d"].shape)
+                        st.a3["iradius"] = rng.uniform(2.0, 160.0, st.a3["qc3d"].shape)
+                    else:
+                        cloud.update(warm_rain=True)
+                    desc += f" {variant}"
                 kw = dict(tile=tile, cloud=cloud, profiles=bool(rng.integers(0, 2)), clean=int(rng.integers(0, 2)),
                           aer=int(rng.integers(0, 2)))
                 device = bool(rng.integers(0, 2))
