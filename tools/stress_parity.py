@@ -43,7 +43,7 @@ def main():
     ncase = nfail = 0
     while time.time() < t_end:
         ncase += 1
-        kind = "optics" if args.mixed else ["sw", "lw", "optics"][int(rng.integers(0, 3))]
+        kind = "optics" if args.mixed else ["sw", "lw", "optics", "routes"][int(rng.integers(0, 4))]
         ni, nj = int(rng.integers(1, 9)), int(rng.integers(1, 7))
         nk = int(rng.choice([12, 20, 28, 33, 40, 50, 57, 64, 80, 100]))
         seed = int(rng.integers(1, 2**31 - 1))
@@ -54,7 +54,54 @@ def main():
             tile = dict(its=its, ite=int(rng.integers(its, ni + 1)), jts=jts, jte=int(rng.integers(jts, nj + 1)))
         desc = f"{kind} {ni}x{nj}x{nk} seed {seed} tile {tile}"
         try:
-            if kind in ("sw", "lw"):
+            if kind == "routes":
+                # the shortwave call's other input routes, cloud-free: six ECMWF aerosol types (aer_opt 1, SW:9313-9340),
+                # band-resolved aerosol (aer_opt 2 / 3, SW:10982-10991), SSiB spectral albedos (SW:10692-10703), each
+                # with or without the WRF-Chem arrays, both memory modes, sub-tiles
+                import torch
+                from helpers import AER, IN2, IN3, alloc_outputs, dims_of
+                chem = int(rng.integers(0, 2))
+                arrays = {n: st.a2[n] for n in IN2}
+                arrays.update({n: st.a3[n] for n in IN3 + (AER if chem else [])})
+                route = ["aerod", "aer3d", "ssib"][int(rng.integers(0, 3))]
+                shp2, shp3 = st.a2["albedo"].shape, (st.nj, st.nk + 1, st.ni)
+                if route == "aerod":
+                    e = np.zeros((6,) + shp3)
+                    z = np.arange(st.nk)[None, :, None] / st.nk
+                    for ia, (amp, scale) in enumerate([(0.2, 0.08), (0.1, 0.06), (0.3, 0.3), (0.1, 0.04), (0.02, 0.6), (0.01, 0.8)]):
+                        e[ia, :, :st.nk, :] = rng.uniform(0, amp, (st.nj, 1, st.ni)) * np.exp(-z / scale) / st.nk * 4
+                    e[:, :, :, ::4] = 0.0
+                    arrays["aerod"] = e
+                elif route == "aer3d":
+                    tau = np.zeros((14,) + shp3)
+                    tau[:, :, :st.nk, :] = rng.uniform(0.0, 0.03, size=(14, st.nj, st.nk, st.ni))
+                    tau[:, :, :, ::3] = 0.0
+                    arrays.update(tauaer3d_sw=tau, ssaaer3d_sw=rng.uniform(0.7, 1.0, size=tau.shape),
+                                  asyaer3d_sw=rng.uniform(0.5, 0.85, size=tau.shape))
+                else:
+                    arrays["xland"] = np.where(rng.uniform(size=shp2) < 0.6, 1.0, 2.0)
+                    for nm, lo, hi in (("alswvisdir", 0.03, 0.25), ("alswvisdif", 0.03, 0.25), ("alswnirdir", 0.15, 0.55),
+                                       ("alswnirdif", 0.15, 0.55)):
+                        arrays[nm] = rng.uniform(lo, hi, shp2)
+                device = bool(rng.integers(0, 2))
+                profiles = bool(rng.integers(0, 2))
+                desc = f"routes {route} {ni}x{nj}x{nk} seed {seed} chem {chem} tile {tile} {device=} {profiles=}"
+                d = dims_of(st, tile)
+                ref, out = alloc_outputs(st, profiles), alloc_outputs(st, profiles)
+                orc.swrad_tile(sw_orc, d, arrays, 1370.0, chem, 1, ref)
+                if device:
+                    dev_in = {n: torch.from_numpy(np.ascontiguousarray(v)).cuda() for n, v in arrays.items()}
+                    dev_out = {n: torch.from_numpy(v).cuda() for n, v in out.items()}
+                    wa.engine.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=chem, clean_atm_diag=1, icloud=0, **d, **dev_in, **dev_out)
+                    wa.engine.sw_status()
+                    got = {n: v.cpu().numpy() for n, v in dev_out.items()}
+                else:
+                    wa.engine.rrtmg_swrad(solcon=1370.0, aer_ra_feedback=chem, clean_atm_diag=1, icloud=0, **d,
+                                          **{n: np.ascontiguousarray(v) for n, v in arrays.items()}, **out)
+                    got = out
+                compare_sw(got, ref, 1e-9, 1e-9, names=[n for n in got if not n.endswith("dif")])
+                compare_sw(got, ref, 1e-8, 1e-8, names=[n for n in got if n.endswith("dif")])
+            elif kind in ("sw", "lw"):
                 cloud = None
                 if rng.uniform() < 0.5:
                     cloud = wa.synth_clouds.add_clouds(st, seed=seed + 1, cloudy_fraction=float(rng.choice([0.3, 0.6, 1.0])),
