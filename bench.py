@@ -789,8 +789,19 @@ def main():
                         host_opt()
                         reps.append(time.perf_counter() - t1)
                     ho = float(np.median(reps))
+                    os.environ["RRTMG_HIP_REGISTER_HOST"] = "1"
+                    try:
+                        host_opt()
+                        reps_reg = []
+                        for _ in range(3):
+                            t1 = time.perf_counter()
+                            host_opt()
+                            reps_reg.append(time.perf_counter() - t1)
+                    finally:
+                        os.environ["RRTMG_HIP_REGISTER_HOST"] = "0"
                     line["host_path"]["optics"] = {
                         "columns_per_s": rows * ni / ho, "seconds_per_call": ho,
+                        "registered_columns_per_s": rows * ni / float(np.median(reps_reg)),
                         "what": "rrtmg_hip_optical_averaging with mem = 0 on the same rows: the section tracers of every "
                                 "cell over PCIe in, 28 fields per cell out"}
                     line["host_path"]["whole_step_columns_per_s"] = rows * ni / (hs + ho)
