@@ -107,9 +107,12 @@ extern "C" int rrtmg_hip_lw_init(const char *data_path, int data_real_bytes, dou
     }
     if (!st.dStatus) HIPCHK(hipMalloc(&st.dStatus, sizeof(int)));
     HIPCHK(hipMemset(st.dStatus, 0, sizeof(int)));
+    if (!st.dPairs) HIPCHK(hipMalloc(&st.dPairs, (size_t)(LW_NTBL + 1) * 2 * sizeof(double)));
+    HIPCHK(lw_fill_pairs(static_cast<double *>(st.dPairs), host.bpade));
     st.dev.K = static_cast<const double *>(st.dK);
     st.dev.exp_tbl = static_cast<const double *>(st.dExp);
     st.dev.tfn_tbl = static_cast<const double *>(st.dTfn);
+    st.dev.tbl_pairs = static_cast<const double *>(st.dPairs);
     st.dev.totplnk = static_cast<const double *>(st.dPlk);
     st.dev.chi_mls = static_cast<const double *>(st.dChi);
     st.dev.gdesc = static_cast<const LwGDesc *>(st.dG);
@@ -409,7 +412,7 @@ extern "C" int rrtmg_hip_lw_status(char *err)
 extern "C" int rrtmg_hip_lw_finalize(void)
 {
     LwState &st = lw_state();
-    void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus, &st.dCld};
+    void **ps[] = {&st.dK, &st.dExp, &st.dTfn, &st.dPlk, &st.dChi, &st.dG, &st.dStatus, &st.dCld, &st.dPairs};
     for (auto &kv : st.dJump) if (kv.second) (void)hipFree(kv.second);
     st.dJump.clear();
     for (void **p : ps) { if (*p) (void)hipFree(*p); *p = nullptr; }

@@ -73,6 +73,7 @@ struct LwGDesc {
 struct LwDeviceTables {
     const double *K;
     const double *exp_tbl, *tfn_tbl;   // tau_tbl is not needed by cloud-free columns (LW:3284-3296)
+    const double *tbl_pairs;           // [LW_NTBL + 1][2]: (1 - exp_tbl, tfn_tbl) as the kernels evaluate them (lw_fill_pairs)
     const double *totplnk;             // [16][181]
     const double *chi_mls;             // [7][59]
     const LwGDesc *gdesc;

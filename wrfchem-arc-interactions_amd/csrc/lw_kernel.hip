@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "lw_common.h"
 #include "lw_kernel.h"
@@ -205,9 +206,7 @@ struct LCol {   // LDS image of the column
     double *pz;        // [nl+1]
     double *mul;       // [LS_COUNT][nl]
     double *rat;       // [LR_COUNT][2][nl]
-    double *planklay;  // [16][nl]
-    double *planklev;  // [16][nl+1]
-    double *taua;      // [16][nl]
+    double *q4;        // [16][nl4][4]: planklay, dplankdn, dplankup, taua (lw_kernel.h)
     double *secdiff, *plankbnd;   // [16]
     double *wrk;       // [2][nl] scratch for the column sums
     double *tz;        // [nl+1] level temperatures
@@ -239,11 +238,8 @@ __device__ __forceinline__ LCol carve_gas(double *base, double *rec, int nl, boo
     c.cont = stage_cont ? p : nullptr; p += stage_cont ? 3 * CONT_DOUBLES : 0;
     int *q = reinterpret_cast<int *>(p);
     c.rb0 = q; q += nl; c.rb1 = q; q += nl; c.inds = q; q += nl; c.indf = q; q += nl; c.indm = q; q += nl;
-    double *r = rec;
-    c.planklay = r; r += LW_NBND * nl;
-    c.planklev = r; r += LW_NBND * (nl + 1);
-    c.taua = r; r += LW_NBND * nl;
-    c.secdiff = r; r += LW_NBND; c.plankbnd = r; r += LW_NBND;
+    c.secdiff = rec; c.plankbnd = rec + LW_NBND;
+    c.q4 = rec + lw_rec_q4_offset(nl);
     c.flux = nullptr;
     return c;
 }
@@ -253,13 +249,12 @@ __device__ __forceinline__ LCol carve_rt(double *base, int nl, bool cloud)
     LCol c{};
     c.nl = nl;
     double *p = base;
-    c.planklay = p; p += LW_NBND * nl;
-    c.planklev = p; p += LW_NBND * (nl + 1);
-    c.taua = p; p += LW_NBND * nl;
     c.secdiff = p; p += LW_NBND; c.plankbnd = p; p += LW_NBND;
     c.pz = p; p += nl + 1;
-    // after the cloud part of the record when there is one; [3 waves][4 or 6][nl+1]
-    c.flux = base + (cloud ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
+    c.q4 = base + lw_rec_q4_offset(nl);
+    // after the image of the whole record; [3 waves][4 or 6][nl+1]
+    c.flux = base + lw_rec_doubles(nl);
+    (void)cloud;
     return c;
 }
 
@@ -549,32 +544,52 @@ __device__ __forceinline__ void gas_item_binary(const LwDeviceTables &tb, const 
     frac = fmode == 2 ? mad2(ppd[17 * PP_LAYERS + l], sub2(fr1, fr0), fr0) : (fmode == 1 ? G.fracconst : zero);
 }
 
-// absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
-__device__ __forceinline__ void layer_src(const LwDeviceTables &tb, double tau, double secdiff, double plfrac,
-                                          double blay, double dplankup, double dplankdn, double &atrans,
-                                          double &bbd, double &bbu)
+// One entry of the pair table (lw_fill_pairs): what layer_src needs of exp_tbl(itr) / tfn_tbl(itr) -- the absorptivity
+// 1 - exp_tbl(itr) and tfn_tbl(itr), formed by the arithmetic the kernels use when they re-evaluate an entry from its
+// index, so a table read and a re-evaluation give the same bits.
+__device__ __forceinline__ double2 lw_pair_entry(double bpade, int itr)
 {
-    double odepth = secdiff * tau;
-    odepth = odepth < 0.0 ? 0.0 : odepth;
-    double tblind = fdiv(odepth, tb.bpade + odepth);
-    int itr = (int)(10000.0 * tblind + 0.5);
     const bool last = itr >= LW_NTBL;
     itr = last ? LW_NTBL - 1 : itr;
-    const bool small = odepth <= 0.06;
-    // The reference reads exp_tbl(itr) and tfn_tbl(itr) (10 001-entry tables, LW:7940-7957).  A 64-lane
-    // gather of random entries costs more texture-addresser time than recomputing the entry, so the
-    // quantised table value is re-evaluated from its index: same itr, the formulas of rrtmg_lw_ini with
-    // tfn = itr/10000 substituted (tau = bpade*itr/(10000-itr)) and the two quotients of tfn_tbl,
-    // 1/tau - trans/(1-trans), taken over one common denominator.
     const double fi = (double)itr;
-    const double tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
+    const double tau_t = (bpade * fi) * frcp(10000.0 - fi);
     double transc = fmax(exp_neg(tau_t), 1.e-20);
     const double omt = 1. - transc;
     double tausfac_t = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp1(tau_t * omt));
     transc = last ? 1.e-20 : transc;
     tausfac_t = last ? 1.0 : tausfac_t;
-    atrans = small ? odepth - 0.5 * odepth * odepth : 1. - transc;
-    double tausfac = small ? 0.166667 * odepth : tausfac_t;
+    return make_double2(1. - transc, tausfac_t);
+}
+
+// absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
+// ltbl: the pair table in LDS (lw_rt_fast_kernel, cloud-free instantiation) or nullptr (compile-time in either case)
+template <bool USE_TBL>
+__device__ __forceinline__ void layer_src(const LwDeviceTables &tb, const double2 *ltbl, double tau, double secdiff,
+                                          double plfrac, double blay, double dplankup, double dplankdn, double &atrans,
+                                          double &bbd, double &bbu)
+{
+#ifdef RTF_PROBE_NOCOMPUTE
+    atrans = tau * 1.e-3; bbd = plfrac * blay; bbu = bbd + dplankup + dplankdn * secdiff; return;
+#endif
+    double odepth = secdiff * tau;
+    odepth = odepth < 0.0 ? 0.0 : odepth;
+    double tblind = fdiv(odepth, tb.bpade + odepth);
+    int itr = (int)(10000.0 * tblind + 0.5);
+    const bool small = odepth <= 0.06;
+    // The reference reads exp_tbl(itr) and tfn_tbl(itr) (10 001-entry tables, LW:7940-7957).  A 64-lane gather of
+    // random entries from memory costs the vector cache more than re-evaluating the entry costs the SIMD, so the
+    // kernels either read the pair from a copy of the table in LDS (160 KB: a CU's whole LDS, which the sixteen-wave
+    // workgroup of lw_rt_fast_kernel has to itself anyway) or re-evaluate the quantised value from its index: same itr,
+    // the formulas of rrtmg_lw_ini with tfn = itr/10000 substituted (tau = bpade*itr/(10000-itr)) and the two quotients
+    // of tfn_tbl, 1/tau - trans/(1-trans), taken over one common denominator.
+    double2 e;
+    if constexpr (USE_TBL) {
+        e = ltbl[(unsigned)itr > (unsigned)LW_NTBL ? LW_NTBL : itr];   // (0 <= itr <= 10000 for every finite odepth >= 0)
+        asm("" : "+v"(e.x), "+v"(e.y));   // (one 16-byte read for every lane, not two reads and a branch on `small`)
+    }
+    else e = lw_pair_entry(tb.bpade, itr);
+    atrans = small ? odepth - 0.5 * odepth * odepth : e.x;
+    double tausfac = small ? 0.166667 * odepth : e.y;
     // small branch: plfrac*(blay + dplank*odepth_rec); table branch: plfrac*(blay + tausfac*dplank)
     bbd = small ? plfrac * (blay + dplankdn * tausfac) : plfrac * (blay + tausfac * dplankdn);
     bbu = small ? plfrac * (blay + dplankup * tausfac) : plfrac * (blay + tausfac * dplankup);
@@ -736,21 +751,36 @@ __device__ __forceinline__ double adjcol(double col, double coldry, double chire
 // layer's regime (lower / upper atmosphere, decided by the column's laytrop) interpolates it, else the descriptor's
 // constant (the gas kernel does not store those).
 struct FracSrc {
-    bool lo2, up2;
-    double fclo, fcup;
+    double c_lo, c_up;      // the constant of the regime (0 where the fraction is stored, or where it is zero)
+    bool st_lo, st_up;      // stored in the scratch (fdel doubles behind the lane's taug slot)
     int ltrop;
+    ptrdiff_t fdel;         // (the same for every lane: scalar registers)
 };
-__device__ __forceinline__ FracSrc frac_src(const LwGDesc *gd, double laytrop)
+__device__ __forceinline__ FracSrc frac_src(const LwGDesc *gd, double laytrop, ptrdiff_t fdel)
 {
     const int mlo = (gd->lo.cfg >> LC_FRAC_SHIFT) & 3, mup = (gd->up.cfg >> LC_FRAC_SHIFT) & 3;
-    return FracSrc{mlo == 2, mup == 2, mlo == 1 ? gd->lo.fracconst : 0., mup == 1 ? gd->up.fracconst : 0., (int)laytrop};
+    return FracSrc{mlo == 1 ? gd->lo.fracconst : 0., mup == 1 ? gd->up.fracconst : 0., mlo == 2, mup == 2, (int)laytrop, fdel};
 }
-__device__ __forceinline__ double frac_at(const FracSrc &F, const double *fr, int k, int ng)
+// The Planck fraction of layer k from a pointer to the lane's taug slot of that layer.  The load is unconditional and
+// from the scratch in every lane, and its value is used in every lane (times 0 where the fraction is a constant: those
+// lanes read their finite taug slot again -- same line, no traffic).  A conditional load came out of the compiler as a
+// FLAT load from "the scratch or a stack slot holding the constant", and with a flat load in flight every wait of the
+// loop is vmcnt(0): the layer fetched one iteration ahead was waited for right after its issue (r03: the transfer
+// kernel "waits on its reads").
+// (in two halves, so that a loop can issue the read ahead and touch the value only when the layer's turn comes)
+#ifdef RTF_PROBE_NT
+#define RTF_LD(p) __builtin_nontemporal_load(p)
+#else
+#define RTF_LD(p) (*(p))
+#endif
+__device__ __forceinline__ double frac_read(const FracSrc &F, const double *tgk, int k)
+{
+    return RTF_LD(tgk + ((k < F.ltrop ? F.st_lo : F.st_up) ? F.fdel : (ptrdiff_t)0));
+}
+__device__ __forceinline__ double frac_value(const FracSrc &F, double v, int k)
 {
     const bool lower = k < F.ltrop;
-    double f = lower ? F.fclo : F.fcup;
-    if (lower ? F.lo2 : F.up2) f = fr[(size_t)k * ng];
-    return f;
+    return __builtin_fma(v, (lower ? F.st_lo : F.st_up) ? 1. : 0., lower ? F.c_lo : F.c_up);
 }
 
 // column slot of this workgroup within the batch: consecutive slots stay on one XCD (its own L2)
@@ -788,6 +818,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     if (a.colmap) col = a.colmap[col];   // entry of the call's column list (cloud_lists.h)
     double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
     LCol c = carve_gas(lds, rec, nl, a.stage_cont != 0);
+    const size_t nl4 = lw_rec_q4_layers(nl);
 
     const int it = col % a.ni_t, jt = col / a.ni_t;
     const size_t i0 = (size_t)(a.its - a.ims + it), j0 = (size_t)(a.jts - a.jms + jt), k0 = (size_t)(a.kts - a.kms);
@@ -844,7 +875,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             }
             const bool on = t[0] > 1.e-9 && t[15] > 1.e-9;
 #pragma unroll
-            for (int nb = 0; nb < LW_NBND; ++nb) c.taua[nb * nl + k] = on ? t[nb] : 0.;
+            for (int nb = 0; nb < LW_NBND; ++nb) c.q4[((size_t)nb * nl4 + k) * 4 + 3] = on ? t[nb] : 0.;
         }
     }
     LW_STAMP(1);
@@ -1135,33 +1166,35 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         for (int item = tid - 64; item < LW_NBND * nl; item += LW_THREADS - 64) {
             const int ib = item / nl, k = item - ib * nl;
             const double *P = tb.totplnk + ib * 181;
-            const double tz_t = c.tz[k + 1];
-            const double tavel = k <= nk - 2 ? c.tav[k] : 0.5 * (tz_t + c.tz[k]);
+            const double tz_b = c.tz[k], tz_t = c.tz[k + 1];
+            const double tavel = k <= nk - 2 ? c.tav[k] : 0.5 * (tz_t + tz_b);
             int indlay = (int)(tavel - 159.);
             indlay = indlay < 1 ? 1 : (indlay > 180 ? 180 : indlay);
             const double tlayfrac = tavel - 159. - (double)indlay;
-            int indlev = (int)(tz_t - 159.);
-            indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
-            const double tlevfrac = tz_t - 159. - (double)indlev;
-            const double dbdtlev = P[indlev] - P[indlev - 1];
             const double dbdtlay = P[indlay] - P[indlay - 1];
-            c.planklay[ib * nl + k] = P[indlay - 1] + tlayfrac * dbdtlay;
-            c.planklev[ib * (nl + 1) + k + 1] = P[indlev - 1] + tlevfrac * dbdtlev;
+            const double blay = P[indlay - 1] + tlayfrac * dbdtlay;
+            // the level below and the level above (every inner level is formed twice, by its two layers, alike)
+            double plev[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const double tz = m == 0 ? tz_b : tz_t;
+                int indlev = (int)(tz - 159.);
+                indlev = indlev < 1 ? 1 : (indlev > 180 ? 180 : indlev);
+                const double tlevfrac = tz - 159. - (double)indlev;
+                const double dbdtlev = P[indlev] - P[indlev - 1];
+                plev[m] = P[indlev - 1] + tlevfrac * dbdtlev;
+            }
+            double *q = c.q4 + ((size_t)ib * nl4 + k) * 4;
+            q[0] = blay; q[1] = plev[0] - blay; q[2] = plev[1] - blay;
         }
-        if (tid >= 128 && tid < 128 + LW_NBND) {   // the surface level and the boundary
+        if (tid >= 128 && tid < 128 + LW_NBND) {   // the boundary
             const int ib = tid - 128;
             const double *P = tb.totplnk + ib * 181;
-            const double tz0 = c.tz[0];
             int indbound = (int)(tbound - 159.);
             indbound = indbound < 1 ? 1 : (indbound > 180 ? 180 : indbound);
             const double tbndfrac = tbound - 159. - (double)indbound;
-            int indlev0 = (int)(tz0 - 159.);
-            indlev0 = indlev0 < 1 ? 1 : (indlev0 > 180 ? 180 : indlev0);
-            const double t0frac = tz0 - 159. - (double)indlev0;
-            double dbdtlev = P[indbound] - P[indbound - 1];
+            const double dbdtlev = P[indbound] - P[indbound - 1];
             c.plankbnd[ib] = semiss * (P[indbound - 1] + tbndfrac * dbdtlev);
-            dbdtlev = P[indlev0] - P[indlev0 - 1];
-            c.planklev[ib * (nl + 1)] = P[indlev0 - 1] + t0frac * dbdtlev;
         }
     }
     LW_STAMP(3);
@@ -1192,7 +1225,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         // another order decides the same way unless it is zero to rounding)
         for (int nb = 0; nb < LW_NBND; ++nb) {
             double v = 0.;
-            for (int k = lane; k < nk; k += 64) v += c.taua[nb * nl + k];
+            for (int k = lane; k < nk; k += 64) v += c.q4[((size_t)nb * nl4 + k) * 4 + 3];
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
             if (lane == 0 && v < 0.) atomicMax(a.status, 1 + col);
@@ -1322,7 +1355,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const int nslot = a.icloud != 0 ? 6 : 4;   // flux slots per wave: + clear-sky down / up with clouds
     {
         const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
-        const int n = (int)(a.icloud != 0 ? lw_rec_doubles(nl) : lw_rec_base_doubles(nl));
+        const int n = (int)lw_rec_doubles(nl);   // (the cloud part is written only when icloud != 0; it is not read otherwise)
         for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
     }
     // cloud part of the record: cldf clwp ciwp cswp fliq fice fsno iliq iice isno [nl] each, seeds[4]
@@ -1352,10 +1385,10 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
     const double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
-    const FracSrc FS = frac_src(gd, c.pz[nl + 1]);   // laytrop follows pz in the record
+    const FracSrc FS = frac_src(gd, c.pz[nl + 1], fr - tg);   // laytrop follows pz in the record
     const double secdiff = c.secdiff[band];
     double *fl = c.flux + (size_t)wave * nslot * nlev;   // down clean, down total, up clean, up total, down clear, up clear
-    const double *pl = c.planklay + band * nl, *pv = c.planklev + band * nlev, *ta = c.taua + band * nl;
+    const double *q4 = c.q4 + (size_t)band * lw_rec_q4_layers(nl) * 4;   // planklay, dplankdn, dplankup, taua per layer
 
     // McICA (generate_stochastic_clouds, LW:2208-2578, icld = 2): this lane's sub-column of binary cloud over the
     // model layers (the buffer layers above carry none); lmask = layers in which any sub-column is cloudy
@@ -1403,20 +1436,20 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     double radld_c = 0., radld_t = 0., radclr = 0., frac0 = 0.;
     bool iclddn = false;
     if (lane == 0) { fl[0 * nlev + nl] = 0.; fl[1 * nlev + nl] = 0.; if (nslot == 6) fl[4 * nlev + nl] = 0.; }
-    double tnext = tg[(size_t)(nl - 1) * ng], fnext = frac_at(FS, fr, nl - 1, ng);
+    double tnext = tg[(size_t)(nl - 1) * ng], fnext = frac_read(FS, tg + (size_t)(nl - 1) * ng, nl - 1);
     for (int k = nl - 1; k >= 0; --k) {
-        const double taug = tnext, plfrac = fnext;
-        if (k > 0) { tnext = tg[(size_t)(k - 1) * ng]; fnext = frac_at(FS, fr, k - 1, ng); }
-        const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+        const double taug = tnext, plfrac = frac_value(FS, fnext, k);
+        if (k > 0) { tnext = tg[(size_t)(k - 1) * ng]; fnext = frac_read(FS, tg + (size_t)(k - 1) * ng, k - 1); }
+        const double blay = q4[4 * k], dplankdn = q4[4 * k + 1], dplankup = q4[4 * k + 2], tak = q4[4 * k + 3];
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
             double at, bbd, bbu;
-            layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
+            layer_src<false>(tb, nullptr, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);   // taut, LW:11004-11008
             radld_t = relax(radld_t, bbd, at);
             radclr = iclddn ? relax(radclr, bbd, at) : radld_t;   // LW:3304-3311
             if (clean_on) {
                 // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-                if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                if (__any(tak != 0.)) layer_src<false>(tb, nullptr, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                 radld_c = relax(radld_c, bbd, at);
             }
         } else {
@@ -1429,7 +1462,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
                 efcl = 1. - exp_neg(odcld);
             }
             LwCldSrc s;
-            layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
             double gassrc = s.bbd * s.atrans;
             radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
             radclr = radclr + (s.bbd - radclr) * s.atrans;
@@ -1464,18 +1497,18 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     }
     // ---- upward sweep (surface -> top), LW:3331-3356 ----
     for (int k = 0; k < nl; ++k) {   // tnext / fnext hold layer 0 after the downward sweep
-        const double taug = tnext, plfrac = fnext;
-        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * ng]; fnext = frac_at(FS, fr, k + 1, ng); }
-        const double blay = pl[k], dplankup = pv[k + 1] - blay, dplankdn = pv[k] - blay;
+        const double taug = tnext, plfrac = frac_value(FS, fnext, k);
+        if (k + 1 < nl) { tnext = tg[(size_t)(k + 1) * ng]; fnext = frac_read(FS, tg + (size_t)(k + 1) * ng, k + 1); }
+        const double blay = q4[4 * k], dplankdn = q4[4 * k + 1], dplankup = q4[4 * k + 2], tak = q4[4 * k + 3];
         const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (col_cloudy && deep && k < 128 && ((s_lmask[1] >> (k - 64)) & 1));
         if (!lay_cld) {
             double at, bbd, bbu;
-            layer_src(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+            layer_src<false>(tb, nullptr, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
             radlu_t = relax(radlu_t, bbu, at);
             radclru = col_cloudy ? relax(radclru, bbu, at) : radlu_t;   // LW:3348-3354 (iclddn of the column)
             if (clean_on) {
                 // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-                if (__any(ta[k] != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                if (__any(tak != 0.)) layer_src<false>(tb, nullptr, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                 radlu_c = relax(radlu_c, bbu, at);
             }
         } else {
@@ -1487,7 +1520,7 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
                 efcl = 1. - exp_neg(odcld);
             }
             LwCldSrc s;
-            layer_src_cld(tb, taug + ta[k], secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
             double gassrc = s.bbugas * s.atrans;
             radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
             radclru = radclru + (s.bbugas - radclru) * s.atrans;
@@ -1566,11 +1599,6 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
 // 2.05 waves per SIMD).  Every spectral sum is taken per chunk, i.e. inside a row, and the nine chunk sums of a column
 // are added in chunk order: a column's sums are formed the same way whichever rows it has (results do not depend on
 // the tiling of the domain).
-// What the upward sweep works from: the (A, S) pairs the downward sweep stored in the scratch slots of the gas optics
-// (true: no second evaluation of the layer optics, but 2 x 35 GB more HBM traffic per 250 000 columns x 63 layers -- the
-// kernel then runs at the memory system's pace: measured 33.8 ms), or the gas optics read a second time with the
-// layer optics evaluated again (false: 4.4 G more wave-instructions, 49 GB less traffic).
-constexpr bool RTF_STORE_UP = false;
 constexpr int RTF_COLS = 7, RTF_WAVES = 16, RTF_THREADS = RTF_WAVES * 64, RTF_CHUNK = 16, RTF_NCHUNK = 9;
 static_assert(RTF_CHUNK * RTF_NCHUNK >= LW_NGPT && RTF_CHUNK * (RTF_NCHUNK - 1) < LW_NGPT, "chunks must cover the g-points");
 static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4, "a row per chunk");
@@ -1579,6 +1607,7 @@ static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4, "a row per chunk");
 // The per-band arrays of the column record (Planck functions, aerosol optical depth) are NOT staged: the lanes of a
 // band read the same address, a wave's load touches a handful of lines that the workgroup's other waves find in L1,
 // and without them two workgroups fit a CU whatever the layer count (staged, 3 x 25 KB at 63 layers left one).
+static_assert(LW_RTF_NCHUNK == RTF_NCHUNK, "lw_flux_doubles (lw_kernel.h) sizes the flux slots of RTF_NCHUNK chunks");
 __host__ __device__ inline size_t rtf_cloud_doubles(int nl) { return (size_t)10 * nl + 4; }
 __host__ __device__ inline size_t rtf_col_doubles(int nl, bool cloud)
 {
@@ -1607,9 +1636,14 @@ __device__ __forceinline__ double row_sum4(double v0, double v1, double v2, doub
     return y;
 }
 
-template <bool DEEP, bool CLOUD>   // CLOUD: McICA (icloud != 0); the cloud-free instantiation carries none of it
+// TBL (cloud-free instantiation): the pair table of layer_src -- 10 001 x (1 - exp_tbl, tfn_tbl), 160 016 bytes -- fills
+// the workgroup's LDS, and the flux slots live in the column's block of the scratch instead (lw_flux_doubles: written
+// by one lane in four once per four layers, read by the epilogue; they never leave L2).  An evaluation of the layer
+// optics is then ~25 instructions instead of ~80 (r03: three evaluations per (layer, g-point) were half of the kernel).
+template <bool DEEP, bool CLOUD, bool TBL>   // CLOUD: McICA (icloud != 0); the cloud-free instantiation carries none of it
 __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 {
+    static_assert(!(TBL && CLOUD), "the pair table and the staged cloud state do not fit one LDS");
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1621,6 +1655,12 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int ncols = nbatch - RTF_COLS * grp < RTF_COLS ? nbatch - RTF_COLS * grp : RTF_COLS;   // 1..7
     const size_t recn = cloud ? rtf_cloud_doubles(nl) : 0;   // staged part of the record
     const size_t cold = rtf_col_doubles(nl, cloud);
+    const double2 *const LTBL = TBL ? reinterpret_cast<const double2 *>(lds) : nullptr;
+    if (TBL) {
+        const double2 *src = reinterpret_cast<const double2 *>(tb.tbl_pairs);
+        double2 *dst = reinterpret_cast<double2 *>(lds);
+        for (int q = tid; q <= LW_NTBL; q += RTF_THREADS) dst[q] = src[q];
+    }
     if (cloud)
         for (int cc = 0; cc < ncols; ++cc) {
             const double *rec = a.rec + (size_t)(RTF_COLS * grp + cc) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl);
@@ -1642,7 +1682,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int slot = RTF_COLS * grp + colsel;
     int col = a.col0 + slot;
     if (a.colmap) col = a.colmap[col];   // (an existing entry: slot is clamped to the group's columns)
-    const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: planklay planklev taua secdiff plankbnd pz
+    const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: secdiff plankbnd pz laytrop [cloud] q4
     const double *cb = lds + colsel * cold;
     const int r4 = a.real4;
     double semiss;
@@ -1652,23 +1692,38 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         semiss = ldr(a.emiss, i2, r4);
     }
     const LwGDesc *gd = tb.gdesc + g;
+#ifdef RTF_PROBE_LAYERMAJOR
+    const int band = gd->band, ng = LW_NGPT;
+#else
     const int band = gd->band, ng = gd->ng;
+#endif
     const double wgt = live ? 0.5 * gd->delwave : 0.;
     // the clean-sky call differs from the one with aerosol only if there is aerosol; without it the reference's
     // two calls are the same arithmetic on the same numbers, and the outputs are copies
     const bool clean_on = a.clean > 0, clean_own = clean_on && a.aer_ra_feedback == 1;
     const int nlev = nl + 1;
     // scratch of the column, band-major: [band][layer][ig] (lw_kernel.h)
+#ifdef RTF_PROBE_LAYERMAJOR
+    const size_t sbase = (size_t)slot * nl * LW_NGPT + g;
+#else
     const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
+#endif
     double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
-    const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1]);
+#ifdef RTF_PROBE_NOFRAC
+    const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1], 0);
+#else
+    const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1], fr - tg);
+#endif
     // per chunk: downward and upward flux of the call with aerosol at every level, then the small sums
     // [0..2] clean sky: surface down, surface up, top up; [4..6] clear sky alike
     const size_t ws = 2 * nlev + 8;
-    double *const fl = lds + colsel * cold + recn + (size_t)chunk * ws;   // this seat's slots
-    const double *pl = rec + band * nl, *pv = rec + LW_NBND * nl + band * nlev, *ta = rec + LW_NBND * (nl + nlev) + band * nl;
-    const double secdiff = rec[LW_NBND * (2 * nl + nlev) + band], plankbnd = rec[LW_NBND * (2 * nl + nlev) + LW_NBND + band];
+    double *fl;                                                           // this seat's slots
+    if constexpr (TBL) fl = a.flx + (size_t)slot * lw_flux_doubles(nl) + (size_t)chunk * ws;
+    else fl = lds + colsel * cold + recn + (size_t)chunk * ws;
+    // the lane's band in the packed part of the record: per layer (planklay, dplankdn) and (dplankup, taua)
+    const double2 *const q4 = reinterpret_cast<const double2 *>(rec + lw_rec_q4_offset(nl)) + (size_t)band * lw_rec_q4_layers(nl) * 2;
+    const double secdiff = rec[band], plankbnd = rec[LW_NBND + band];
 
     uint64_t cmask = 0;
     constexpr bool deep = DEEP;
@@ -1713,31 +1768,40 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     bool iclddn = false;
     if (writer && jw == 0) fl[nl] = 0.;
     const int nblk = (nl + 3) >> 2;
-    // the layer's inputs are fetched one layer ahead: gas optics from the scratch, Planck functions and aerosol
-    // optical depth of the lane's band from the column record
-    // (one layer ahead; two layers ahead, in either issue order, was measured slower: 30.2 against 28.0 ms)
-    double tnext = tg[(size_t)(nl - 1) * ng], fnext = frac_at(FS, fr, nl - 1, ng);
-    double blnext = pl[nl - 1], pvnext = pv[nl - 1], tanext = ta[nl - 1], pvhi = pv[nl];
+    // The layer's inputs are fetched ahead.  The gas optics come from HBM, 16 bytes per lane and layer: a whole block of
+    // four layers ahead (T4 / F4 hold the block in turn, the reads of the next one are in flight meanwhile) -- with one
+    // layer ahead the kernel had 16 KB in flight per CU and ran at the 2.9 TB/s that allows (Little's law at ~2 us),
+    // whatever its instruction count.  The Planck functions and the aerosol optical depth of the lane's band come from
+    // the column record, which the lanes of a band share (L1 / L2 hits): one layer ahead.
+    const double *tgw = tg + (size_t)(4 * (nblk - 1)) * ng;   // the lane's taug slot of the block's first layer
+    double T4[4], F4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = 4 * (nblk - 1) + j;
+        T4[j] = 0.; F4[j] = 0.;
+        if (k < nl) { T4[j] = RTF_LD(tgw + j * ng); F4[j] = frac_read(FS, tgw + j * ng, k); }
+    }
+    double2 qa = q4[2 * (nl - 1)], qb = q4[2 * (nl - 1) + 1];
     for (int b = nblk - 1; b >= 0; --b) {
         double v[4] = {0., 0., 0., 0.};
+        double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
+        if (b > 0) {
+            tgw -= 4 * ng;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { Tn[j] = RTF_LD(tgw + j * ng); Fn[j] = frac_read(FS, tgw + j * ng, 4 * (b - 1) + j); }
+        }
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
             const int k = b * 4 + j;
             if (k < nl) {
-                const double taug = tnext, plfrac = fnext, blay = blnext, pvlo = pvnext, tak = tanext;
-                if (k > 0) {
-                    tnext = tg[(size_t)(k - 1) * ng]; fnext = frac_at(FS, fr, k - 1, ng);
-                    blnext = pl[k - 1]; pvnext = pv[k - 1]; tanext = ta[k - 1];
-                }
-                const double dplankup = pvhi - blay, dplankdn = pvlo - blay;
-                pvhi = pvlo;
+                const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
+                const double blay = qa.x, dplankdn = qa.y, dplankup = qb.x, tak = qb.y;
+                if (k > 0) { qa = q4[2 * (k - 1)]; qb = q4[2 * (k - 1) + 1]; }
                 const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
-                double up_a, up_s;   // what the upward sweep needs of this layer
                 if (!lay_cld) {
                     double at, bbd, bbu;
-                    layer_src(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                    layer_src<TBL>(tb, LTBL, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                     radld_t = relax(radld_t, bbd, at);
-                    up_a = at; up_s = bbu;
                     if (col_cloudy) {
                         radclr = iclddn ? relax(radclr, bbd, at) : radld_t;   // LW:3304-3311
                         ek = __builtin_fma(bbu * at, trk, ek);
@@ -1745,7 +1809,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     }
                     if (clean_own) {
                         // without aerosol in this layer (buffer layers, clean air) the clean call equals the one above
-                        if (__any(tak != 0.)) layer_src(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                        if (__any(tak != 0.)) layer_src<TBL>(tb, LTBL, taug, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                         radld_c = relax(radld_c, bbd, at);
                         ec = __builtin_fma(bbu * at, trc, ec);
                         trc = __builtin_fma(-trc, at, trc);
@@ -1762,12 +1826,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     LwCldSrc s;
                     layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                     double gassrc = s.bbd * s.atrans;
-                    up_a = s.atrans + efcl * (1. - s.atrans);
-                    radld_t = radld_t - radld_t * up_a + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
-                    {
-                        const double gasu = s.bbugas * s.atrans;
-                        up_s = gasu + cfm * (s.bbutot * s.atot - gasu);
-                    }
+                    radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
                     radclr = radclr + (s.bbd - radclr) * s.atrans;
                     ek = __builtin_fma(s.bbugas * s.atrans, trk, ek);
                     trk = __builtin_fma(-trk, s.atrans, trk);
@@ -1781,7 +1840,6 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         trc = __builtin_fma(-trc, A, trc);
                     }
                 }
-                if (RTF_STORE_UP && live) { tg[(size_t)k * ng] = up_a; fr[(size_t)k * ng] = up_s; }
                 v[j] = wgt * radld_t;
                 frac0 = plfrac;
             }
@@ -1789,6 +1847,10 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         // downward flux at the bottom of the block's layers = levels 4b .. 4b+3
         const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
         if (writer && b * 4 + jw < nl) fl[b * 4 + jw] = qs;
+        if (b > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
+        }
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
     const double rad0 = frac0 * plankbnd;
@@ -1805,48 +1867,36 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         }
     }
     // ---- upward sweep (surface -> top), LW:3331-3356: the call with aerosol ----
-    if (RTF_STORE_UP) {
-        // from the stored (A, bbu | S): each lane reads back what it stored itself (program order, no fence needed)
-        double anext = tg[0], snext = fr[0];
+    // (the gas optics are read a second time and the layer optics evaluated again: with the pair table that is 25
+    // instructions; storing (A, S) on the way down instead was 46 GB more traffic and slower, r03)
+    {
+        // T4 / F4 hold block 0 after the downward sweep, qa / qb layer 0
+#ifdef RTF_PROBE_NOUP
+        for (int b = 0; b < (nl > 10000 ? nblk : 0); ++b) {
+#else
         for (int b = 0; b < nblk; ++b) {
+#endif
             double v[4] = {0., 0., 0., 0.};
+            double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
+            if (b + 1 < nblk) {
+                tgw += 4 * ng;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = b * 4 + j;
-                if (k < nl) {
-                    const double A = anext, S = snext;
-                    if (k + 1 < nl) { anext = tg[(size_t)(k + 1) * ng]; snext = fr[(size_t)(k + 1) * ng]; }
-                    const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
-                    if (!lay_cld) radlu_t = relax(radlu_t, S, A);
-                    else radlu_t = radlu_t - radlu_t * A + S;
-                    v[j] = live ? wgt * radlu_t : 0.;   // (an idle lane reads slots it does not own)
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * (b + 1) + j;
+                    if (k < nl) { Tn[j] = RTF_LD(tgw + j * ng); Fn[j] = frac_read(FS, tgw + j * ng, k); }
                 }
             }
-            // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
-            const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
-            if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
-        }
-    } else {
-        // tnext / fnext / blnext / tanext hold layer 0 after the downward sweep, pvhi the level below it
-        double pvlo = pvhi;
-        pvnext = pv[1];
-        for (int b = 0; b < nblk; ++b) {
-            double v[4] = {0., 0., 0., 0.};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = b * 4 + j;
                 if (k < nl) {
-                    const double taug = tnext, plfrac = fnext, blay = blnext, tak = tanext, pvup = pvnext;
-                    if (k + 1 < nl) {
-                        tnext = tg[(size_t)(k + 1) * ng]; fnext = frac_at(FS, fr, k + 1, ng);
-                        blnext = pl[k + 1]; pvnext = pv[k + 2]; tanext = ta[k + 1];
-                    }
-                    const double dplankup = pvup - blay, dplankdn = pvlo - blay;
-                    pvlo = pvup;
+                    const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
+                    const double blay = qa.x, dplankdn = qa.y, dplankup = qb.x, tak = qb.y;
+                    if (k + 1 < nl) { qa = q4[2 * (k + 1)]; qb = q4[2 * (k + 1) + 1]; }
                     const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
                     if (!lay_cld) {
                         double at, bbd, bbu;
-                        layer_src(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
+                        layer_src<TBL>(tb, LTBL, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                         radlu_t = relax(radlu_t, bbu, at);
                     } else {
                         const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
@@ -1867,6 +1917,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             // upward flux at the top of the block's layers = levels 4b+1 .. 4b+4
             const double qs = row_sum4(v[0], v[1], v[2], v[3], lane);
             if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
         }
     }
     if (bad && live) atomicMax(a.status, (bad << 28) | (1 + col));
@@ -1884,7 +1936,9 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
         const size_t base3 = ej0 * sj + k0 * sk + ei0;
         const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 2);
-        const double *f0 = lds + ec_col * cold + recn;
+        const double *f0;
+        if constexpr (TBL) f0 = a.flx + (size_t)(RTF_COLS * grp + ec_col) * lw_flux_doubles(nl);
+        else f0 = lds + ec_col * cold + recn;
         const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
         // the chunk sums in chunk order
         auto tot = [&](size_t q) {
@@ -1927,13 +1981,29 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 
 __global__ void __launch_bounds__(LW_THREADS) lw_rt_kernel(const LwKernelArgs a) { lw_rt_body<false>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false, false>(a); }
+lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, false>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lw_rt_fast_cld_kernel(const LwKernelArgs a) { lw_rt_fast<false, true>(a); }
+lw_rt_fast_tbl_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, true>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true, true>(a); }
+lw_rt_fast_cld_kernel(const LwKernelArgs a) { lw_rt_fast<false, true, false>(a); }
+__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true, true, false>(a); }
 __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
+
+// the pair table of layer_src, filled once at init by the arithmetic the kernels use for a re-evaluated entry
+__global__ void lw_fill_pairs_kernel(double *out, double bpade)
+{
+    const int itr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (itr > LW_NTBL) return;
+    reinterpret_cast<double2 *>(out)[itr] = lw_pair_entry(bpade, itr);
+}
+hipError_t lw_fill_pairs(double *out, double bpade)
+{
+    hipLaunchKernelGGL(lw_fill_pairs_kernel, dim3((LW_NTBL + 256) / 256), dim3(256), 0, nullptr, out, bpade);
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
 
 // ---------------------------------------------------------------------------
 size_t lw_gas_lds_bytes(int nl, bool stage_cont)
@@ -1949,8 +2019,7 @@ size_t lw_rt_fast_lds_bytes(int nl, bool cloud)
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
-    if (!cloud) return (lw_rec_base_doubles(nl) + (size_t)3 * 4 * (nl + 1)) * sizeof(double);
-    return (lw_rec_doubles(nl) + (size_t)3 * 6 * (nl + 1)) * sizeof(double);
+    return (lw_rec_doubles(nl) + (size_t)3 * (cloud ? 6 : 4) * (nl + 1)) * sizeof(double);
 }
 
 // band descriptors and the order of the gas-optics segments (see lw_gas_kernel)
@@ -2044,36 +2113,44 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
     a.stage_cont = lw_gas_lds_bytes(nl, true) + 64 <= 160 * 1024 / 4 ? 1 : 0;
     const size_t lds_gas = lw_gas_lds_bytes(nl, a.stage_cont != 0), lds_rt = lw_rt_lds_bytes(nl, a.icloud != 0);
     const size_t lds_fast = lw_rt_fast_lds_bytes(nl, a.icloud != 0);
-    static size_t attr_gas = 0, attr_rt = 0, attr_fast = 0;
-    if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_gas_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gas);
-        if (e != hipSuccess) return e;
-        attr_gas = lds_gas;
-    }
-    if (lds_rt > attr_rt && lds_rt > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_deep_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rt);
-        if (e != hipSuccess) return e;
-        attr_rt = lds_rt;
-    }
+    // the cloud-free transfer kernel with the pair table in LDS (RRTMG_HIP_LW_TABLE=0: the re-evaluating one)
+    static const bool use_tbl = [] { const char *e = std::getenv("RRTMG_HIP_LW_TABLE"); return !(e && e[0] == '0'); }();
+    const size_t lds_tbl = (size_t)(LW_NTBL + 1) * 2 * sizeof(double);
     // the three-column transfer kernel holds three column records; beyond what a workgroup may have (very deep
     // columns) the one-column kernel serves the call
     const bool fast_fits = lds_fast <= 160 * 1024 - 2048;
-    if (fast_fits && lds_fast > attr_fast && lds_fast > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_cld_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_rt_fast_deep_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast);
-        if (e != hipSuccess) return e;
-        attr_fast = lds_fast;
+    {
+        // opt-in to more than 48 KB of dynamic LDS, once per size: concurrent tile threads launch from here (mem = 0
+        // calls run outside the engine lock), so the bookkeeping has its own lock; the launches stay outside it
+        static std::mutex attr_mutex;
+        static size_t attr_gas = 0, attr_rt = 0, attr_fast = 0, attr_tbl = 0;
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        auto opt_in = [](const void *f, size_t bytes) {
+            return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        };
+        if (lds_gas > attr_gas && lds_gas > 48 * 1024) {
+            hipError_t e = opt_in(reinterpret_cast<const void *>(lw_gas_kernel), lds_gas);
+            if (e != hipSuccess) return e;
+            attr_gas = lds_gas;
+        }
+        if (lds_rt > attr_rt && lds_rt > 48 * 1024) {
+            hipError_t e = opt_in(reinterpret_cast<const void *>(lw_rt_kernel), lds_rt);
+            if (e == hipSuccess) e = opt_in(reinterpret_cast<const void *>(lw_rt_deep_kernel), lds_rt);
+            if (e != hipSuccess) return e;
+            attr_rt = lds_rt;
+        }
+        if (fast_fits && lds_fast > attr_fast && lds_fast > 48 * 1024) {
+            hipError_t e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_kernel), lds_fast);
+            if (e == hipSuccess) e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_cld_kernel), lds_fast);
+            if (e == hipSuccess) e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_deep_kernel), lds_fast);
+            if (e != hipSuccess) return e;
+            attr_fast = lds_fast;
+        }
+        if (use_tbl && attr_tbl == 0) {
+            hipError_t e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_tbl_kernel), lds_tbl);
+            if (e != hipSuccess) return e;
+            attr_tbl = lds_tbl;
+        }
     }
     const bool deep = a.icloud != 0 && a.nk > 64;
     if (!scratch || cap_cols <= 0) return hipErrorInvalidValue;
@@ -2087,12 +2164,16 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
     a.taug = scratch;
     a.frac = a.taug + (size_t)cap_cols * nl * LW_NGPT;
     a.rec = a.frac + (size_t)cap_cols * nl * LW_NGPT;
+    a.flx = a.rec + (size_t)cap_cols * lw_rec_doubles(nl);
     for (int c0 = 0; c0 < ncol; c0 += cap_cols) {
         const int n = ncol - c0 < cap_cols ? ncol - c0 : cap_cols;
         a.col0 = c0;
         a.nbatch = n;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
-        if (!a.lwupflx && fast_fits) {   // no layer-flux profiles requested: what the radiation driver calls
+        if (!a.lwupflx && a.icloud == 0 && use_tbl) {   // no layer-flux profiles requested, no McICA
+            const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
+            hipLaunchKernelGGL(lw_rt_fast_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
+        } else if (!a.lwupflx && fast_fits) {   // no layer-flux profiles requested: what the radiation driver calls
             const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
             if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
             else if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);

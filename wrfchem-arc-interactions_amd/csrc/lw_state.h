@@ -27,6 +27,7 @@ struct LwState {
     LwDeviceTables dev{};
     void *dK = nullptr, *dExp = nullptr, *dTfn = nullptr, *dPlk = nullptr, *dChi = nullptr, *dG = nullptr,
          *dStatus = nullptr;
+    void *dPairs = nullptr;                // LwDeviceTables::tbl_pairs
     void *dCld = nullptr;                  // cloud absorption coefficient tables (lw_cloud_tables)
     std::map<int, void *> dJump;           // KISS jump tables by NLAYERS (guarded by scratch_mutex)
     // Scratch between the two kernels (taug, frac, column record), one grow-only buffer per stream: calls
