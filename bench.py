@@ -767,6 +767,8 @@ def main():
                         reps_reg.append(time.perf_counter() - t1)
                 finally:
                     os.environ["RRTMG_HIP_REGISTER_HOST"] = "0"
+                    # the registry remembers arrays by address: tell it before these are freed
+                    wa.engine.unregister_host(*[v for d in (hin, hout, lin, lout) for v in d.values()])
                 line["host_path"] = {"columns_per_s": rows * ni / hs, "columns": rows * ni, "seconds_per_call_pair": hs,
                                      "best_of_5_columns_per_s": rows * ni / min(reps),
                                      "registered_columns_per_s": rows * ni / float(np.median(reps_reg)),
@@ -799,6 +801,7 @@ def main():
                             reps_reg.append(time.perf_counter() - t1)
                     finally:
                         os.environ["RRTMG_HIP_REGISTER_HOST"] = "0"
+                        wa.engine.unregister_host(*oh_in.values(), *oh_out.values())
                     line["host_path"]["optics"] = {
                         "columns_per_s": rows * ni / ho, "seconds_per_call": ho,
                         "registered_columns_per_s": rows * ni / float(np.median(reps_reg)),

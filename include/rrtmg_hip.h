@@ -339,6 +339,11 @@ int rrtmg_hip_optics_table_info(double *wavelength_um20, double *refindex_9x20x2
  * SLURM_LOCALID, LOCAL_RANK) modulo the visible device count, else 0. */
 int rrtmg_hip_pick_device(void);
 
+/* Opt-in RRTMG_HIP_REGISTER_HOST=1 (mem = 0 calls): the caller's arrays are pinned in place (hipHostRegister) and
+ * remembered by base address until the finalize calls.  A host that frees such an array earlier tells the engine
+ * first; unknown addresses are ignored.  No reference counterpart (WRF's grid fields live as long as the run). */
+int rrtmg_hip_unregister_host(const void *base);
+
 int rrtmg_hip_finalize(void);
 
 /* version / build info: "rrtmg_hip <ver> gfx950" */

@@ -331,18 +331,23 @@ extern "C" int rrtmg_hip_swrad(const rrtmg_hip_swrad_args *a, char *err)
             ncol_all = 0;
             for (int c = 0; c < nchunk; ++c) ncol_all = std::max(ncol_all, ni_t * stg.chunk_nj(c));
         }
-        size_t mb = default_scratch_mb(32768);
+        size_t mb = 0;
         if (const char *e = std::getenv("RRTMG_HIP_SW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;
         }
         const size_t percol = sw_scratch_doubles_per_column(k.nk);
-        size_t cols = (mb << 20) / (percol * sizeof(double));
-        if (cols < 8) cols = 8;
-        int cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
+        int cap_cols = ncol_all;
         {
             std::unique_lock<std::mutex> lock(st.jump_mutex);
             SwState::Scratch &w = st.scratch[stream];
+            if (mb || w.doubles < percol * (size_t)ncol_all) {
+                // the buffer may have to grow: the cap from what the device has free now (asked only here)
+                if (!mb) mb = default_scratch_mb(32768);
+                size_t cols = (mb << 20) / (percol * sizeof(double));
+                if (cols < 8) cols = 8;
+                cap_cols = (size_t)ncol_all < cols ? ncol_all : (int)cols;
+            }
             if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
             if (w.doubles < percol * (size_t)cap_cols) {
                 if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }
@@ -445,6 +450,14 @@ extern "C" int rrtmg_hip_sw_status(char *err)
     return 0;
 }
 
+
+// RRTMG_HIP_REGISTER_HOST=1 pins the caller's arrays where they are and remembers them by base address; an array
+// that the host is about to free is dropped from that registry here (no-op for an address that is not in it).
+extern "C" int rrtmg_hip_unregister_host(const void *base)
+{
+    if (base) HostRegistry::instance().release(base);
+    return 0;
+}
 
 extern "C" int rrtmg_hip_finalize(void)
 {

@@ -310,17 +310,22 @@ extern "C" int rrtmg_hip_lwrad(const rrtmg_hip_lwrad_args *a, char *err)
     double *scratch = nullptr;
     int cap_cols = 0;
     {
-        size_t mb = default_scratch_mb(16384);
+        size_t mb = 0;
         if (const char *e = std::getenv("RRTMG_HIP_LW_SCRATCH_MB")) {
             const long v = std::atol(e);
             if (v > 0) mb = (size_t)v;
         }
         const size_t percol = lw_scratch_doubles(nl);
-        size_t cols = (mb << 20) / (percol * sizeof(double));
-        if (cols < 8) cols = 8;
-        cap_cols = (size_t)ncol < cols ? ncol : (int)cols;
+        cap_cols = ncol;
         std::unique_lock<std::mutex> lock(st.scratch_mutex);
         LwState::Scratch &w = st.scratch[stream];
+        if (mb || w.doubles < percol * (size_t)ncol) {
+            // the buffer may have to grow: the cap from what the device has free now (asked only here)
+            if (!mb) mb = default_scratch_mb(16384);
+            size_t cols = (mb << 20) / (percol * sizeof(double));
+            if (cols < 8) cols = 8;
+            cap_cols = (size_t)ncol < cols ? ncol : (int)cols;
+        }
         if (w.limit && percol * (size_t)cap_cols > w.limit) cap_cols = w.limit / percol < 8 ? 8 : (int)(w.limit / percol);
         if (w.doubles < percol * (size_t)cap_cols) {
             if (w.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(w.p)); w.p = nullptr; w.doubles = 0; }

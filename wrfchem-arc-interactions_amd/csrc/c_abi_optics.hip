@@ -211,7 +211,10 @@ extern "C" int rrtmg_hip_optical_averaging(const rrtmg_hip_optics_args *a, char 
             const size_t ncell = (size_t)k.ni_m * k.nk_m * k.nj_m;
             void *tmp = nullptr;
             HIPCHK(hipMallocAsync(&tmp, (size_t)nbin * OPT_NSLOT * ncell * a->real_bytes, stream));
-            HIPCHK(optics_combine_cw(k.chem, tmp, k.idx, cw, nbin, ncell, k.real4, stream));
+            {
+                const hipError_t ec = optics_combine_cw(k.chem, tmp, k.idx, cw, nbin, ncell, k.real4, stream);
+                if (ec != hipSuccess) { (void)hipFreeAsync(tmp, stream); HIPCHK(ec); }
+            }
             OpticsKernelArgs kc = k;
             kc.chem = tmp;
             for (int b = 0; b < OPT_MAXBIN; ++b)

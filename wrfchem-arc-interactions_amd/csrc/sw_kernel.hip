@@ -41,6 +41,8 @@
 // No MFMA: there is no contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 
 #include "rrtmg_common.h"
@@ -1572,12 +1574,18 @@ hipError_t sw_launch(const SwKernelArgs &a, hipStream_t stream)
                                    : reinterpret_cast<const void *>(sw_column_kernel<true, false>))
                            : (prof ? reinterpret_cast<const void *>(sw_column_kernel<false, true>)
                                    : reinterpret_cast<const void *>(sw_column_kernel<false, false>));
-    static size_t attr_bytes[4] = {0, 0, 0, 0};   // grow-only opt-in for > 64 KB of dynamic LDS, per instantiation
-    size_t &ab = attr_bytes[(cloud ? 2 : 0) + (prof ? 1 : 0)];
-    if (lds > ab) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        ab = lds;
+    {
+        // grow-only opt-in for > 64 KB of dynamic LDS, per instantiation.  Concurrent tile threads launch from here
+        // (mem = 0 calls run outside the engine lock), so the bookkeeping has its own lock; the launch stays outside it
+        static std::mutex attr_mutex;
+        static size_t attr_bytes[4] = {0, 0, 0, 0};
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        size_t &ab = attr_bytes[(cloud ? 2 : 0) + (prof ? 1 : 0)];
+        if (lds > ab) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            ab = lds;
+        }
     }
     if (cloud) {
         if (prof) hipLaunchKernelGGL((sw_column_kernel<true, true>), dim3(a.ncol), dim3(NTHREADS), lds, stream, a);

@@ -23,6 +23,7 @@
 // caller; when several tiles call at once only one of them gets the helpers, the others pack alone.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -39,22 +40,15 @@
 namespace rrtmg {
 
 // default cap (MiB) of a radiation entry point's layer scratch: a modest fixed size, and never more than a quarter of
-// what the device has FREE at the first call (other tenants -- a framework's allocator, other ranks, other streams --
-// keep their room).  One launch per kernel for a very large tile is an explicit opt-in through
+// what the device has free WHEN THE BUFFER HAS TO GROW (other tenants -- a framework's allocator, other ranks, the other
+// engine, other threads' streams -- keep their room; ADVICE r2, r3: the figure is asked for every time, it is cheap
+// next to the hipMalloc that follows).  One launch per kernel for a very large tile is an explicit opt-in through
 // RRTMG_HIP_SW_SCRATCH_MB / RRTMG_HIP_LW_SCRATCH_MB (bench.py sets them); larger tiles otherwise run in column batches.
 inline size_t default_scratch_mb(size_t modest_mb)
 {
-    static std::mutex m;
-    static size_t free_at_first_call = 0;   // asked once per process
-    {
-        std::lock_guard<std::mutex> lock(m);
-        if (!free_at_first_call) {
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return modest_mb; }
-            free_at_first_call = fr ? fr : 1;
-        }
-    }
-    const size_t quarter = (free_at_first_call / 4) >> 20;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return modest_mb; }
+    const size_t quarter = (fr / 4) >> 20;
     return quarter < modest_mb ? (quarter > 64 ? quarter : 64) : modest_mb;
 }
 
@@ -99,7 +93,15 @@ public:
 private:
     PackPool()
     {
-        int n = (int)std::thread::hardware_concurrency() / 2 - 1;
+        // half of the cores this PROCESS may run on (its affinity mask: with one MPI rank per few cores the machine's
+        // core count would oversubscribe the node), less the caller
+        int cores = (int)std::thread::hardware_concurrency();
+        {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && c < cores) cores = c; }
+        }
+        int n = cores / 2 - 1;
         if (n > 7) n = 7;
         if (const char *e = std::getenv("RRTMG_HIP_PACK_THREADS")) n = std::atoi(e);
         if (n < 0) n = 0;
@@ -171,11 +173,36 @@ struct HostRegistry {
     {
         std::lock_guard<std::mutex> lock(m);
         auto it = bytes.find(p);
-        if (it != bytes.end() && (it->second >= n || it->second == 0)) return;
-        if (it != bytes.end()) (void)hipHostUnregister(const_cast<void *>(p));   // grew: pin the larger range
+        if (it != bytes.end() && it->second == 0) return;   // refused before: the runtime stages it itself
+        if (it != bytes.end() && it->second >= n) {
+            // remembered: still pinned?  (memory unmapped and mapped again at this address is not; ask the runtime
+            // instead of trusting the address)
+            void *d = nullptr;
+            if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) == hipSuccess) return;
+            (void)hipGetLastError();
+            (void)hipHostUnregister(const_cast<void *>(p));
+            (void)hipGetLastError();
+        } else if (it != bytes.end()) {
+            // grew: pin the larger range -- after every copy that may still read the old one has ended (other
+            // threads' streams included)
+            (void)hipDeviceSynchronize();
+            (void)hipHostUnregister(const_cast<void *>(p));
+        }
         const hipError_t e = hipHostRegister(const_cast<void *>(p), n, hipHostRegisterDefault);
         if (e != hipSuccess) (void)hipGetLastError();
         bytes[p] = (e == hipSuccess || e == hipErrorHostMemoryAlreadyRegistered) ? n : 0;
+    }
+    // one array: before the host frees it (rrtmg_hip_unregister_host)
+    void release(const void *p)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        auto it = bytes.find(p);
+        if (it == bytes.end()) return;
+        if (it->second) {
+            (void)hipDeviceSynchronize();
+            if (hipHostUnregister(const_cast<void *>(p)) != hipSuccess) (void)hipGetLastError();
+        }
+        bytes.erase(it);
     }
     void release_all()
     {
@@ -270,6 +297,17 @@ class TileStager {
 public:
     static constexpr int MAX_CHUNKS = 16;   // one status word each in the first 64 bytes of the buffers
     explicit TileStager(const TileGeom &g) : g_(g) {}
+    // A call that leaves early (an error from stage(), a launch, fetch(), an allocation) would otherwise leave copies and
+    // kernels in flight on the thread's buffers -- with registered host arrays even copies into the caller's memory --
+    // while the next call on this thread re-packs and may free them: whatever was enqueued ends here.
+    ~TileStager()
+    {
+        if (!pool_ || !begun_ || finished_) return;
+        for (hipStream_t q : {pool_->h2d, pool_->stream, pool_->d2h})
+            if (q && hipStreamSynchronize(q) != hipSuccess) (void)hipGetLastError();
+    }
+    TileStager(const TileStager &) = delete;
+    TileStager &operator=(const TileStager &) = delete;
 
     // kext: extent of the k dimension in memory (1 for a 2-D array, nk_m, nk_m + 2 for the flux profiles);
     // nblk: leading blocks of a 4-D array (i,k,j,block).  target receives the chunk's device address in stage().
@@ -308,6 +346,7 @@ public:
     hipError_t begin(long cols_per_chunk)
     {
         if (!pool_) { hipError_t e = open(); if (e != hipSuccess) return e; }
+        begun_ = true;
         direct_ = host_registration_enabled();
         if (direct_) {
             for (const Req &r : reqs_)
@@ -410,6 +449,7 @@ public:
         hipError_t e = hipMemcpyAsync(p.pin, p.dev, 64, hipMemcpyDeviceToHost, p.d2h);
         if (e == hipSuccess) e = hipStreamSynchronize(p.d2h);
         if (e != hipSuccess) return e;
+        finished_ = true;
         *status = 0;
         if (chunk) *chunk = 0;
         for (int c = 0; c < nchunks(); ++c) {
@@ -497,6 +537,7 @@ private:
     size_t used_ = 0;
     StagePool *pool_ = nullptr;
     bool direct_ = false;   // RRTMG_HIP_REGISTER_HOST: pitched copies between the caller's arrays and the device
+    bool begun_ = false, finished_ = false;
 };
 
 }  // namespace rrtmg

@@ -95,7 +95,8 @@ def load_library(path: str | None = None):
 
 
 EXPORTS = ["rrtmg_hip_sw_init", "rrtmg_hip_swrad", "rrtmg_hip_sw_status", "rrtmg_hip_swrad_staging_bytes",
-           "rrtmg_hip_sw_tile_sums", "rrtmg_hip_finalize", "rrtmg_hip_pick_device", "rrtmg_hip_version",
+           "rrtmg_hip_sw_tile_sums", "rrtmg_hip_finalize", "rrtmg_hip_unregister_host", "rrtmg_hip_pick_device",
+           "rrtmg_hip_version",
            "rrtmg_hip_sw_reduce_tables", "rrtmg_hip_sw_table_info"]
 
 
@@ -167,6 +168,15 @@ def rrtmg_swrad(*, ims, ime, jms, jme, kms, kme, its, ite, jts, jte, kts, kte,
         a.stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     err = C.create_string_buffer(ERRLEN)
     _check(lib.rrtmg_hip_swrad(C.byref(a), err), err)
+
+
+def unregister_host(*arrays):
+    """Drop numpy arrays from the RRTMG_HIP_REGISTER_HOST registry before they are freed (rrtmg_hip_unregister_host)."""
+    lib = load_library()
+    lib.rrtmg_hip_unregister_host.argtypes = [C.c_void_p]
+    for a in arrays:
+        if isinstance(a, np.ndarray):
+            lib.rrtmg_hip_unregister_host(C.c_void_p(a.ctypes.data))
 
 
 def sw_status():

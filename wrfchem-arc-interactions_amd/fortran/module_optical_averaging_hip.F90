@@ -180,10 +180,10 @@ CONTAINS
       INTEGER, INTENT(IN) :: nbin_o, aer_op_opt, num_chem
       INTEGER, INTENT(IN) :: idx(aer_nspec, nbin_o)
       INTEGER, INTENT(IN), OPTIONAL :: idx_cw(aer_nspec, nbin_o)
+      INTEGER, INTENT(IN) :: ids,ide, jds,jde, kds,kde, ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte
       ! Legendre moments of the phase function at the four wavelengths (registry.chem:1382-1387): all six or none
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme, 4), INTENT(INOUT), OPTIONAL, TARGET ::           &
             l2aer, l3aer, l4aer, l5aer, l6aer, l7aer
-      INTEGER, INTENT(IN) :: ids,ide, jds,jde, kds,kde, ims,ime, jms,jme, kms,kme, its,ite, jts,jte, kts,kte
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme, num_chem), INTENT(IN), TARGET :: chem
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme), INTENT(IN), TARGET :: dz8w, alt
       REAL, DIMENSION(ims:ime, kms:kme, jms:jme), INTENT(INOUT), TARGET ::                       &
