@@ -1723,6 +1723,39 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     else fl = lds + colsel * cold + recn + (size_t)chunk * ws;
     // the lane's band in the packed part of the record: per layer (planklay, dplankdn) and (dplankup, taua)
     const double2 *const q4 = reinterpret_cast<const double2 *>(rec + lw_rec_q4_offset(nl)) + (size_t)band * lw_rec_q4_layers(nl) * 2;
+    // The lanes of a band read the same quadruple, and a band's block of four layers is one 128-byte line: the WAVE
+    // fetches each line once per block -- lane 4s + j the quadruple of layer j of the wave's s-th (column, band) pair,
+    // a block ahead -- and a lane takes its layer's four values from that lane's registers through the LDS crossbar
+    // (ds_bpermute: no LDS memory, no trip to the vector cache).  Read per lane and layer, the quadruples cost the
+    // vector cache a line fill per band, layer and wave (the streaming gas optics turn the L1 over in between), 5 of the
+    // kernel's 19.5 ms.  A wave's four rows hold at most 14 pairs (16 x 4 loader lanes).
+    int bp_idx;                 // byte index (lane * 4) of the loader lane of this lane's pair, layer 0 of a block
+    const double2 *bp_src;      // loader lanes: the pair's quadruples (layer 0); others: nullptr
+    {
+        const int key = colsel * LW_NBND + band, prev = __shfl_up(key, 1, 64);
+        const unsigned long long firsts = __ballot(lane == 0 || key != prev);
+        const int myslot = __popcll(firsts & (~0ull >> (63 - lane))) - 1;
+        bp_idx = 16 * myslot;
+        // loader lane l serves pair l >> 2: the lane that opens the pair knows its quadruples
+        const int s_ld = lane >> 2;
+        unsigned long long t = firsts;
+        for (int i = 0; i < s_ld && t; ++i) t &= t - 1;
+        const int opener = t ? __builtin_ctzll(t) : 0;
+        const unsigned long long qaddr = reinterpret_cast<unsigned long long>(q4);
+        const unsigned lo = __shfl((unsigned)qaddr, opener, 64), hi = __shfl((unsigned)(qaddr >> 32), opener, 64);
+        bp_src = t ? reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo) + 2 * (lane & 3) : nullptr;
+    }
+    auto bp_fetch = [&](const int b, double2 &u, double2 &w) {   // the loader lanes' part of block b
+        if (bp_src) { u = bp_src[8 * b]; w = bp_src[8 * b + 1]; }
+    };
+    auto bp_take = [&](const int j, const double2 u, const double2 w, double &blay, double &dpdn, double &dpup, double &tak) {
+        const int idx = bp_idx + 4 * j;
+        auto pick = [&](const double x) {
+            return __hiloint2double(__builtin_amdgcn_ds_bpermute(idx, __double2hiint(x)),
+                                    __builtin_amdgcn_ds_bpermute(idx, __double2loint(x)));
+        };
+        blay = pick(u.x); dpdn = pick(u.y); dpup = pick(w.x); tak = pick(w.y);
+    };
     const double secdiff = rec[band], plankbnd = rec[LW_NBND + band];
 
     uint64_t cmask = 0;
@@ -1781,11 +1814,14 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         T4[j] = 0.; F4[j] = 0.;
         if (k < nl) { T4[j] = RTF_LD(tgw + j * ng); F4[j] = frac_read(FS, tgw + j * ng, k); }
     }
-    double2 qa = q4[2 * (nl - 1)], qb = q4[2 * (nl - 1) + 1];
+    double2 qu = make_double2(0., 0.), qw = qu;
+    bp_fetch(nblk - 1, qu, qw);
     for (int b = nblk - 1; b >= 0; --b) {
         double v[4] = {0., 0., 0., 0.};
         double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
+        double2 qun = make_double2(0., 0.), qwn = qun;
         if (b > 0) {
+            bp_fetch(b - 1, qun, qwn);
             tgw -= 4 * ng;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { Tn[j] = RTF_LD(tgw + j * ng); Fn[j] = frac_read(FS, tgw + j * ng, 4 * (b - 1) + j); }
@@ -1795,8 +1831,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             const int k = b * 4 + j;
             if (k < nl) {
                 const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
-                const double blay = qa.x, dplankdn = qa.y, dplankup = qb.x, tak = qb.y;
-                if (k > 0) { qa = q4[2 * (k - 1)]; qb = q4[2 * (k - 1) + 1]; }
+                double blay, dplankdn, dplankup, tak;
+                bp_take(j, qu, qw, blay, dplankdn, dplankup, tak);
                 const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
                 if (!lay_cld) {
                     double at, bbd, bbu;
@@ -1850,6 +1886,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         if (b > 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
+            qu = qun; qw = qwn;
         }
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
@@ -1870,7 +1907,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     // (the gas optics are read a second time and the layer optics evaluated again: with the pair table that is 25
     // instructions; storing (A, S) on the way down instead was 46 GB more traffic and slower, r03)
     {
-        // T4 / F4 hold block 0 after the downward sweep, qa / qb layer 0
+        // T4 / F4 and qu / qw hold block 0 after the downward sweep
 #ifdef RTF_PROBE_NOUP
         for (int b = 0; b < (nl > 10000 ? nblk : 0); ++b) {
 #else
@@ -1878,7 +1915,9 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 #endif
             double v[4] = {0., 0., 0., 0.};
             double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
+            double2 qun = make_double2(0., 0.), qwn = qun;
             if (b + 1 < nblk) {
+                bp_fetch(b + 1, qun, qwn);
                 tgw += 4 * ng;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1891,8 +1930,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                 const int k = b * 4 + j;
                 if (k < nl) {
                     const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
-                    const double blay = qa.x, dplankdn = qa.y, dplankup = qb.x, tak = qb.y;
-                    if (k + 1 < nl) { qa = q4[2 * (k + 1)]; qb = q4[2 * (k + 1) + 1]; }
+                    double blay, dplankdn, dplankup, tak;
+                    bp_take(j, qu, qw, blay, dplankdn, dplankup, tak);
                     const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
                     if (!lay_cld) {
                         double at, bbd, bbu;
@@ -1919,6 +1958,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
+            qu = qun; qw = qwn;
         }
     }
     if (bad && live) atomicMax(a.status, (bad << 28) | (1 + col));
