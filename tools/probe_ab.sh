@@ -1,12 +1,12 @@
 #!/bin/bash
 # Development aid: A/B two versions of one source file on the same GPU box.
-#   bash tools/probe_ab.sh <file under csrc> <variant A> <variant B> [rounds]
-f=$1; A=$2; B=$3; rounds=${4:-2}
+#   bash tools/probe_ab.sh <rounds> <file under csrc> <variant A> <variant B> [<variant C> ...]
+rounds=$1; f=$2; shift 2
 out=gpurun_out/probe_ab; mkdir -p $out
 export TMPDIR=/tmp
 cp wrfchem-arc-interactions_amd/csrc/$f /tmp/orig_$f
 for r in $(seq $rounds); do
-for v in $A $B; do
+for v in "$@"; do
   cp $v wrfchem-arc-interactions_amd/csrc/$f
   make -s -C wrfchem-arc-interactions_amd/csrc > $out/build.log 2>&1 || { echo "build failed for $v"; tail -5 $out/build.log; continue; }
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 > $out/log.txt 2>&1

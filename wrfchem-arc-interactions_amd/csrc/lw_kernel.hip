@@ -844,22 +844,47 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ int s_laytrop, s_nextseg;
     if (tid == 0) { s_laytrop = 0; s_nextseg = 0; }
     LW_STAMP(0);
-    if (wave == 0) {
-        for (int l = lane; l <= nl; l += 64) {
-            c.pz[l] = plev_at(a, base3, sk, l, nk, nl);
-            c.tz[l] = tlev_at(a, base3, sk, l, nk, nl);
-            if (l < nl) {
-                const int km = l < nk ? l : nk - 1;
-                c.tav[l] = ldr(a.t3d, base3 + (size_t)km * sk, r4);
-                c.pavel[l] = ldr(a.p3d, base3 + (size_t)km * sk, r4) / 100.;
-                c.wrk[l] = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
-            }
+    if (wave == 2) {
+        // the ozone climatology of the layers (O3DATA: a 31-step sum per layer, a third of the instructions of phase B)
+        // off wave 0's path: this wave forms the level pressures a second time and parks the result in the upper half
+        // of wrk, which phase B overwrites only after it has read the value
+        for (int k = lane; k < nl; k += 64) {
+            const int lb = k < nk ? k : nk, lu = k + 1 < nk ? k + 1 : nk;
+            const double pb8 = ldr(a.p8w, base3 + (size_t)lb * sk, r4), pu8 = ldr(a.p8w, base3 + (size_t)lu * sk, r4);
+            double pb = fdiv(pb8, 100.), pu = fdiv(pu8, 100.);   // (lb = lu = nk above the model top: p8w(kte+1) / 100)
+            if (k > nk) pb = pb - 4. * (double)(k - nk);
+            if (k + 1 > nk) pu = k + 1 == nl ? 0.00 : pu - 4. * (double)(k + 1 - nk);
+            c.wrk[nl + k] = o3clim(pb, pu);
         }
-    } else {
+    } else if (wave == 0) {
+        // every load of the phase goes out first, at clamped indices (a buffer level reads the model top's values again;
+        // written with the branches of plev_at / tlev_at, the loads of the buffer levels waited for those of the model
+        // levels: three to four trips to memory instead of one), then the levels are formed as LW:12207-12247 forms them
+        for (int l = lane; l <= nl; l += 64) {
+            const int lp = l < nk ? l : nk, lt = l < nk - 1 ? l : nk - 1;
+            const double p8 = ldr(a.p8w, base3 + (size_t)lp * sk, r4), t8 = ldr(a.t8w, base3 + (size_t)lt * sk, r4);
+            const double p8top = ldr(a.p8w, base3 + (size_t)nk * sk, r4), p8sub = ldr(a.p8w, base3 + (size_t)(nk - 1) * sk, r4);
+            const double t3 = ldr(a.t3d, base3 + (size_t)lt * sk, r4), p3 = ldr(a.p3d, base3 + (size_t)lt * sk, r4),
+                         q3 = ldr(a.qv3d, base3 + (size_t)lt * sk, r4);
+            // plev: the model's levels, then steps of deltap = 4 mb down from the model top (the reference subtracts 4
+            // level by level; every partial result is exact, so one subtraction gives the same number), 0 at the top
+            double pz = fdiv(p8, 100.);
+            if (l > nk) pz = l == nl ? 0.00 : fdiv(p8top, 100.) - 4. * (double)(l - nk);
+            // tlev(L) = varint(L) + (tlev(kte) - varint(kte)) for L >= kte+1, LW:12244-12247
+            double tz = t8;
+            if (l > nk - 1) tz = varint_at(pz) + (t8 - varint_at(fdiv(p8sub, 100.)));
+            c.pz[l] = pz;
+            c.tz[l] = tz;
+            if (l < nl) { c.tav[l] = t3; c.pavel[l] = fdiv(p3, 100.); c.wrk[l] = q3; }
+        }
+    } else if (wave == 1) {
         // aerosol optical depth per band, LW:12576-12604 (zero in the buffer layers): lanes = layers, the sixteen
         // bands of a layer by one lane (bands 1 and 16, which gate the copy, are read once; the REAL width is decided
         // outside the loads so that the sixteen of a layer go out together)
-        for (int k = tid - 64; k < nl; k += LW_THREADS - 64) {
+        double asum[LW_NBND];   // this lane's share of the column sums (the guard of LW:12607-12615)
+#pragma unroll
+        for (int nb = 0; nb < LW_NBND; ++nb) asum[nb] = 0.;
+        for (int k = lane; k < nl; k += 64) {
             double t[LW_NBND];
 #pragma unroll
             for (int nb = 0; nb < LW_NBND; ++nb) t[nb] = 0.;
@@ -875,7 +900,23 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             }
             const bool on = t[0] > 1.e-9 && t[15] > 1.e-9;
 #pragma unroll
-            for (int nb = 0; nb < LW_NBND; ++nb) c.q4[((size_t)nb * nl4 + k) * 4 + 3] = on ? t[nb] : 0.;
+            for (int nb = 0; nb < LW_NBND; ++nb) {
+                const double v = on ? t[nb] : 0.;
+                c.q4[((size_t)nb * nl4 + k) * 4 + 3] = v;
+                asum[nb] += v;
+            }
+        }
+        // negative column aerosol optical depth is fatal, LW:12607-12615: the column sums of the 16 bands from the
+        // registers that fetched them (a sum of the same numbers in another order decides the same way unless it is
+        // zero to rounding)
+        if (a.aer_ra_feedback == 1) {
+#pragma unroll
+            for (int nb = 0; nb < LW_NBND; ++nb) {
+                double v = asum[nb];
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                if (lane == 0 && v < 0.) atomicMax(a.status, 1 + col);
+            }
         }
     }
     LW_STAMP(1);
@@ -893,7 +934,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         qv = fmax(qv, 1.E-12);
         const double amdw = 1.607793, amdo = 0.603461;
         const double h2ovmr = qv * amdw;
-        const double o3mmr = o3clim(plev_b, plev_t);
+        const double o3mmr = c.wrk[nl + k];   // o3clim(plev_b, plev_t), wave 2 in phase A
         double o3vmr = o3mmr * amdo;
         if (a.o33d && a.o3input == 2) {   // LW:12268-12280
             if (k < nk) o3vmr = ldr(a.o33d, base3 + (size_t)k * sk, r4);
@@ -1218,18 +1259,6 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             if (sd < 1.50) sd = 1.50;
         }
         c.secdiff[ib] = sd;
-    }
-    if (a.aer_ra_feedback == 1 && wave == 1) {
-        // negative column aerosol optical depth is fatal, LW:12607-12615: the column sums of the 16 bands, lanes =
-        // layers (the optical depths were written to the column record in phase A; a sum of the same numbers in
-        // another order decides the same way unless it is zero to rounding)
-        for (int nb = 0; nb < LW_NBND; ++nb) {
-            double v = 0.;
-            for (int k = lane; k < nk; k += 64) v += c.q4[((size_t)nb * nl4 + k) * 4 + 3];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0 && v < 0.) atomicMax(a.status, 1 + col);
-        }
     }
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
