@@ -61,6 +61,13 @@ def main(tmp, out):
     wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, chem=chem, alt=alt, dz8w=dz, **oo)
     for n, v in oo.items():
         res["optics_" + n] = v.copy()
+    # a host that frees an array tells the engine first (rrtmg_hip_unregister_host; a no-op for unknown addresses and
+    # without the opt-in); the same call on the same arrays afterwards pins them again and gives the same bits
+    wa.engine.unregister_host(*keep)
+    wa.engine.unregister_host(np.zeros(3))
+    wa.engine_optics.optical_averaging(idx=ms.idx, aer_op_opt=1, **d, chem=chem, alt=alt, dz8w=dz, **oo)
+    for n, v in oo.items():
+        np.testing.assert_array_equal(res["optics_" + n], v, err_msg="after unregister: " + n)
     np.savez(out, **res)
     print("REGISTER-OK")
 

@@ -568,9 +568,6 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, const double
                                           double plfrac, double blay, double dplankup, double dplankdn, double &atrans,
                                           double &bbd, double &bbu)
 {
-#ifdef RTF_PROBE_NOCOMPUTE
-    atrans = tau * 1.e-3; bbd = plfrac * blay; bbu = bbd + dplankup + dplankdn * secdiff; return;
-#endif
     double odepth = secdiff * tau;
     odepth = odepth < 0.0 ? 0.0 : odepth;
     double tblind = fdiv(odepth, tb.bpade + odepth);
@@ -768,14 +765,9 @@ __device__ __forceinline__ FracSrc frac_src(const LwGDesc *gd, double laytrop, p
 // loop is vmcnt(0): the layer fetched one iteration ahead was waited for right after its issue (r03: the transfer
 // kernel "waits on its reads").
 // (in two halves, so that a loop can issue the read ahead and touch the value only when the layer's turn comes)
-#ifdef RTF_PROBE_NT
-#define RTF_LD(p) __builtin_nontemporal_load(p)
-#else
-#define RTF_LD(p) (*(p))
-#endif
 __device__ __forceinline__ double frac_read(const FracSrc &F, const double *tgk, int k)
 {
-    return RTF_LD(tgk + ((k < F.ltrop ? F.st_lo : F.st_up) ? F.fdel : (ptrdiff_t)0));
+    return tgk[(k < F.ltrop ? F.st_lo : F.st_up) ? F.fdel : (ptrdiff_t)0];
 }
 __device__ __forceinline__ double frac_value(const FracSrc &F, double v, int k)
 {
@@ -1721,29 +1713,17 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         semiss = ldr(a.emiss, i2, r4);
     }
     const LwGDesc *gd = tb.gdesc + g;
-#ifdef RTF_PROBE_LAYERMAJOR
-    const int band = gd->band, ng = LW_NGPT;
-#else
     const int band = gd->band, ng = gd->ng;
-#endif
     const double wgt = live ? 0.5 * gd->delwave : 0.;
     // the clean-sky call differs from the one with aerosol only if there is aerosol; without it the reference's
     // two calls are the same arithmetic on the same numbers, and the outputs are copies
     const bool clean_on = a.clean > 0, clean_own = clean_on && a.aer_ra_feedback == 1;
     const int nlev = nl + 1;
     // scratch of the column, band-major: [band][layer][ig] (lw_kernel.h)
-#ifdef RTF_PROBE_LAYERMAJOR
-    const size_t sbase = (size_t)slot * nl * LW_NGPT + g;
-#else
     const size_t sbase = (size_t)slot * nl * LW_NGPT + (size_t)nl * (g - gd->ig) + gd->ig;
-#endif
     double *tg = a.taug + sbase, *fr = a.frac + sbase;
     __syncthreads();
-#ifdef RTF_PROBE_NOFRAC
-    const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1], 0);
-#else
     const FracSrc FS = frac_src(gd, rec[lw_rec_base_doubles(nl) - 1], fr - tg);
-#endif
     // per chunk: downward and upward flux of the call with aerosol at every level, then the small sums
     // [0..2] clean sky: surface down, surface up, top up; [4..6] clear sky alike
     const size_t ws = 2 * nlev + 8;
@@ -1841,7 +1821,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     for (int j = 0; j < 4; ++j) {
         const int k = 4 * (nblk - 1) + j;
         T4[j] = 0.; F4[j] = 0.;
-        if (k < nl) { T4[j] = RTF_LD(tgw + j * ng); F4[j] = frac_read(FS, tgw + j * ng, k); }
+        if (k < nl) { T4[j] = tgw[j * ng]; F4[j] = frac_read(FS, tgw + j * ng, k); }
     }
     double2 qu = make_double2(0., 0.), qw = qu;
     bp_fetch(nblk - 1, qu, qw);
@@ -1853,7 +1833,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             bp_fetch(b - 1, qun, qwn);
             tgw -= 4 * ng;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { Tn[j] = RTF_LD(tgw + j * ng); Fn[j] = frac_read(FS, tgw + j * ng, 4 * (b - 1) + j); }
+            for (int j = 0; j < 4; ++j) { Tn[j] = tgw[j * ng]; Fn[j] = frac_read(FS, tgw + j * ng, 4 * (b - 1) + j); }
         }
 #pragma unroll
         for (int j = 3; j >= 0; --j) {
@@ -1937,11 +1917,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     // instructions; storing (A, S) on the way down instead was 46 GB more traffic and slower, r03)
     {
         // T4 / F4 and qu / qw hold block 0 after the downward sweep
-#ifdef RTF_PROBE_NOUP
-        for (int b = 0; b < (nl > 10000 ? nblk : 0); ++b) {
-#else
         for (int b = 0; b < nblk; ++b) {
-#endif
             double v[4] = {0., 0., 0., 0.};
             double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
             double2 qun = make_double2(0., 0.), qwn = qun;
@@ -1951,7 +1927,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int k = 4 * (b + 1) + j;
-                    if (k < nl) { Tn[j] = RTF_LD(tgw + j * ng); Fn[j] = frac_read(FS, tgw + j * ng, k); }
+                    if (k < nl) { Tn[j] = tgw[j * ng]; Fn[j] = frac_read(FS, tgw + j * ng, k); }
                 }
             }
 #pragma unroll
