@@ -586,9 +586,13 @@ def main():
         achieved = ncol * dom_bpc / (dom_ms * 1e-3) / 1e9
         traffic, valu, traffic_source = None, {}, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        imported = {}   # kernel -> HBM bytes per step of the builder-run profile, scaled to this run's columns
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
+                for kn, kv in tj.get("kernels", {}).items():
+                    if kv.get("hbm_bytes_per_launch") is not None and kv.get("columns_per_dispatch"):
+                        imported[kn] = kv["hbm_bytes_per_launch"] * ncol / kv["columns_per_dispatch"]
                 kd = tj.get("kernels", {}).get(dom_name, {})
                 if kd.get("hbm_bytes_per_launch") is not None and kd.get("columns_per_dispatch"):
                     # PMC bytes per dispatch of the profiled run scaled to the columns of one step here (same kernel)
@@ -641,9 +645,17 @@ def main():
                          "kernels": [
                              {"kernel": nm, "ms": ms_, "algorithmic_bytes_per_column": b_,
                               "achieved": ncol * b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
-                              "frac": ncol * b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None}
-                             for nm, ms_, b_ in (cand + ([("lw_gas_kernel + lw_rt_fast_kernel", lw_ms, bpc_lw)] if do_lw else []))],
-                         "note": "fp64-VALU-bound path (SURVEY 8d): see roofline.fp64 and DESIGN.md 4.4"},
+                              "frac": ncol * b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_ > 0 else None,
+                              # HBM bytes the kernel(s) actually moved per step (imported like `traffic`) and the rate
+                              # that is over this run's duration
+                              "traffic": (sum(imported[q] for q in nm.split(" + ")) if all(q in imported for q in nm.split(" + "))
+                                          else None),
+                              "traffic_GBs": (sum(imported[q] for q in nm.split(" + ")) / (ms_ * 1e-3) / 1e9
+                                              if ms_ > 0 and all(q in imported for q in nm.split(" + ")) else None)}
+                             for nm, ms_, b_ in (cand + ([("lw_gas_kernel + lw_rt_fast_tbl_kernel", lw_ms, bpc_lw)] if do_lw else []))],
+                         "note": "not HBM-bound at the algorithmic bytes (SURVEY 8d): the optical averaging is bound by fp64 "
+                                 "issue, the radiation kernels by the memory path of their own scratch streams and table "
+                                 "gathers (kernels[*].traffic); see roofline.fp64 and DESIGN.md 4.4"},
         }
         if world > 1:
             # what the one collective delivered: the column count and the domain-mean TOA upward fluxes (tiles.domain_means)

@@ -561,6 +561,16 @@ __device__ __forceinline__ double2 lw_pair_entry(double bpade, int itr)
     return make_double2(1. - transc, tausfac_t);
 }
 
+// The copy of the pair table in LDS starts at entry LW_PAIR_FIRST: an optical depth above 0.06 -- the only kind that
+// reads the table -- has an index of 164 or more (0.06 / (bpade + 0.06) * 10000 = 164.07); smaller ones take the
+// expansion.  (0 <= itr <= 10000 for every finite optical depth >= 0; anything else reads the last entry.)
+constexpr int LW_PAIR_FIRST = 164, LW_PAIR_COUNT = LW_NTBL + 1 - LW_PAIR_FIRST;
+__device__ __forceinline__ int lw_pair_slot(int itr)
+{
+    itr = itr < LW_PAIR_FIRST ? LW_PAIR_FIRST : itr;
+    return ((unsigned)itr > (unsigned)LW_NTBL ? LW_NTBL : itr) - LW_PAIR_FIRST;
+}
+
 // absorptivity and Planck source terms of one layer for one g-point, LW:3284-3296
 // ltbl: the pair table in LDS (lw_rt_fast_kernel, cloud-free instantiation) or nullptr (compile-time in either case)
 template <bool USE_TBL>
@@ -581,7 +591,7 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, const double
     // of tfn_tbl, 1/tau - trans/(1-trans), taken over one common denominator.
     double2 e;
     if constexpr (USE_TBL) {
-        e = ltbl[(unsigned)itr > (unsigned)LW_NTBL ? LW_NTBL : itr];   // (0 <= itr <= 10000 for every finite odepth >= 0)
+        e = ltbl[lw_pair_slot(itr)];
         asm("" : "+v"(e.x), "+v"(e.y));   // (one 16-byte read for every lane, not two reads and a branch on `small`)
     }
     else e = lw_pair_entry(tb.bpade, itr);
@@ -592,29 +602,44 @@ __device__ __forceinline__ void layer_src(const LwDeviceTables &tb, const double
     bbu = small ? plfrac * (blay + dplankup * tausfac) : plfrac * (blay + tausfac * dplankup);
 }
 
-// One quantised entry of the reference's lookup tables (rrtmg_lw_ini, LW:7940-7957), re-evaluated from its index
-// as in layer_src: tau_tbl, exp_tbl (transmittance) and tfn_tbl.
-__device__ __forceinline__ void lw_tbl_entry(const LwDeviceTables &tb, double od, double &tau_t, double &transc, double &tfn)
+// One quantised entry of the reference's lookup tables (rrtmg_lw_ini, LW:7940-7957): tau_tbl (only where NEED_TAU),
+// 1 - exp_tbl and tfn_tbl, read from the pair table in LDS (USE_TBL) or re-evaluated from the index as in layer_src.
+template <bool USE_TBL, bool NEED_TAU>
+__device__ __forceinline__ void lw_tbl_entry(const LwDeviceTables &tb, const double2 *ltbl, double od, double &tau_t,
+                                             double &atr, double &tfn)
 {
     const double tblind = fdiv(od, tb.bpade + od);
     int itr = (int)(10000.0 * tblind + 0.5);
     const bool last = itr >= LW_NTBL;
-    itr = last ? LW_NTBL - 1 : itr;
-    const double fi = (double)itr;
-    tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
-    transc = fmax(exp_neg(tau_t), 1.e-20);
-    const double omt = 1. - transc;
-    tfn = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp1(tau_t * omt));
-    tau_t = last ? 1.e10 : tau_t;
-    transc = last ? 1.e-20 : transc;
-    tfn = last ? 1.0 : tfn;
+    if constexpr (USE_TBL) {
+        const double2 e = ltbl[lw_pair_slot(itr)];
+        atr = e.x; tfn = e.y;
+        tau_t = 0.;
+        if (NEED_TAU) {
+            const double fi = (double)(last ? LW_NTBL - 1 : itr);
+            tau_t = last ? 1.e10 : (tb.bpade * fi) * frcp(10000.0 - fi);
+        }
+    } else {
+        itr = last ? LW_NTBL - 1 : itr;
+        const double fi = (double)itr;
+        tau_t = (tb.bpade * fi) * frcp(10000.0 - fi);
+        double transc = fmax(exp_neg(tau_t), 1.e-20);
+        const double omt = 1. - transc;
+        tfn = tau_t < 0.06 ? tau_t * (1. / 6.) : 1. - 2. * ((omt - tau_t * transc) * frcp1(tau_t * omt));
+        tau_t = last ? 1.e10 : tau_t;
+        transc = last ? 1.e-20 : transc;
+        tfn = last ? 1.0 : tfn;
+        atr = 1. - transc;
+    }
 }
 
 // A layer in which some sub-column is cloudy: the three optical-depth regimes of rtrnmc, LW:3216-3282.
 // odcld = secdiff * cloud optical depth of this sub-column (0 where it is clear).
 struct LwCldSrc { double atrans, atot, bbd, bbdtot, bbugas, bbutot; };
-__device__ __forceinline__ void layer_src_cld(const LwDeviceTables &tb, double tau, double secdiff, double plfrac,
-                                              double blay, double dplankup, double dplankdn, double odcld, LwCldSrc &o)
+template <bool USE_TBL>
+__device__ __forceinline__ void layer_src_cld(const LwDeviceTables &tb, const double2 *ltbl, double tau, double secdiff,
+                                              double plfrac, double blay, double dplankup, double dplankdn, double odcld,
+                                              LwCldSrc &o)
 {
     const double rec_6 = 0.166667;
     double odepth = secdiff * tau;
@@ -632,23 +657,23 @@ __device__ __forceinline__ void layer_src_cld(const LwDeviceTables &tb, double t
     } else if (odepth <= 0.06) {
         o.atrans = odepth - 0.5 * odepth * odepth;
         const double odepth_rec = rec_6 * odepth;
-        double tt, transc, tfactot;
-        lw_tbl_entry(tb, odtot, tt, transc, tfactot);
+        double tt, atot, tfactot;
+        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, tfactot);
         o.bbdtot = plfrac * (blay + tfactot * dplankdn);
         o.bbd = plfrac * (blay + dplankdn * odepth_rec);
-        o.atot = 1. - transc;
+        o.atot = atot;
         o.bbugas = plfrac * (blay + dplankup * odepth_rec);
         o.bbutot = plfrac * (blay + tfactot * dplankup);
     } else {
-        double tgas, transg, tfacgas;
-        lw_tbl_entry(tb, odepth, tgas, transg, tfacgas);
-        o.atrans = 1. - transg;
+        double tgas, agas, tfacgas;
+        lw_tbl_entry<USE_TBL, true>(tb, ltbl, odepth, tgas, agas, tfacgas);
+        o.atrans = agas;
         odtot = tgas + odcld;            // odepth = tau_tbl(itgas), LW:3262
-        double tt, transc, tfactot;
-        lw_tbl_entry(tb, odtot, tt, transc, tfactot);
+        double tt, atot, tfactot;
+        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, tfactot);
         o.bbdtot = plfrac * (blay + tfactot * dplankdn);
         o.bbd = plfrac * (blay + tfacgas * dplankdn);
-        o.atot = 1. - transc;
+        o.atot = atot;
         o.bbugas = plfrac * (blay + tfacgas * dplankup);
         o.bbutot = plfrac * (blay + tfactot * dplankup);
     }
@@ -1483,12 +1508,12 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
                 efcl = 1. - exp_neg(odcld);
             }
             LwCldSrc s;
-            layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            layer_src_cld<false>(tb, nullptr, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
             double gassrc = s.bbd * s.atrans;
             radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
             radclr = radclr + (s.bbd - radclr) * s.atrans;
             if (clean_on) {
-                layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                layer_src_cld<false>(tb, nullptr, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                 gassrc = s.bbd * s.atrans;
                 radld_c = radld_c - radld_c * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
             }
@@ -1541,12 +1566,12 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
                 efcl = 1. - exp_neg(odcld);
             }
             LwCldSrc s;
-            layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+            layer_src_cld<false>(tb, nullptr, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
             double gassrc = s.bbugas * s.atrans;
             radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
             radclru = radclru + (s.bbugas - radclru) * s.atrans;
             if (clean_on) {
-                layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                layer_src_cld<false>(tb, nullptr, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                 gassrc = s.bbugas * s.atrans;
                 radlu_c = radlu_c - radlu_c * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
             }
@@ -1657,14 +1682,16 @@ __device__ __forceinline__ double row_sum4(double v0, double v1, double v2, doub
     return y;
 }
 
-// TBL (cloud-free instantiation): the pair table of layer_src -- 10 001 x (1 - exp_tbl, tfn_tbl), 160 016 bytes -- fills
-// the workgroup's LDS, and the flux slots live in the column's block of the scratch instead (lw_flux_doubles: written
-// by one lane in four once per four layers, read by the epilogue; they never leave L2).  An evaluation of the layer
-// optics is then ~25 instructions instead of ~80 (r03: three evaluations per (layer, g-point) were half of the kernel).
+// TBL: the pair table of layer_src -- the entries from LW_PAIR_FIRST on of 10 001 x (1 - exp_tbl, tfn_tbl), 157 392 bytes
+// -- fills the workgroup's LDS, and the flux slots live in the column's block of the scratch instead (lw_flux_doubles:
+// written by one lane in four once per four layers, read by the epilogue; they never leave L2).  An evaluation of the
+// layer optics is then ~25 instructions instead of ~80 (r03: three evaluations per (layer, g-point) were half of the
+// kernel).  With McICA only the layer cloud fractions (the sub-column generator walks through them) follow the table in
+// LDS; the in-cloud water paths and sizes of the few cloudy layers are read from the column record.
 template <bool DEEP, bool CLOUD, bool TBL>   // CLOUD: McICA (icloud != 0); the cloud-free instantiation carries none of it
 __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 {
-    static_assert(!(TBL && CLOUD), "the pair table and the staged cloud state do not fit one LDS");
+    static_assert(!(TBL && DEEP), "more than 64 cloud layers: the instantiation without the table");
     extern __shared__ double lds[];
     const LwDeviceTables &tb = a.tab;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1674,18 +1701,20 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int grp = batch_slot((nbatch + RTF_COLS - 1) / RTF_COLS);
     if (grp < 0) return;   // (uniform over the workgroup, in front of its first barrier)
     const int ncols = nbatch - RTF_COLS * grp < RTF_COLS ? nbatch - RTF_COLS * grp : RTF_COLS;   // 1..7
-    const size_t recn = cloud ? rtf_cloud_doubles(nl) : 0;   // staged part of the record
-    const size_t cold = rtf_col_doubles(nl, cloud);
+    // staged part of a column's record: all of its cloud part, or (TBL) the cloud fractions alone
+    const size_t recn = cloud ? (TBL ? (size_t)nl : rtf_cloud_doubles(nl)) : 0;
+    const size_t cold = TBL ? recn : rtf_col_doubles(nl, cloud);   // a column's LDS (TBL: behind the table)
+    double *const lds_cols = TBL ? lds + 2 * LW_PAIR_COUNT : lds;
     const double2 *const LTBL = TBL ? reinterpret_cast<const double2 *>(lds) : nullptr;
     if (TBL) {
-        const double2 *src = reinterpret_cast<const double2 *>(tb.tbl_pairs);
+        const double2 *src = reinterpret_cast<const double2 *>(tb.tbl_pairs) + LW_PAIR_FIRST;
         double2 *dst = reinterpret_cast<double2 *>(lds);
-        for (int q = tid; q <= LW_NTBL; q += RTF_THREADS) dst[q] = src[q];
+        for (int q = tid; q < LW_PAIR_COUNT; q += RTF_THREADS) dst[q] = src[q];
     }
     if (cloud)
         for (int cc = 0; cc < ncols; ++cc) {
             const double *rec = a.rec + (size_t)(RTF_COLS * grp + cc) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl);
-            double *dst = lds + cc * cold;
+            double *dst = lds_cols + cc * cold;
             for (int q = tid; q < (int)recn; q += RTF_THREADS) dst[q] = rec[q];
         }
     __shared__ unsigned long long s_lmask[RTF_COLS][2];     // [column][layers 0..63, 64..127]
@@ -1704,7 +1733,10 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     int col = a.col0 + slot;
     if (a.colmap) col = a.colmap[col];   // (an existing entry: slot is clamped to the group's columns)
     const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: secdiff plankbnd pz laytrop [cloud] q4
-    const double *cb = lds + colsel * cold;
+    // cloud part of the record: cbf = the cloud fractions (LDS), cb = all of it (LDS, or with TBL the record itself)
+    const double *const cbf = lds_cols + colsel * cold;
+    const double *cb;
+    if constexpr (TBL) cb = rec + lw_rec_base_doubles(nl); else cb = lds_cols + colsel * cold;
     const int r4 = a.real4;
     double semiss;
     {
@@ -1729,9 +1761,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const size_t ws = 2 * nlev + 8;
     double *fl;                                                           // this seat's slots
     if constexpr (TBL) fl = a.flx + (size_t)slot * lw_flux_doubles(nl) + (size_t)chunk * ws;
-    else fl = lds + colsel * cold + recn + (size_t)chunk * ws;
+    else fl = lds_cols + colsel * cold + recn + (size_t)chunk * ws;
     // the lane's band in the packed part of the record: per layer (planklay, dplankdn) and (dplankup, taua)
-    const double2 *const q4 = reinterpret_cast<const double2 *>(rec + lw_rec_q4_offset(nl)) + (size_t)band * lw_rec_q4_layers(nl) * 2;
     // The lanes of a band read the same quadruple, and a band's block of four layers is one 128-byte line: the WAVE
     // fetches each line once per block -- lane 4s + j the quadruple of layer j of the wave's s-th (column, band) pair,
     // a block ahead -- and a lane takes its layer's four values from that lane's registers through the LDS crossbar
@@ -1739,7 +1770,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     // vector cache a line fill per band, layer and wave (the streaming gas optics turn the L1 over in between), 5 of the
     // kernel's 19.5 ms.  A wave's four rows hold at most 14 pairs (16 x 4 loader lanes).
     int bp_idx;                 // byte index (lane * 4) of the loader lane of this lane's pair, layer 0 of a block
-    const double2 *bp_src;      // loader lanes: the pair's quadruples (layer 0); others: nullptr
+    long long bp_off;           // loader lanes: where the pair's quadruples (layer 0) sit behind a.rec, in doubles; others: -1
     {
         const int key = colsel * LW_NBND + band, prev = __shfl_up(key, 1, 64);
         const unsigned long long firsts = __ballot(lane == 0 || key != prev);
@@ -1750,12 +1781,20 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         unsigned long long t = firsts;
         for (int i = 0; i < s_ld && t; ++i) t &= t - 1;
         const int opener = t ? __builtin_ctzll(t) : 0;
-        const unsigned long long qaddr = reinterpret_cast<unsigned long long>(q4);
-        const unsigned lo = __shfl((unsigned)qaddr, opener, 64), hi = __shfl((unsigned)(qaddr >> 32), opener, 64);
-        bp_src = t ? reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo) + 2 * (lane & 3) : nullptr;
+        // (as an offset into the scratch's record area, formed by integer arithmetic alone: a pointer put together from
+        // shuffled halves is read through flat loads, and even the conversion of a record pointer to an integer makes
+        // the compiler treat every access to the record as flat -- with a flat load in flight every wait of the loop is
+        // vmcnt(0))
+        const unsigned long long qoff = (unsigned long long)slot * lw_rec_doubles(nl) + lw_rec_q4_offset(nl) +
+                                        (unsigned long long)band * lw_rec_q4_layers(nl) * 4;
+        const unsigned lo = __shfl((unsigned)qoff, opener, 64), hi = __shfl((unsigned)(qoff >> 32), opener, 64);
+        bp_off = t ? (long long)((((unsigned long long)hi << 32) | lo) + 4 * (lane & 3)) : -1;
     }
     auto bp_fetch = [&](const int b, double2 &u, double2 &w) {   // the loader lanes' part of block b
-        if (bp_src) { u = bp_src[8 * b]; w = bp_src[8 * b + 1]; }
+        if (bp_off >= 0) {
+            const double2 *src = reinterpret_cast<const double2 *>(a.rec + bp_off) + 8 * b;
+            u = src[0]; w = src[1];
+        }
     };
     auto bp_take = [&](const int j, const double2 u, const double2 w, double &blay, double &dpdn, double &dpup, double &tak) {
         const int idx = bp_idx + 4 * j;
@@ -1781,10 +1820,10 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         for (int l = 0; l < nk; ++l) {
             double cur = kiss_next(ks);
             if (l > 0) {
-                const double cbl = cb[l - 1];
+                const double cbl = cbf[l - 1];
                 cur = prev > 1. - cbl ? prev : cur * (1. - cbl);
             }
-            if (cur >= 1. - cb[l]) {
+            if (cur >= 1. - cbf[l]) {
                 if (l < 64) cmask |= (uint64_t)1 << l; else cmhi |= (uint64_t)1 << (l - 64);
             }
             prev = cur;
@@ -1861,7 +1900,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     }
                 } else {
                     iclddn = true;
-                    const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
+                    const bool cl = k < 64 ? (cmask >> k) & 1 : (deep ? (s_cmhi[tid] >> (k - 64)) & 1 : 0);
                     const double cfm = cl ? 1. : 0.;
                     double odcld = 0., efcl = 0.;
                     if (cl) {
@@ -1869,14 +1908,14 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         efcl = 1. - exp_neg(odcld);
                     }
                     LwCldSrc s;
-                    layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                    layer_src_cld<TBL>(tb, LTBL, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                     double gassrc = s.bbd * s.atrans;
                     radld_t = radld_t - radld_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
                     radclr = radclr + (s.bbd - radclr) * s.atrans;
                     ek = __builtin_fma(s.bbugas * s.atrans, trk, ek);
                     trk = __builtin_fma(-trk, s.atrans, trk);
                     if (clean_own) {
-                        layer_src_cld(tb, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                        layer_src_cld<TBL>(tb, LTBL, taug, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                         gassrc = s.bbd * s.atrans;
                         const double A = s.atrans + efcl * (1. - s.atrans);
                         radld_c = radld_c - radld_c * A + gassrc + cfm * (s.bbdtot * s.atot - gassrc);
@@ -1943,7 +1982,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         layer_src<TBL>(tb, LTBL, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, at, bbd, bbu);
                         radlu_t = relax(radlu_t, bbu, at);
                     } else {
-                        const bool cl = k < 64 ? (cmask >> k) & 1 : (s_cmhi[tid] >> (k - 64)) & 1;
+                        const bool cl = k < 64 ? (cmask >> k) & 1 : (deep ? (s_cmhi[tid] >> (k - 64)) & 1 : 0);
                         const double cfm = cl ? 1. : 0.;
                         double odcld = 0., efcl = 0.;
                         if (cl) {
@@ -1951,7 +1990,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                             efcl = 1. - exp_neg(odcld);
                         }
                         LwCldSrc s;
-                        layer_src_cld(tb, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
+                        layer_src_cld<TBL>(tb, LTBL, taug + tak, secdiff, plfrac, blay, dplankup, dplankdn, odcld, s);
                         const double gassrc = s.bbugas * s.atrans;
                         radlu_t = radlu_t - radlu_t * (s.atrans + efcl * (1. - s.atrans)) + gassrc + cfm * (s.bbutot * s.atot - gassrc);
                     }
@@ -1983,7 +2022,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 2);
         const double *f0;
         if constexpr (TBL) f0 = a.flx + (size_t)(RTF_COLS * grp + ec_col) * lw_flux_doubles(nl);
-        else f0 = lds + ec_col * cold + recn;
+        else f0 = lds_cols + ec_col * cold + recn;
         const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
         // the chunk sums in chunk order
         auto tot = [&](size_t q) {
@@ -2029,6 +2068,8 @@ __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_e
 lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, false>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_fast_tbl_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, true>(a); }
+__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+lw_rt_fast_cld_tbl_kernel(const LwKernelArgs a) { lw_rt_fast<false, true, true>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_fast_cld_kernel(const LwKernelArgs a) { lw_rt_fast<false, true, false>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -2160,7 +2201,9 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
     const size_t lds_fast = lw_rt_fast_lds_bytes(nl, a.icloud != 0);
     // the cloud-free transfer kernel with the pair table in LDS (RRTMG_HIP_LW_TABLE=0: the re-evaluating one)
     static const bool use_tbl = [] { const char *e = std::getenv("RRTMG_HIP_LW_TABLE"); return !(e && e[0] == '0'); }();
-    const size_t lds_tbl = (size_t)(LW_NTBL + 1) * 2 * sizeof(double);
+    const size_t lds_tbl = (size_t)LW_PAIR_COUNT * 2 * sizeof(double) +
+                           (a.icloud != 0 ? (size_t)RTF_COLS * nl * sizeof(double) : 0);   // (+ the layer cloud fractions)
+    const bool tbl_fits = lds_tbl <= 160 * 1024 - 256;
     // the three-column transfer kernel holds three column records; beyond what a workgroup may have (very deep
     // columns) the one-column kernel serves the call
     const bool fast_fits = lds_fast <= 160 * 1024 - 2048;
@@ -2191,8 +2234,9 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
             if (e != hipSuccess) return e;
             attr_fast = lds_fast;
         }
-        if (use_tbl && attr_tbl == 0) {
+        if (use_tbl && tbl_fits && lds_tbl > attr_tbl) {
             hipError_t e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_tbl_kernel), lds_tbl);
+            if (e == hipSuccess) e = opt_in(reinterpret_cast<const void *>(lw_rt_fast_cld_tbl_kernel), lds_tbl);
             if (e != hipSuccess) return e;
             attr_tbl = lds_tbl;
         }
@@ -2215,9 +2259,10 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         a.col0 = c0;
         a.nbatch = n;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
-        if (!a.lwupflx && a.icloud == 0 && use_tbl) {   // no layer-flux profiles requested, no McICA
+        if (!a.lwupflx && !deep && use_tbl && tbl_fits) {   // no layer-flux profiles requested: the pair table in LDS
             const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
-            hipLaunchKernelGGL(lw_rt_fast_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
+            if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
+            else hipLaunchKernelGGL(lw_rt_fast_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
         } else if (!a.lwupflx && fast_fits) {   // no layer-flux profiles requested: what the radiation driver calls
             const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
             if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
