@@ -6,16 +6,16 @@ out=gpurun_out/probe_${tag}; mkdir -p $out
 export TMPDIR=/tmp
 cd wrfchem-arc-interactions_amd/csrc
 for v in "$@"; do
-  touch lw_kernel.hip sw_kernel.hip
+  touch lw_kernel.hip sw_kernel.hip optics_kernel.hip
   make -s EXTRA="$v" > ../../$out/build.log 2>&1 || { echo "build failed for [$v]"; tail -5 ../../$out/build.log; continue; }
   ( cd ../.. && rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 > $out/log.txt 2>&1
     f=$(find $out/t -name "*kernel_stats.csv" | head -1)
     echo "== [$v]"; python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if ("lw_" in r["Name"] or "sw_col" in r["Name"]) and "optics" not in r["Name"]:
+    if ("lw_" in r["Name"] or "sw_col" in r["Name"] or "optics" in r["Name"]):
         print("   %-50s avg %8.3f ms" % (r["Name"][:50], float(r["AverageNs"]) / 1e6))
 PY
     rm -rf $out/t )
 done
-touch lw_kernel.hip sw_kernel.hip; make -s > /dev/null 2>&1
+touch lw_kernel.hip sw_kernel.hip optics_kernel.hip; make -s > /dev/null 2>&1

@@ -62,7 +62,10 @@ constexpr int SCR_ROW = CHUNK;    // lanes of a scratch row: 448 bytes = seven w
                                   // eight idle lanes of a wave neither store nor own a slot)
 constexpr int NTHREADS = 128;     // two waves: g-chunks 0 and 1
 constexpr int NWAVE = NTHREADS / 64;
-constexpr int SW_WAVES_PER_SIMD = 3; // register budget: 12 waves per CU
+#ifndef SW_WAVES_PER_SIMD_V
+#define SW_WAVES_PER_SIMD_V 3
+#endif
+constexpr int SW_WAVES_PER_SIMD = SW_WAVES_PER_SIMD_V; // register budget: 12 waves per CU
 
 // reference atmosphere, SW:3019-3045 (preflog is 6.96 - 0.2*i)
 __constant__ double c_tref[59] = {
