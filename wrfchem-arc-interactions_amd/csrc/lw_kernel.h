@@ -55,7 +55,12 @@ hipError_t lw_upload_retab();
 __host__ __device__ inline size_t lw_rec_base_doubles(int nl) { return (size_t)nl + 34; }
 __host__ __device__ inline size_t lw_rec_q4_offset(int nl) { return (lw_rec_base_doubles(nl) + (size_t)10 * nl + 4 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t lw_rec_q4_layers(int nl) { return (size_t)4 * ((nl + 3) / 4); }
-__host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_q4_offset(nl) + (size_t)LW_NBND * lw_rec_q4_layers(nl) * 4; }
+//   tc [16][nl4] (McICA calls): the cloud absorption optical depth of every (band, layer) (cldprmc, LW:2800-2908) -- it
+//   does not depend on the sub-column, so the gas kernel forms it once and the cloudy lanes of the transfer kernel take
+//   it like the quadruples; a size out of the tables' bounds is stored as minus its kind (fatal only if a cloudy
+//   sub-column uses it, as in the reference)
+__host__ __device__ inline size_t lw_rec_tc_offset(int nl) { return lw_rec_q4_offset(nl) + (size_t)LW_NBND * lw_rec_q4_layers(nl) * 4; }
+__host__ __device__ inline size_t lw_rec_doubles(int nl) { return lw_rec_tc_offset(nl) + (size_t)LW_NBND * lw_rec_q4_layers(nl); }
 // flux slots of a column in the transfer kernel without profile outputs: per chunk of 16 g-points the downward and
 // upward flux of the call with aerosol at every level and eight small sums (lw_rt_fast in lw_kernel.hip)
 constexpr int LW_RTF_NCHUNK = 9;

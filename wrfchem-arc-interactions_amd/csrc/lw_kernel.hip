@@ -1277,6 +1277,25 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         c.secdiff[ib] = sd;
     }
+    if (a.icloud != 0 && wave != 0) {
+        // cloud absorption optical depth per (band, layer) for the transfer kernel (lw_kernel.h); the in-cloud state
+        // was written to the record by wave 0 in front of the barrier above
+        int iceflag = 3;
+        if (a.has_reqi != 0) iceflag = 4;
+        if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
+        const double *cbg = rec + lw_rec_base_doubles(nl);
+        double *tc = rec + lw_rec_tc_offset(nl);
+        for (int item = tid - 64; item < LW_NBND * (int)nl4; item += LW_THREADS - 64) {
+            const int ib = item / (int)nl4, k = item - ib * (int)nl4;
+            double v = 0.;
+            if (k < nk) {
+                int badk = 0;
+                v = lw_cloud_tau(a.cldtab, cbg, nl, ib, k, iceflag, badk);
+                if (badk) v = -(double)badk;
+            }
+            tc[item] = v;
+        }
+    }
 
     // pressure levels complete the record (heating-rate denominators of the transfer kernel)
     for (int l = tid; l <= nl; l += LW_THREADS) rec[lw_rec_base_doubles(nl) - (nl + 2) + l] = c.pz[l];
@@ -1654,10 +1673,9 @@ static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4, "a row per chunk");
 // band read the same address, a wave's load touches a handful of lines that the workgroup's other waves find in L1,
 // and without them two workgroups fit a CU whatever the layer count (staged, 3 x 25 KB at 63 layers left one).
 static_assert(LW_RTF_NCHUNK == RTF_NCHUNK, "lw_flux_doubles (lw_kernel.h) sizes the flux slots of RTF_NCHUNK chunks");
-__host__ __device__ inline size_t rtf_cloud_doubles(int nl) { return (size_t)10 * nl + 4; }
 __host__ __device__ inline size_t rtf_col_doubles(int nl, bool cloud)
 {
-    return (cloud ? rtf_cloud_doubles(nl) : 0) + (size_t)RTF_NCHUNK * (2 * (nl + 1) + 8);
+    return (cloud ? (size_t)nl : 0) + (size_t)RTF_NCHUNK * (2 * (nl + 1) + 8);   // (cloud fractions) + flux slots
 }
 
 // Sums of four values over each ROW of the wave (16 lanes): afterwards every lane of quad q of a row holds the row's
@@ -1701,8 +1719,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int grp = batch_slot((nbatch + RTF_COLS - 1) / RTF_COLS);
     if (grp < 0) return;   // (uniform over the workgroup, in front of its first barrier)
     const int ncols = nbatch - RTF_COLS * grp < RTF_COLS ? nbatch - RTF_COLS * grp : RTF_COLS;   // 1..7
-    // staged part of a column's record: all of its cloud part, or (TBL) the cloud fractions alone
-    const size_t recn = cloud ? (TBL ? (size_t)nl : rtf_cloud_doubles(nl)) : 0;
+    // staged part of a column's record: the layer cloud fractions (the sub-column generator walks through them)
+    const size_t recn = cloud ? (size_t)nl : 0;
     const size_t cold = TBL ? recn : rtf_col_doubles(nl, cloud);   // a column's LDS (TBL: behind the table)
     double *const lds_cols = TBL ? lds + 2 * LW_PAIR_COUNT : lds;
     const double2 *const LTBL = TBL ? reinterpret_cast<const double2 *>(lds) : nullptr;
@@ -1733,10 +1751,9 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     int col = a.col0 + slot;
     if (a.colmap) col = a.colmap[col];   // (an existing entry: slot is clamped to the group's columns)
     const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: secdiff plankbnd pz laytrop [cloud] q4
-    // cloud part of the record: cbf = the cloud fractions (LDS), cb = all of it (LDS, or with TBL the record itself)
+    // cloud part of the record: cbf = the cloud fractions (LDS), cb = all of it (the record: the four seeds)
     const double *const cbf = lds_cols + colsel * cold;
-    const double *cb;
-    if constexpr (TBL) cb = rec + lw_rec_base_doubles(nl); else cb = lds_cols + colsel * cold;
+    const double *const cb = rec + lw_rec_base_doubles(nl);
     const int r4 = a.real4;
     double semiss;
     {
@@ -1771,6 +1788,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     // kernel's 19.5 ms.  A wave's four rows hold at most 14 pairs (16 x 4 loader lanes).
     int bp_idx;                 // byte index (lane * 4) of the loader lane of this lane's pair, layer 0 of a block
     long long bp_off;           // loader lanes: where the pair's quadruples (layer 0) sit behind a.rec, in doubles; others: -1
+    long long bp_tc;            // ... and its cloud optical depths (McICA instantiations)
     {
         const int key = colsel * LW_NBND + band, prev = __shfl_up(key, 1, 64);
         const unsigned long long firsts = __ballot(lane == 0 || key != prev);
@@ -1789,12 +1807,25 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                                         (unsigned long long)band * lw_rec_q4_layers(nl) * 4;
         const unsigned lo = __shfl((unsigned)qoff, opener, 64), hi = __shfl((unsigned)(qoff >> 32), opener, 64);
         bp_off = t ? (long long)((((unsigned long long)hi << 32) | lo) + 4 * (lane & 3)) : -1;
+        bp_tc = 0;
+        if (cloud) {
+            const unsigned long long toff = (unsigned long long)slot * lw_rec_doubles(nl) + lw_rec_tc_offset(nl) +
+                                            (unsigned long long)band * lw_rec_q4_layers(nl);
+            const unsigned tlo = __shfl((unsigned)toff, opener, 64), thi = __shfl((unsigned)(toff >> 32), opener, 64);
+            bp_tc = (long long)((((unsigned long long)thi << 32) | tlo) + (lane & 3));
+        }
     }
-    auto bp_fetch = [&](const int b, double2 &u, double2 &w) {   // the loader lanes' part of block b
+    auto bp_fetch = [&](const int b, double2 &u, double2 &w, double &tcv) {   // the loader lanes' part of block b
         if (bp_off >= 0) {
             const double2 *src = reinterpret_cast<const double2 *>(a.rec + bp_off) + 8 * b;
             u = src[0]; w = src[1];
+            if (cloud) tcv = a.rec[bp_tc + 4 * b];
         }
+    };
+    auto bp_take1 = [&](const int j, const double x) {
+        const int idx = bp_idx + 4 * j;
+        return __hiloint2double(__builtin_amdgcn_ds_bpermute(idx, __double2hiint(x)),
+                                __builtin_amdgcn_ds_bpermute(idx, __double2loint(x)));
     };
     auto bp_take = [&](const int j, const double2 u, const double2 w, double &blay, double &dpdn, double &dpup, double &tak) {
         const int idx = bp_idx + 4 * j;
@@ -1808,10 +1839,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
 
     uint64_t cmask = 0;
     constexpr bool deep = DEEP;
-    int iceflag = 3;
     if (cloud) {
-        if (a.has_reqi != 0) iceflag = 4;
-        if (a.has_reqs != 0 || (a.has_reqi != 0 && a.has_reqc != 0)) iceflag = 5;
         KissState ks = {(uint32_t)(int)cb[10 * nl + 0], (uint32_t)(int)cb[10 * nl + 1], (uint32_t)(int)cb[10 * nl + 2],
                         (uint32_t)(int)cb[10 * nl + 3]};
         kiss_jump(ks, a.jump + (size_t)g * KISS_JUMP_WORDS);
@@ -1863,13 +1891,15 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         if (k < nl) { T4[j] = tgw[j * ng]; F4[j] = frac_read(FS, tgw + j * ng, k); }
     }
     double2 qu = make_double2(0., 0.), qw = qu;
-    bp_fetch(nblk - 1, qu, qw);
+    double qt = 0.;
+    bp_fetch(nblk - 1, qu, qw, qt);
     for (int b = nblk - 1; b >= 0; --b) {
         double v[4] = {0., 0., 0., 0.};
         double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
         double2 qun = make_double2(0., 0.), qwn = qun;
+        double qtn = 0.;
         if (b > 0) {
-            bp_fetch(b - 1, qun, qwn);
+            bp_fetch(b - 1, qun, qwn, qtn);
             tgw -= 4 * ng;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { Tn[j] = tgw[j * ng]; Fn[j] = frac_read(FS, tgw + j * ng, 4 * (b - 1) + j); }
@@ -1881,6 +1911,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                 const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
                 double blay, dplankdn, dplankup, tak;
                 bp_take(j, qu, qw, blay, dplankdn, dplankup, tak);
+                double tcv = cloud ? bp_take1(j, qt) : 0.;   // (here, where every lane takes part in the exchange)
                 const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
                 if (!lay_cld) {
                     double at, bbd, bbu;
@@ -1904,7 +1935,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     const double cfm = cl ? 1. : 0.;
                     double odcld = 0., efcl = 0.;
                     if (cl) {
-                        odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);   // LW:3172-3176
+                        if (tcv < 0.) { bad = (int)(-tcv); tcv = 0.; }   // a size out of bounds, used (lw_kernel.h)
+                        odcld = secdiff * tcv;   // LW:3172-3176
                         efcl = 1. - exp_neg(odcld);
                     }
                     LwCldSrc s;
@@ -1934,7 +1966,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
         if (b > 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
-            qu = qun; qw = qwn;
+            qu = qun; qw = qwn; qt = qtn;
         }
     }
     // ---- surface: emission + reflection, LW:3320-3324 ----
@@ -1960,8 +1992,9 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             double v[4] = {0., 0., 0., 0.};
             double Tn[4] = {0., 0., 0., 0.}, Fn[4] = {0., 0., 0., 0.};
             double2 qun = make_double2(0., 0.), qwn = qun;
+            double qtn = 0.;
             if (b + 1 < nblk) {
-                bp_fetch(b + 1, qun, qwn);
+                bp_fetch(b + 1, qun, qwn, qtn);
                 tgw += 4 * ng;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1976,6 +2009,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                     const double taug = T4[j], plfrac = frac_value(FS, F4[j], k);
                     double blay, dplankdn, dplankup, tak;
                     bp_take(j, qu, qw, blay, dplankdn, dplankup, tak);
+                    double tcv = cloud ? bp_take1(j, qt) : 0.;
                     const bool lay_cld = k < 64 ? (lmask >> k) & 1 : (deep && k < 128 && ((lmask_hi >> (k - 64)) & 1));
                     if (!lay_cld) {
                         double at, bbd, bbu;
@@ -1986,7 +2020,8 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
                         const double cfm = cl ? 1. : 0.;
                         double odcld = 0., efcl = 0.;
                         if (cl) {
-                            odcld = secdiff * lw_cloud_tau(a.cldtab, cb, nl, band, k, iceflag, bad);
+                            if (tcv < 0.) { bad = (int)(-tcv); tcv = 0.; }
+                            odcld = secdiff * tcv;
                             efcl = 1. - exp_neg(odcld);
                         }
                         LwCldSrc s;
@@ -2002,7 +2037,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
             if (writer && b * 4 + jw < nl) fl[nlev + b * 4 + 1 + jw] = qs;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { T4[j] = Tn[j]; F4[j] = Fn[j]; }
-            qu = qun; qw = qwn;
+            qu = qun; qw = qwn; qt = qtn;
         }
     }
     if (bad && live) atomicMax(a.status, (bad << 28) | (1 + col));
