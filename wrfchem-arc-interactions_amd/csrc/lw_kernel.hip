@@ -253,7 +253,7 @@ __device__ __forceinline__ LCol carve_rt(double *base, int nl, bool cloud)
     c.pz = p; p += nl + 1;
     c.q4 = base + lw_rec_q4_offset(nl);
     // after the image of the whole record; [3 waves][4 or 6][nl+1]
-    c.flux = base + lw_rec_doubles(nl);
+    c.flux = base + lw_rec_tc_offset(nl);   // (the record without its last part, which this kernel does not read)
     (void)cloud;
     return c;
 }
@@ -1420,7 +1420,9 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
     const int nslot = a.icloud != 0 ? 6 : 4;   // flux slots per wave: + clear-sky down / up with clouds
     {
         const double *rec = a.rec + (size_t)slot * lw_rec_doubles(nl);
-        const int n = (int)lw_rec_doubles(nl);   // (the cloud part is written only when icloud != 0; it is not read otherwise)
+        // (everything in front of the per-band cloud optical depths: this kernel forms them itself from the in-cloud
+        // state; the cloud part is written only when icloud != 0 and is not read otherwise)
+        const int n = (int)lw_rec_tc_offset(nl);
         for (int q = tid; q < n; q += LW_THREADS) lds[q] = rec[q];
     }
     // cloud part of the record: cldf clwp ciwp cswp fliq fice fsno iliq iice isno [nl] each, seeds[4]
@@ -2140,7 +2142,7 @@ size_t lw_rt_fast_lds_bytes(int nl, bool cloud)
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
-    return (lw_rec_doubles(nl) + (size_t)3 * (cloud ? 6 : 4) * (nl + 1)) * sizeof(double);
+    return (lw_rec_tc_offset(nl) + (size_t)3 * (cloud ? 6 : 4) * (nl + 1)) * sizeof(double);
 }
 
 // band descriptors and the order of the gas-optics segments (see lw_gas_kernel)
