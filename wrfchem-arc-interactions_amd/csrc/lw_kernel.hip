@@ -821,6 +821,13 @@ __device__ __forceinline__ int batch_columns(const LwKernelArgs &a)
     return n;
 }
 
+// the gas optics leave the chip once and are read back by another kernel: streaming (non-temporal) stores, so that the
+// 46 GB of a launch do not push the spectroscopic tables out of L2 on their way
+__device__ __forceinline__ void st2_stream(double *p, const double2 v)
+{
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+}
 // Kernel 1 of 2: column set-up (inatm + setcoef, lanes = layers) and gaseous optical depths / Planck
 // fractions of every (layer, g-point) (taumol, lanes = g-points) -> scratch.
 __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) lw_gas_kernel(const LwKernelArgs a)
@@ -919,7 +926,7 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int nb = 0; nb < LW_NBND; ++nb) {
                 const double v = on ? t[nb] : 0.;
-                c.q4[((size_t)nb * nl4 + k) * 4 + 3] = v;
+                __builtin_nontemporal_store(v, &c.q4[((size_t)nb * nl4 + k) * 4 + 3]);
                 asum[nb] += v;
             }
         }
@@ -1243,7 +1250,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                 plev[m] = P[indlev - 1] + tlevfrac * dbdtlev;
             }
             double *q = c.q4 + ((size_t)ib * nl4 + k) * 4;
-            q[0] = blay; q[1] = plev[0] - blay; q[2] = plev[1] - blay;
+            __builtin_nontemporal_store(blay, q); __builtin_nontemporal_store(plev[0] - blay, q + 1);
+            __builtin_nontemporal_store(plev[1] - blay, q + 2);
         }
         if (tid >= 128 && tid < 128 + LW_NBND) {   // the boundary
             const int ib = tid - 128;
@@ -1374,8 +1382,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
                     double2 taug, plfrac;
                     gas_item_binary(tb, c, R, B.stride, B.off_self, B.off_for, G, ppd, ppi, k, l, cont, taug, plfrac);
                     if (act) {
-                        *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
-                        if (frac_stored) *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
+                        st2_stream(tgb + (size_t)k * ng, taug);
+                        if (frac_stored) st2_stream(frb + (size_t)k * ng, plfrac);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -1389,8 +1397,8 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             double2 taug, plfrac;
             gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, cont, taug, plfrac);
             if (act) {
-                *reinterpret_cast<double2 *>(tgb + (size_t)k * ng) = taug;
-                if (frac_stored) *reinterpret_cast<double2 *>(frb + (size_t)k * ng) = plfrac;
+                st2_stream(tgb + (size_t)k * ng, taug);
+                if (frac_stored) st2_stream(frb + (size_t)k * ng, plfrac);
             }
         }
     }
