@@ -14,7 +14,7 @@ for v in "$@"; do
   echo "== $v"; python3 - "$fcsv" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if ("lw_" in r["Name"] or "sw_col" in r["Name"]) and "optics" not in r["Name"] and "fill" not in r["Name"]:
+    if ("lw_" in r["Name"] or "sw_col" in r["Name"] or "optics" in r["Name"]) and "fill" not in r["Name"]:
         print("   %-50s avg %8.3f ms" % (r["Name"][:50], float(r["AverageNs"]) / 1e6))
 PY
   rm -rf $out/t
