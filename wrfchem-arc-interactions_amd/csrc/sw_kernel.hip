@@ -705,6 +705,40 @@ __device__ __forceinline__ void add_on_top(Stack &s, const RT &b)
 
 }  // namespace
 
+// O3DATA (LW:12806-12836): the annual-mean ozone mixing ratio of the layer between plev_b and plev_t (mb)
+__device__ __forceinline__ double sw_o3clim(const double plev_b, const double plev_t)
+{
+    double o3mmr = 0.;
+    for (int jj = 0; jj < 31; ++jj) {
+        double pb1 = (-(plev_b - c_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj];
+        double pb2 = (-(plev_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj + 1];
+        double pt1 = (-(plev_t - c_ppwrkh[jj]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj];
+        double pt2 = (-(plev_t - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj + 1];
+        o3mmr = o3mmr + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
+    }
+    return o3mmr / (plev_b - plev_t);
+}
+
+// ozone volume mixing ratio of layer k from the climatology o3mmr, or (o3input = 2) from the model's field, SW:10661-10680
+__device__ __forceinline__ double sw_o3vmr(const SwKernelArgs &a, const size_t base3, const size_t sk, const int r4, const int k,
+                                           const int nk, const double plev_b, const double o3mmr)
+{
+    const double amdo = 0.603461;
+    double o3vmr = o3mmr * amdo;
+    if (a.o33d && a.o3input == 2) {
+        if (k != nk) {
+            o3vmr = ldr(a.o33d, base3 + (size_t)k * sk, r4);
+        } else {
+            // o31d(kte) - o3mmr(kte)*amdo + o3mmr(k)*amdo needs the climatology of the layer below
+            const double pb_b = ldr(a.p8w, base3 + (size_t)(nk - 1) * sk, r4) / 100.;
+            const double o3b = sw_o3clim(pb_b, plev_b);
+            const double v = ldr(a.o33d, base3 + (size_t)(nk - 1) * sk, r4) - o3b * amdo + o3mmr * amdo;
+            o3vmr = v <= 0. ? o3mmr * amdo : v;
+        }
+    }
+    return o3vmr;
+}
+
 // One column: vb = position of the column in the XCD-interleaved order, scr_block = this workgroup's slice of the
 // layer scratch.  CLOUD: icloud /= 0 (McICA sub-columns); PROF: the optional layer-flux profiles are requested.
 template <bool CLOUD, bool PROF>
@@ -765,6 +799,17 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
 
     // ======================= prologue: lanes = layers =======================
     bool lowerp = false;
+    // With at most 64 layers the second wave holds none: it forms the ozone climatology of the layers (a 31-step sum each,
+    // a third of the set-up's instructions) while the first does the rest; the ozone amount follows behind the barrier.
+    const bool o3_split = nlp <= 64;
+    double *const o3tmp = c.flux;   // (the flux slots are idle until the sweeps)
+    double coldry_k = 0., plev_b_k = 0.;
+    if (o3_split && wave == 1 && lane < nlay) {
+        const int k = lane;
+        const double pb = ldr(a.p8w, base3 + (size_t)k * sk, r4) / 100.;
+        const double pt = k == nk ? 1.0e-5 : ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4) / 100.;
+        o3tmp[k] = sw_o3clim(pb, pt);
+    }
     if (tid < nlp) {
         const int k = tid;
         if (k < nlay) {
@@ -778,38 +823,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             double qv = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
             qv = fmax(0., qv);
             qv = fmax(qv, 1.E-12);
-            const double amdw = 1.607793, amdo = 0.603461;
+            const double amdw = 1.607793;
             double h2ovmr = qv * amdw;
-            // O3 climatology, O3DATA LW:12806-12836
-            double o3mmr = 0.;
-            for (int jj = 0; jj < 31; ++jj) {
-                double pb1 = (-(plev_b - c_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj];
-                double pb2 = (-(plev_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj + 1];
-                double pt1 = (-(plev_t - c_ppwrkh[jj]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj];
-                double pt2 = (-(plev_t - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj + 1];
-                o3mmr = o3mmr + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
-            }
-            o3mmr = o3mmr / (plev_b - plev_t);
-            double o3vmr = o3mmr * amdo;
-            if (a.o33d && a.o3input == 2) {   // SW:10661-10680
-                if (!top) {
-                    o3vmr = ldr(a.o33d, base3 + (size_t)k * sk, r4);
-                } else {
-                    // o31d(kte) - o3mmr(kte)*amdo + o3mmr(k)*amdo needs the climatology of the layer below
-                    double pb_b = ldr(a.p8w, base3 + (size_t)(nk - 1) * sk, r4) / 100.;
-                    double o3b = 0.;
-                    for (int jj = 0; jj < 31; ++jj) {
-                        double pb1 = (-(pb_b - c_ppwrkh[jj]) >= 0.) ? 0. : pb_b - c_ppwrkh[jj];
-                        double pb2 = (-(pb_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : pb_b - c_ppwrkh[jj + 1];
-                        double pt1 = (-(plev_b - c_ppwrkh[jj]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj];
-                        double pt2 = (-(plev_b - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_b - c_ppwrkh[jj + 1];
-                        o3b = o3b + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
-                    }
-                    o3b = o3b / (pb_b - plev_b);
-                    double v = ldr(a.o33d, base3 + (size_t)(nk - 1) * sk, r4) - o3b * amdo + o3mmr * amdo;
-                    o3vmr = v <= 0. ? o3mmr * amdo : v;
-                }
-            }
+            // O3 climatology, O3DATA LW:12806-12836 (o3_split: by the other wave, see above; the amount follows below)
+            double o3vmr = 0.;
+            if (!o3_split) o3vmr = sw_o3vmr(a, base3, sk, r4, k, nk, plev_b, sw_o3clim(plev_b, plev_t));
             // inatm_sw, SW:9777-9779 and SW:9810-9814
             const double avogad = 6.02214199e+23, grav = 9.8066, amd = 28.9660, amw = 18.0160;
             const double co2 = 379.e-6, ch4 = 1774.e-9, o2 = 0.209488;
@@ -818,6 +836,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             double coldry = (plev_b - plev_t) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + h2ovmr));
             double wh2o = coldry * h2ovmr, wco2 = coldry * co2, wo3 = coldry * o3vmr, wch4 = coldry * ch4,
                    wo2 = coldry * o2;
+            coldry_k = coldry; plev_b_k = plev_b;
             // setcoef_sw, SW:2850-2987
             const double stpfac = 296. / 1013.;
             double plog = log(pavel);
@@ -1034,6 +1053,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     if (tid == 0) c.jp[nlp] = 0;
     // laytrop = number of layers with ln(p) > 4.56 (SW:2890)
     const int laytrop = __syncthreads_count(lowerp ? 1 : 0);
+    if (o3_split && tid < nlay) {
+        // colo3 = 1e-20 * (coldry * o3vmr), SW:9810-9814, with the climatology the other wave has formed
+        const double o3vmr = sw_o3vmr(a, base3, sk, r4, tid, nk, plev_b_k, o3tmp[tid]);
+        c.col[SP_O3 * nlp + tid] = 1.e-20 * (coldry_k * o3vmr);
+    }
 
     // aerosol: defaults, then 300/400/600/999 nm -> 14 bands (SW:10974-11023)
     if (compact) {
