@@ -716,7 +716,7 @@ __device__ __forceinline__ double sw_o3clim(const double plev_b, const double pl
         double pt2 = (-(plev_t - c_ppwrkh[jj + 1]) >= 0.) ? 0. : plev_t - c_ppwrkh[jj + 1];
         o3mmr = o3mmr + (pb2 - pb1 - pt2 + pt1) * c_o3ann[jj];
     }
-    return o3mmr / (plev_b - plev_t);
+    return fdiv(o3mmr, plev_b - plev_t);
 }
 
 // ozone volume mixing ratio of layer k from the climatology o3mmr, or (o3input = 2) from the model's field, SW:10661-10680
@@ -806,8 +806,8 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
     double coldry_k = 0., plev_b_k = 0.;
     if (o3_split && wave == 1 && lane < nlay) {
         const int k = lane;
-        const double pb = ldr(a.p8w, base3 + (size_t)k * sk, r4) / 100.;
-        const double pt = k == nk ? 1.0e-5 : ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4) / 100.;
+        const double pb = fdiv(ldr(a.p8w, base3 + (size_t)k * sk, r4), 100.);
+        const double pt = k == nk ? 1.0e-5 : fdiv(ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4), 100.);
         o3tmp[k] = sw_o3clim(pb, pt);
     }
     if (tid < nlp) {
@@ -816,9 +816,11 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             // 1-D profile, SW:10340-10390, 10628-10656 (extra layer to 1e-5 mb on top)
             const bool top = (k == nk);
             const int km = top ? nk - 1 : k;
-            double plev_b = ldr(a.p8w, base3 + (size_t)k * sk, r4) / 100.;
-            double plev_t = top ? 1.0e-5 : ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4) / 100.;
-            double pavel = top ? 0.5 * plev_b : ldr(a.p3d, base3 + (size_t)k * sk, r4) / 100.;
+            // (the quotients of the set-up through fdiv: the correctly rounded quotient in 8 instructions where the
+            // compiler's IEEE division takes 30 -- this block is one wave's serial path)
+            double plev_b = fdiv(ldr(a.p8w, base3 + (size_t)k * sk, r4), 100.);
+            double plev_t = top ? 1.0e-5 : fdiv(ldr(a.p8w, base3 + (size_t)(k + 1) * sk, r4), 100.);
+            double pavel = top ? 0.5 * plev_b : fdiv(ldr(a.p3d, base3 + (size_t)k * sk, r4), 100.);
             double tavel = top ? ldr(a.t8w, base3 + (size_t)k * sk, r4) + 0.0 : ldr(a.t3d, base3 + (size_t)k * sk, r4);
             double qv = ldr(a.qv3d, base3 + (size_t)km * sk, r4);
             qv = fmax(0., qv);
@@ -833,7 +835,7 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             const double co2 = 379.e-6, ch4 = 1774.e-9, o2 = 0.209488;
             double pdp = plev_b - plev_t;
             double amm = (1. - h2ovmr) * amd + h2ovmr * amw;
-            double coldry = (plev_b - plev_t) * 1.e3 * avogad / (1.e2 * grav * amm * (1. + h2ovmr));
+            double coldry = fdiv((plev_b - plev_t) * 1.e3 * avogad, 1.e2 * grav * amm * (1. + h2ovmr));
             double wh2o = coldry * h2ovmr, wco2 = coldry * co2, wo3 = coldry * o3vmr, wch4 = coldry * ch4,
                    wo2 = coldry * o2;
             coldry_k = coldry; plev_b_k = plev_b;
@@ -844,31 +846,31 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
             jp = jp < 1 ? 1 : (jp > 58 ? 58 : jp);
             int jp1 = jp + 1;
             double fp = 5. * (c_preflog[jp - 1] - plog);
-            double d0 = (tavel - c_tref[jp - 1]) / 15.;
+            double d0 = fdiv(tavel - c_tref[jp - 1], 15.);
             int jtt = (int)(3. + d0);
             jtt = jtt < 1 ? 1 : (jtt > 4 ? 4 : jtt);
             double ft = d0 - (double)(jtt - 3);
-            double d1 = (tavel - c_tref[jp1 - 1]) / 15.;
+            double d1 = fdiv(tavel - c_tref[jp1 - 1], 15.);
             int jt1 = (int)(3. + d1);
             jt1 = jt1 < 1 ? 1 : (jt1 > 4 ? 4 : jt1);
             double ft1 = d1 - (double)(jt1 - 3);
-            double water = wh2o / coldry;
-            double scalefac = pavel * stpfac / tavel;
+            double water = fdiv(wh2o, coldry);
+            double scalefac = fdiv(pavel * stpfac, tavel);
             lowerp = plog > 4.56;
-            double forfac = scalefac / (1. + water), forfrac, selffac = 0., selffrac = 0.;
+            double forfac = fdiv(scalefac, 1. + water), forfrac, selffac = 0., selffrac = 0.;
             int indfor, indself = 1;
             if (lowerp) {
-                double factor = (332.0 - tavel) / 36.0;
+                double factor = fdiv(332.0 - tavel, 36.0);
                 int ifac = (int)factor;
                 indfor = ifac > 1 ? (ifac < 2 ? ifac : 2) : 1;
                 forfrac = factor - (double)indfor;
                 selffac = water * forfac;
-                factor = (tavel - 188.0) / 7.2;
+                factor = fdiv(tavel - 188.0, 7.2);
                 int is = (int)factor - 7;
                 indself = is > 1 ? (is < 9 ? is : 9) : 1;
                 selffrac = factor - (double)(indself + 7);
             } else {
-                double factor = (tavel - 188.0) / 36.0;
+                double factor = fdiv(tavel - 188.0, 36.0);
                 indfor = 3;
                 forfrac = factor - 1.0;
             }
