@@ -23,8 +23,10 @@ def main(tmp, out):
     for tag, (ni, nj, nk, p_top) in (("k40", (11, 9, 40, 5000.0)), ("k60", (7, 5, 60, 1000.0))):
         st = wa.synth.make_wrf_state(ni, nj, nk, seed=20261300 + nk, night_fraction=0.0)
         wa.engine_lw.rrtmg_lwinit(p_top, lw_tab, kme=nk + 1, device=0)
+        cloud = wa.synth_clouds.add_clouds(st, seed=20261400 + nk, cloudy_fraction=0.6)   # McICA: lw_rt_fast_cld(_tbl)_kernel
         for sub, kw in (("aer", dict(profiles=False)), ("noclean", dict(profiles=False, clean=0)),
-                        ("tile", dict(profiles=False, tile=dict(its=2, ite=ni - 1, jts=2, jte=nj - 1)))):
+                        ("tile", dict(profiles=False, tile=dict(its=2, ite=ni - 1, jts=2, jte=nj - 1))),
+                        ("cloud", dict(profiles=False, cloud=cloud)), ("cloud_noaer", dict(profiles=False, cloud=cloud, aer=0))):
             for n, v in run_hip_lwrad(wa.engine_lw, st, device=True, **kw).items():
                 res[f"{tag}_{sub}_{n}"] = np.asarray(v)
     np.savez(out, **res)

@@ -21,7 +21,8 @@ def test_pair_table_in_lds_gives_the_bits_of_the_reevaluated_entries(hip_lib, tm
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "LWTABLE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         outs[mode] = np.load(out)
-    assert set(outs["0"].files) == set(outs["1"].files) and len(outs["0"].files) > 40
+    assert set(outs["0"].files) == set(outs["1"].files) and len(outs["0"].files) > 70
+    assert any(n.startswith("k40_cloud_") for n in outs["0"].files)
     for n in outs["0"].files:
         np.testing.assert_array_equal(outs["0"][n], outs["1"][n], err_msg=n)
     assert np.isfinite(outs["1"]["k40_aer_lwupt"]).all() and (outs["1"]["k40_aer_lwupt"] > 0).all()
