@@ -1675,8 +1675,14 @@ __device__ __forceinline__ void lw_rt_body(const LwKernelArgs &a)
 // are added in chunk order: a column's sums are formed the same way whichever rows it has (results do not depend on
 // the tiling of the domain).
 constexpr int RTF_COLS = 7, RTF_WAVES = 16, RTF_THREADS = RTF_WAVES * 64, RTF_CHUNK = 16, RTF_NCHUNK = 9;
+// The McICA instantiations: FIVE columns on TWELVE waves (45 of 48 rows), i.e. three waves per SIMD and 168 VGPRs -- on
+// sixteen waves (128 VGPRs) the clear-sky stream and the cloudy-layer terms spilled 300 bytes per lane, 40 spill
+// accesses per layer of the downward sweep, each of them a vector-memory operation in the loop's wait queue.
+constexpr int RTF_CLD_COLS = 5, RTF_CLD_WAVES = 12, RTF_CLD_THREADS = RTF_CLD_WAVES * 64;
 static_assert(RTF_CHUNK * RTF_NCHUNK >= LW_NGPT && RTF_CHUNK * (RTF_NCHUNK - 1) < LW_NGPT, "chunks must cover the g-points");
-static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4, "a row per chunk");
+static_assert(RTF_COLS * RTF_NCHUNK <= RTF_WAVES * 4 && RTF_CLD_COLS * RTF_NCHUNK <= RTF_CLD_WAVES * 4, "a row per chunk");
+__host__ __device__ constexpr int rtf_cols(bool cloud) { return cloud ? RTF_CLD_COLS : RTF_COLS; }
+__host__ __device__ constexpr int rtf_threads(bool cloud) { return cloud ? RTF_CLD_THREADS : RTF_THREADS; }
 
 // LDS per column: the in-cloud state of the column (McICA instantiations only) and the flux slots of its five chunks.
 // The per-band arrays of the column record (Planck functions, aerosol optical depth) are NOT staged: the lanes of a
@@ -1725,10 +1731,11 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nk = a.nk, nl = a.nlayers;
     constexpr bool cloud = CLOUD;
+    constexpr int NCOL = rtf_cols(CLOUD), NTHR = rtf_threads(CLOUD);   // columns and threads of the workgroup
     const int nbatch = batch_columns(a);
-    const int grp = batch_slot((nbatch + RTF_COLS - 1) / RTF_COLS);
+    const int grp = batch_slot((nbatch + NCOL - 1) / NCOL);
     if (grp < 0) return;   // (uniform over the workgroup, in front of its first barrier)
-    const int ncols = nbatch - RTF_COLS * grp < RTF_COLS ? nbatch - RTF_COLS * grp : RTF_COLS;   // 1..7
+    const int ncols = nbatch - NCOL * grp < NCOL ? nbatch - NCOL * grp : NCOL;   // 1..7
     // staged part of a column's record: the layer cloud fractions (the sub-column generator walks through them)
     const size_t recn = cloud ? (size_t)nl : 0;
     const size_t cold = TBL ? recn : rtf_col_doubles(nl, cloud);   // a column's LDS (TBL: behind the table)
@@ -1737,17 +1744,17 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     if (TBL) {
         const double2 *src = reinterpret_cast<const double2 *>(tb.tbl_pairs) + LW_PAIR_FIRST;
         double2 *dst = reinterpret_cast<double2 *>(lds);
-        for (int q = tid; q < LW_PAIR_COUNT; q += RTF_THREADS) dst[q] = src[q];
+        for (int q = tid; q < LW_PAIR_COUNT; q += NTHR) dst[q] = src[q];
     }
     if (cloud)
         for (int cc = 0; cc < ncols; ++cc) {
-            const double *rec = a.rec + (size_t)(RTF_COLS * grp + cc) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl);
+            const double *rec = a.rec + (size_t)(NCOL * grp + cc) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl);
             double *dst = lds_cols + cc * cold;
-            for (int q = tid; q < (int)recn; q += RTF_THREADS) dst[q] = rec[q];
+            for (int q = tid; q < (int)recn; q += NTHR) dst[q] = rec[q];
         }
-    __shared__ unsigned long long s_lmask[RTF_COLS][2];     // [column][layers 0..63, 64..127]
-    __shared__ unsigned long long s_cmhi[RTF_THREADS];
-    if (tid < 2 * RTF_COLS) s_lmask[tid >> 1][tid & 1] = 0ull;
+    __shared__ unsigned long long s_lmask[NCOL][2];     // [column][layers 0..63, 64..127]
+    __shared__ unsigned long long s_cmhi[NTHR];
+    if (tid < 2 * NCOL) s_lmask[tid >> 1][tid & 1] = 0ull;
 
     // this lane's seat: row -> (column, chunk); lanes 12..15 of a column's last chunk and the 64th row are idle
     const int seat = 4 * wave + (lane >> 4), l16 = lane & 15;
@@ -1757,7 +1764,7 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const bool live = seat_on && graw < LW_NGPT;              // a lane with a g-point of an existing column
     const int colsel = seat_on ? scol : 0;                    // idle seats shadow column 0 (no stores, nothing summed)
     const int g = graw < LW_NGPT ? graw : LW_NGPT - 1;
-    const int slot = RTF_COLS * grp + colsel;
+    const int slot = NCOL * grp + colsel;
     int col = a.col0 + slot;
     if (a.colmap) col = a.colmap[col];   // (an existing entry: slot is clamped to the group's columns)
     const double *const rec = a.rec + (size_t)slot * lw_rec_doubles(nl);   // global: secdiff plankbnd pz laytrop [cloud] q4
@@ -2057,16 +2064,16 @@ __device__ __forceinline__ void lw_rt_fast(const LwKernelArgs &a)
     const int ec_col = wave >> 1;
     if (ec_col < ncols) {
         const int etid = tid & 127;
-        int ecol = a.col0 + RTF_COLS * grp + ec_col;
+        int ecol = a.col0 + NCOL * grp + ec_col;
         if (a.colmap) ecol = a.colmap[ecol];
         const int eit = ecol % a.ni_t, ejt = ecol / a.ni_t;
         const size_t ei0 = (size_t)(a.its - a.ims + eit), ej0 = (size_t)(a.jts - a.jms + ejt), k0 = (size_t)(a.kts - a.kms);
         const size_t ei2 = ej0 * a.ni_m + ei0;
         const size_t sk = a.ni_m, sj = (size_t)a.ni_m * a.nk_m;
         const size_t base3 = ej0 * sj + k0 * sk + ei0;
-        const double *pz = a.rec + (size_t)(RTF_COLS * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 2);
+        const double *pz = a.rec + (size_t)(NCOL * grp + ec_col) * lw_rec_doubles(nl) + lw_rec_base_doubles(nl) - (nl + 2);
         const double *f0;
-        if constexpr (TBL) f0 = a.flx + (size_t)(RTF_COLS * grp + ec_col) * lw_flux_doubles(nl);
+        if constexpr (TBL) f0 = a.flx + (size_t)(NCOL * grp + ec_col) * lw_flux_doubles(nl);
         else f0 = lds_cols + ec_col * cold + recn;
         const bool e_cloudy = cloud && (s_lmask[ec_col][0] != 0 || (deep && s_lmask[ec_col][1] != 0));
         // the chunk sums in chunk order
@@ -2113,11 +2120,11 @@ __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_e
 lw_rt_fast_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, false>(a); }
 __global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_fast_tbl_kernel(const LwKernelArgs a) { lw_rt_fast<false, false, true>(a); }
-__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(RTF_CLD_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 lw_rt_fast_cld_tbl_kernel(const LwKernelArgs a) { lw_rt_fast<false, true, true>(a); }
-__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(RTF_CLD_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 lw_rt_fast_cld_kernel(const LwKernelArgs a) { lw_rt_fast<false, true, false>(a); }
-__global__ void __launch_bounds__(RTF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(RTF_CLD_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 lw_rt_fast_deep_kernel(const LwKernelArgs a) { lw_rt_fast<true, true, false>(a); }
 __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lw_rt_deep_kernel(const LwKernelArgs a) { lw_rt_body<true>(a); }
@@ -2146,7 +2153,7 @@ size_t lw_gas_lds_bytes(int nl, bool stage_cont)
 }
 size_t lw_rt_fast_lds_bytes(int nl, bool cloud)
 {
-    return RTF_COLS * rtf_col_doubles(nl, cloud) * sizeof(double);
+    return rtf_cols(cloud) * rtf_col_doubles(nl, cloud) * sizeof(double);
 }
 size_t lw_rt_lds_bytes(int nl, bool cloud)
 {
@@ -2247,7 +2254,7 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
     // the cloud-free transfer kernel with the pair table in LDS (RRTMG_HIP_LW_TABLE=0: the re-evaluating one)
     static const bool use_tbl = [] { const char *e = std::getenv("RRTMG_HIP_LW_TABLE"); return !(e && e[0] == '0'); }();
     const size_t lds_tbl = (size_t)LW_PAIR_COUNT * 2 * sizeof(double) +
-                           (a.icloud != 0 ? (size_t)RTF_COLS * nl * sizeof(double) : 0);   // (+ the layer cloud fractions)
+                           (a.icloud != 0 ? (size_t)RTF_CLD_COLS * nl * sizeof(double) : 0);   // (+ the layer cloud fractions)
     const bool tbl_fits = lds_tbl <= 160 * 1024 - 256;
     // the three-column transfer kernel holds three column records; beyond what a workgroup may have (very deep
     // columns) the one-column kernel serves the call
@@ -2305,13 +2312,13 @@ hipError_t lw_launch(LwKernelArgs a, int ncol, double *scratch, int cap_cols, hi
         a.nbatch = n;
         hipLaunchKernelGGL(lw_gas_kernel, dim3(n), dim3(LW_THREADS), lds_gas, stream, a);
         if (!a.lwupflx && !deep && use_tbl && tbl_fits) {   // no layer-flux profiles requested: the pair table in LDS
-            const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
-            if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
+            const int nc = rtf_cols(a.icloud != 0), ngrp = (n + nc - 1) / nc;
+            if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_tbl_kernel, dim3(ngrp), dim3(RTF_CLD_THREADS), lds_tbl, stream, a);
             else hipLaunchKernelGGL(lw_rt_fast_tbl_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_tbl, stream, a);
         } else if (!a.lwupflx && fast_fits) {   // no layer-flux profiles requested: what the radiation driver calls
-            const int ngrp = (n + RTF_COLS - 1) / RTF_COLS;
-            if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
-            else if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
+            const int nc = rtf_cols(a.icloud != 0), ngrp = (n + nc - 1) / nc;
+            if (deep) hipLaunchKernelGGL(lw_rt_fast_deep_kernel, dim3(ngrp), dim3(RTF_CLD_THREADS), lds_fast, stream, a);
+            else if (a.icloud != 0) hipLaunchKernelGGL(lw_rt_fast_cld_kernel, dim3(ngrp), dim3(RTF_CLD_THREADS), lds_fast, stream, a);
             else hipLaunchKernelGGL(lw_rt_fast_kernel, dim3(ngrp), dim3(RTF_THREADS), lds_fast, stream, a);
         } else if (deep) hipLaunchKernelGGL(lw_rt_deep_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
         else hipLaunchKernelGGL(lw_rt_kernel, dim3(n), dim3(LW_THREADS), lds_rt, stream, a);
