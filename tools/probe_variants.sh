@@ -8,7 +8,7 @@ cd wrfchem-arc-interactions_amd/csrc
 for v in "$@"; do
   touch lw_kernel.hip sw_kernel.hip optics_kernel.hip
   make -s EXTRA="$v" > ../../$out/build.log 2>&1 || { echo "build failed for [$v]"; tail -5 ../../$out/build.log; continue; }
-  ( cd ../.. && rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 > $out/log.txt 2>&1
+  ( cd ../.. && rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 $BENCH_ARGS > $out/log.txt 2>&1
     f=$(find $out/t -name "*kernel_stats.csv" | head -1)
     echo "== [$v]"; python3 - "$f" <<'PY'
 import csv, sys

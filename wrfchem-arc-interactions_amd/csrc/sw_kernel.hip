@@ -1513,8 +1513,13 @@ __device__ __forceinline__ void sw_column(const SwKernelArgs &a, const int vb, d
 // One workgroup per column of the launch; its scratch slice: the layers' two-stream results [2 waves][nlay][5 x 56]
 // (per layer 56 pairs (ref, refd), 56 pairs (tra, trad), 56 dbt)
 // and the upward sweep's checkpoints [2 waves][nblk][2][56].
+// the McICA instantiations: two waves per SIMD and up to 256 VGPRs (231 used, no spill) -- at three waves and 168 VGPRs
+// they spilled 140 / 220 bytes per lane (15.7 -> 15.1 ms for the 50 000 cloudy columns of the section-8d atmosphere)
+#ifndef SW_CLOUD_WAVES
+#define SW_CLOUD_WAVES 2
+#endif
 template <bool CLOUD, bool PROF>
-__global__ void __launch_bounds__(NTHREADS, SW_WAVES_PER_SIMD) sw_column_kernel(const SwKernelArgs a)
+__global__ void __launch_bounds__(NTHREADS, CLOUD ? SW_CLOUD_WAVES : SW_WAVES_PER_SIMD) sw_column_kernel(const SwKernelArgs a)
 {
     extern __shared__ double lds[];
     double *scr = a.scratch + (size_t)blockIdx.x * a.scratch_stride;
