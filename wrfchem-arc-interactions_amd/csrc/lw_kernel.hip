@@ -397,18 +397,26 @@ __device__ __forceinline__ void gas_prepass(const LwDeviceTables &tb, const LCol
     const bool edges = cf & LC_EDGES;
     const double mult = (cf & LC_MULT4) ? 4. : 8.;
     const int fmode = (cf >> LC_FRAC_SHIFT) & 3;
-    const int l = lane & 15;
+    // the lane number afresh (two instructions) rather than a value carried, in scratch, through the segment loop
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int l = ln & 15;
     const int k = kc + l < kend ? kc + l : kend - 1;
     const double colA = c.mul[spa * nl + k], colB = c.mul[spb * nl + k];
     const bool more = R.minor[1].slot != LS_ZERO || R.minor[2].slot != LS_ZERO;   // wave-uniform (band 13)
+    int msp0 = R.minor[0].nsp, msp1 = R.minor[1].nsp, msp2 = R.minor[2].nsp;
+    double rpl = R.planck_ratio, rm0 = R.minor[0].refrat, rm1 = R.minor[1].refrat, rm2 = R.minor[2].refrat;
+    // scalar reads, not one read through a selected address
+    asm("" : "+s"(msp0), "+s"(msp1), "+s"(msp2), "+s"(rpl), "+s"(rm0), "+s"(rm1), "+s"(rm2));
     for (int round = 0; round < (more ? 2 : 1); ++round) {
-        const int slot = (lane >> 4) + 4 * round;
+        const int slot = (ln >> 4) + 4 * round;
         // the job's species ratio
-        double ratio = R.planck_ratio;                                   // slot 3
-        if (slot <= 1) ratio = c.rat[(rs * 2 + slot) * nl + k];
-        else if (slot == 2) ratio = R.minor[0].refrat;
-        else if (slot == 4) ratio = R.minor[1].refrat;
-        else if (slot == 5) ratio = R.minor[2].refrat;
+        const double rat01 = c.rat[(rs * 2 + (slot & 1)) * nl + k];     // read by every lane: a select of values,
+        double ratio = rpl;                                              // slot 3     not of addresses (flat load)
+        if (slot <= 1) ratio = rat01;
+        else if (slot == 2) ratio = rm0;
+        else if (slot == 4) ratio = rm1;
+        else if (slot == 5) ratio = rm2;
         double speccomb, specparm, f;
         int j;
         spec_idx(colA, ratio, colB, mult, tb.oneminus, speccomb, specparm, j, f);
@@ -439,10 +447,12 @@ __device__ __forceinline__ void gas_prepass(const LwDeviceTables &tb, const LCol
         } else {
             const int m = slot == 2 ? 0 : slot - 3;
             if (m < 3) {
-                const LwMinor &M = R.minor[m];
-                const bool bin = M.nsp > 1;
+                // the three species counts are wave-uniform scalar reads and a lane picks its own (R.minor[m] with
+                // the lane's m is a gather through a per-lane pointer, which the segment loop then keeps in scratch)
+                const int msp = m == 0 ? msp0 : (m == 1 ? msp1 : msp2);
+                const bool bin = msp > 1;
                 ppd[(14 + m) * PP_LAYERS + l] = bin ? f : 0.;
-                ppi[(2 + m) * PP_LAYERS + l] = (c.indm[k] * M.nsp + (bin ? j : 0)) * ng;
+                ppi[(2 + m) * PP_LAYERS + l] = (c.indm[k] * msp + (bin ? j : 0)) * ng;
             }
         }
     }
@@ -1396,10 +1406,9 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
             const int k = act ? kb + dk : kend - 1;
             double2 taug, plfrac;
             gas_item_single(tb, c, R, B.stride, B.off_self, B.off_for, G, k, cont, taug, plfrac);
-            if (act) {
-                st2_stream(tgb + (size_t)k * ng, taug);
-                if (frac_stored) st2_stream(frb + (size_t)k * ng, plfrac);
-            }
+            // no fraction to store: only a binary-species regime interpolates it (checked where the segment order is
+            // made, lw_upload_segments), here it is the g-point's constant, which the transfer kernel takes itself
+            if (act) st2_stream(tgb + (size_t)k * ng, taug);
         }
     }
 #ifdef LW_EXP_CLOCK
