@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid: A/B two versions of one source file on the same GPU box.
-#   bash tools/probe_ab.sh <rounds> <file under csrc> <variant A> <variant B> [<variant C> ...]
+#   [BENCH_ARGS="--cloudy-pass 1"] bash tools/probe_ab.sh <rounds> <file under csrc> <variant A> <variant B> [<variant C> ...]
 rounds=$1; f=$2; shift 2
 out=gpurun_out/probe_ab; mkdir -p $out
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ for r in $(seq $rounds); do
 for v in "$@"; do
   cp $v wrfchem-arc-interactions_amd/csrc/$f
   make -s -C wrfchem-arc-interactions_amd/csrc > $out/build.log 2>&1 || { echo "build failed for $v"; tail -5 $out/build.log; continue; }
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 > $out/log.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t -o t -- python3 bench.py --steps 3 --warmup 1 --no-cpu --host-path-rows 0 --cloudy-pass 0 $BENCH_ARGS > $out/log.txt 2>&1
   fcsv=$(find $out/t -name "*kernel_stats.csv" | head -1)
   echo "== $v"; python3 - "$fcsv" <<'PY'
 import csv, sys

@@ -655,38 +655,34 @@ __device__ __forceinline__ void layer_src_cld(const LwDeviceTables &tb, const do
     double odepth = secdiff * tau;
     odepth = odepth < 0.0 ? 0.0 : odepth;
     double odtot = odepth + odcld;
+    // Each case yields four numbers -- the two absorptivities and the two factors of the Planck differences -- in
+    // local scalars, and the six results are formed from them once, behind the cases.  (Assigning the fields of `o` in
+    // every case made the compiler merge the cases' stores into one store through a *selected address*; the record
+    // then lived in scratch memory, with vector-memory stores and loads in the middle of the sweeps.)
+    double atrans, atot, fgas, ftot;
     if (odtot < 0.06) {
-        o.atrans = odepth - 0.5 * odepth * odepth;
-        const double odepth_rec = rec_6 * odepth;
-        o.atot = odtot - 0.5 * odtot * odtot;
-        const double odtot_rec = rec_6 * odtot;
-        o.bbdtot = plfrac * (blay + dplankdn * odtot_rec);
-        o.bbd = plfrac * (blay + dplankdn * odepth_rec);
-        o.bbugas = plfrac * (blay + dplankup * odepth_rec);
-        o.bbutot = plfrac * (blay + dplankup * odtot_rec);
+        atrans = odepth - 0.5 * odepth * odepth;
+        fgas = rec_6 * odepth;
+        atot = odtot - 0.5 * odtot * odtot;
+        ftot = rec_6 * odtot;
     } else if (odepth <= 0.06) {
-        o.atrans = odepth - 0.5 * odepth * odepth;
-        const double odepth_rec = rec_6 * odepth;
-        double tt, atot, tfactot;
-        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, tfactot);
-        o.bbdtot = plfrac * (blay + tfactot * dplankdn);
-        o.bbd = plfrac * (blay + dplankdn * odepth_rec);
-        o.atot = atot;
-        o.bbugas = plfrac * (blay + dplankup * odepth_rec);
-        o.bbutot = plfrac * (blay + tfactot * dplankup);
+        atrans = odepth - 0.5 * odepth * odepth;
+        fgas = rec_6 * odepth;
+        double tt;
+        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, ftot);
     } else {
-        double tgas, agas, tfacgas;
-        lw_tbl_entry<USE_TBL, true>(tb, ltbl, odepth, tgas, agas, tfacgas);
-        o.atrans = agas;
+        double tgas;
+        lw_tbl_entry<USE_TBL, true>(tb, ltbl, odepth, tgas, atrans, fgas);
         odtot = tgas + odcld;            // odepth = tau_tbl(itgas), LW:3262
-        double tt, atot, tfactot;
-        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, tfactot);
-        o.bbdtot = plfrac * (blay + tfactot * dplankdn);
-        o.bbd = plfrac * (blay + tfacgas * dplankdn);
-        o.atot = atot;
-        o.bbugas = plfrac * (blay + tfacgas * dplankup);
-        o.bbutot = plfrac * (blay + tfactot * dplankup);
+        double tt;
+        lw_tbl_entry<USE_TBL, false>(tb, ltbl, odtot, tt, atot, ftot);
     }
+    o.atrans = atrans;
+    o.atot = atot;
+    o.bbdtot = plfrac * (blay + ftot * dplankdn);
+    o.bbd = plfrac * (blay + fgas * dplankdn);
+    o.bbugas = plfrac * (blay + fgas * dplankup);
+    o.bbutot = plfrac * (blay + ftot * dplankup);
 }
 
 // cloud absorption optical depth of a cloudy sub-column layer: cldprmc, LW:2800-2908 (inflag >= 2, liqflag 1,
