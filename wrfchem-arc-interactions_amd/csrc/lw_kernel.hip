@@ -270,12 +270,16 @@ __device__ __forceinline__ void spec_idx(double cola, double ratio, double colb,
     f = specmult - (double)j;
 }
 
-// Band descriptors for the gas-optics segments: entry ib is the LwGDesc of the band's FIRST g-point (offsets of
-// g-point ig are + ig), read with a wave-uniform index, i.e. into scalar registers; c_lwseg_order lists the 32
-// (band, regime) segments (2 ib + upper), costliest first.
-__constant__ LwGDesc c_lwband[LW_NBND];
-__constant__ int c_lwband_g0[LW_NBND];
-__constant__ int c_lwseg_order[2 * LW_NBND];
+// The 32 (band, regime) segments of the gas optics, costliest first: the regime of the band's FIRST g-point (offsets of
+// g-point ig are + ig) and the band's numbers, in ONE record per segment, read with a wave-uniform index, i.e. into
+// scalar registers.  One record, one symbol: a wave that has claimed a segment is two dependent scalar reads away from
+// everything it needs (the symbol's address, then the fields) -- as three tables (order, band, first g-point) it was
+// six.
+struct LwSegRec {
+    LwRegime R;
+    int32_t upper, g0, ng, stride, off_self, off_for;
+};
+__constant__ LwSegRec c_lwseg[2 * LW_NBND];
 
 // A lane of the gas optics owns TWO neighbouring g-points (ig, ig + 1; every band has an even number): each of its
 // table reads is then one 16-byte load -- the kernel is bound by the rate at which the vector cache takes gather
@@ -1327,13 +1331,12 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         if (lane == 0) seg = atomicAdd(&s_nextseg, 1);
         seg = __builtin_amdgcn_readfirstlane(seg);
         if (seg >= 2 * LW_NBND) break;
-        const int sid = c_lwseg_order[seg];
-        const int ib = sid >> 1, upper = sid & 1;
+        const LwSegRec &B = c_lwseg[seg];
+        const LwRegime &R = B.R;
+        const int upper = B.upper;
         const int kbeg = upper ? ltrop : 0, kend = upper ? nl : ltrop;
         if (kbeg >= kend) continue;
-        const LwGDesc &B = c_lwband[ib];
-        const LwRegime &R = upper ? B.up : B.lo;
-        const int ng = B.ng, g0 = c_lwband_g0[ib];
+        const int ng = B.ng, g0 = B.g0;
         const int np = ng >> 1;                 // g-point pairs of the band: a lane owns one pair of one layer
         const int lpi = 64 / np;
         const int dk = lane / np;
@@ -1359,13 +1362,32 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         if (c.cont && (R.cfg & (LC_SELF | LC_FOR))) {
             double *cw = c.cont + (size_t)wave * CONT_DOUBLES;
             __builtin_amdgcn_wave_barrier();   // the previous segment's items have read their rows
-            for (int it = lane; it < (CONT_SELF_ROWS + CONT_FOR_ROWS) * np; it += 64) {
-                const int row = it / np, pr = it - row * np;
+            // At most 14 x 8 = 112 (row, pair) items: two per lane, both reads issued before either is stored -- one
+            // trip to memory per segment.  (As a loop with the band's offsets picked per lane, the compiler read
+            // the picked offset through a per-lane pointer first: two dependent trips per turn, two turns.)
+            static_assert((CONT_SELF_ROWS + CONT_FOR_ROWS) * (16 / 2) <= 128, "two items per lane");
+            int o_self = B.off_self, o_for = B.off_for, strd = B.stride;
+            asm("" : "+s"(o_self), "+s"(o_for), "+s"(strd));
+            const int nitem = (CONT_SELF_ROWS + CONT_FOR_ROWS) * np;
+            const bool has_self = R.cfg & LC_SELF;
+            double2 cv[2];
+            int cdst[2];
+            bool cok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int it = lane + 64 * u;
+                const int itc = it < nitem ? it : nitem - 1;
+                const int row = itc / np, pr = itc - row * np;
                 const bool self = row < CONT_SELF_ROWS;
-                if (self && !(R.cfg & LC_SELF)) continue;
-                const double *src = tb.K + (self ? B.off_self + row * B.stride : B.off_for + (row - CONT_SELF_ROWS) * B.stride) + 2 * pr;
-                *reinterpret_cast<double2 *>(cw + row * CONT_STRIDE + 2 * pr) = ld2(src);
+                cok[u] = it < nitem && (has_self || !self);
+                // (a self row of a band without self continuum is not stored; its lane reads a foreign row instead)
+                const int off = self && has_self ? o_self + row * strd : o_for + (self ? 0 : row - CONT_SELF_ROWS) * strd;
+                cv[u] = ld2(tb.K + off + 2 * pr);
+                cdst[u] = row * CONT_STRIDE + 2 * pr;
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (cok[u]) *reinterpret_cast<double2 *>(cw + cdst[u]) = cv[u];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             cont = cw;
@@ -2203,10 +2225,14 @@ hipError_t lw_upload_segments(const LwGDesc *gdesc)
     }
     if (g != LW_NGPT) return hipErrorInvalidValue;
     std::stable_sort(order, order + 2 * LW_NBND, [&](int x, int y) { return cost[x] > cost[y]; });
-    hipError_t e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lwband), band, sizeof band)) != hipSuccess) return e;
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_lwband_g0), g0, sizeof g0)) != hipSuccess) return e;
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_lwseg_order), order, sizeof order);
+    LwSegRec rec[2 * LW_NBND];
+    for (int s = 0; s < 2 * LW_NBND; ++s) {
+        const int ib = order[s] >> 1, up = order[s] & 1;
+        rec[s].R = up ? band[ib].up : band[ib].lo;
+        rec[s].upper = up; rec[s].g0 = g0[ib]; rec[s].ng = band[ib].ng; rec[s].stride = band[ib].stride;
+        rec[s].off_self = band[ib].off_self; rec[s].off_for = band[ib].off_for;
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_lwseg), rec, sizeof rec);
 }
 
 hipError_t lw_upload_constants(const double *preflog, const double *tref)
