@@ -1041,10 +1041,18 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         const double *X = tb.chi_mls;   // [7][59]
 #define CHI(m, l) X[((m)-1) * 59 + (l)-1]
         // chi_mls ratios at jp and jp + 1 from the tabulated quotients (lw_tables.hip: [LR_*][59] behind the 7 x 59)
+        // all fourteen reads first (left to itself the compiler serialises them, read -> wait -> LDS store, to save
+        // registers the set-up has to spare)
+        double ra[6], rb[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { ra[r] = X[7 * 59 + r * 59 + jp - 1]; rb[r] = X[7 * 59 + r * 59 + jp]; }
+        double chin2o = CHI(4, jp + 1), chico2 = CHI(2, jp + 1);
+        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(rb[0]),
+                          "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(chin2o), "+v"(chico2));
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            c.rat[(r * 2 + 0) * nl + k] = X[7 * 59 + r * 59 + jp - 1];
-            c.rat[(r * 2 + 1) * nl + k] = X[7 * 59 + r * 59 + jp];
+            c.rat[(r * 2 + 0) * nl + k] = ra[r];
+            c.rat[(r * 2 + 1) * nl + k] = rb[r];
         }
         c.rat[(LR_ONE * 2 + 0) * nl + k] = 1.;
         c.rat[(LR_ONE * 2 + 1) * nl + k] = 1.;
@@ -1061,7 +1069,6 @@ __global__ void __launch_bounds__(LW_THREADS) __attribute__((amdgpu_waves_per_eu
         c.mul[LS_H2O * nl + k] = colh2o; c.mul[LS_CO2 * nl + k] = colco2; c.mul[LS_O3 * nl + k] = colo3;
         c.mul[LS_N2O * nl + k] = coln2o; c.mul[LS_CO * nl + k] = colco; c.mul[LS_CH4 * nl + k] = colch4;
         c.mul[LS_O2 * nl + k] = colo2; c.mul[LS_BRD * nl + k] = colbrd; c.mul[LS_ZERO * nl + k] = 0.;
-        const double chin2o = CHI(4, jp + 1), chico2 = CHI(2, jp + 1);
         c.mul[LS_ADJ_N2O * nl + k] = adjcol(coln2o, coldry, chin2o, 1.5, 0.5, 0.65);
         c.mul[LS_ADJ_CO2_6 * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 2.0, 0.77);
         c.mul[LS_ADJ_CO2_7L * nl + k] = adjcol(colco2, coldry, chico2, 3.0, 3.0, 0.79);
